@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (aleflabo/MoCoDAD) on CPU.
+
+Run in the build container only (needs /root/reference, which does not exist on the
+GPU box):   python tests/golden/gen_golden.py
+
+The reference ships no tests, fixtures or pretrained weights, so every
+pin below is produced by the reference's own modules:
+  models/mocodad.py (MoCoDAD.forward :129-184), models/stsae/stsae_unet.py,
+  models/stsae/stsae.py, models/gcae/stsgcn.py, utils/diffusion_utils.py,
+  utils/model_utils.py (processing_data), models/mocodad.py (post_processing :337-430)
+with seeded random-init weights whose BatchNorm running stats / affine and PReLU slopes
+are perturbed (so that BN folding mistakes show), seeded inputs, and noise injected by
+monkey-patching torch.randn_like so that the same noise can be fed to the oracle and
+to the HIP path.
+
+Only DATA is written (npz of inputs / expected outputs / the random-init state_dict);
+no reference source text is stored.  pytorch_lightning is absent from this image, so a
+10-line stub LightningModule(nn.Module) is injected into sys.modules for the import.
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+REF = os.environ.get("MOCODAD_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_lightning_stub():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._dev = torch.device("cpu")
+
+        @property
+        def device(self):
+            return self._dev
+
+        def log(self, *a, **k):
+            pass
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def on_test_epoch_start(self):
+            pass
+
+        def on_validation_epoch_start(self):
+            pass
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+
+
+def make_args(strategy="inject", seg_len=6, cond_idx=(0, 1, 2), noise_steps=10, n_gen=5,
+              aggr="best", ret="loss", gt_path="/tmp/none", dataset="HR-Avenue"):
+    cfg = yaml.load(open(os.path.join(REF, "config/Avenue/mocodad_test.yaml")), Loader=yaml.FullLoader)
+    cfg.update(dict(conditioning_strategy=strategy, seg_len=seg_len,
+                    conditioning_indices=list(cond_idx) if not isinstance(cond_idx, int) else cond_idx,
+                    noise_steps=noise_steps, n_generated_samples=n_gen, aggregation_strategy=aggr,
+                    model_return_value=ret, accelerator="cpu", dataset_choice=dataset,
+                    save_tensors=False, test_path=gt_path))
+    args = argparse.Namespace(**cfg)
+    # what utils/argparser.init_args derives (argparser.py:4-28), without touching the filesystem
+    args.gt_path = args.test_path
+    args.ckpt_dir = "/tmp/mocodad_golden_ckpt"
+    return args, cfg
+
+
+def perturb_(model, gen):
+    """Randomise BN running stats/affine + PReLU slopes so eval-mode BN is not the identity."""
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+        if isinstance(m, nn.PReLU):
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen) * 0.3 + 0.1)
+
+
+def tame_(model, gain):
+    """Scale the last U-Net layer so that the random-init eps-prediction stays O(1) and the
+    reverse chain (cumulative gain 201x at ns=10, 1014x at ns=50) does not overflow."""
+    last = model.model.st_gcnnsu3[-1]
+    with torch.no_grad():
+        last.tcn[0].weight.mul_(gain)
+        last.residual[0].weight.mul_(gain)
+
+
+class NoiseFeeder:
+    """Replaces torch.randn_like: pops pre-drawn tensors in call order (mocodad.py:162,176)."""
+
+    def __init__(self, noise):  # noise: (S, ns-1, B, C, Tx, V); slot 0 = x_T, slots 1.. = z for i=ns-1..2
+        self.noise = noise
+        self.calls = 0
+
+    def __call__(self, ref, **kw):
+        S, K = self.noise.shape[:2]
+        s, k = divmod(self.calls, K)
+        self.calls += 1
+        out = self.noise[s, k]
+        assert out.shape == ref.shape, (out.shape, ref.shape)
+        return out.clone()
+
+
+def synth_windows(B, seg_len, gen):
+    """Smooth random-walk pose windows, roughly robust-scaled."""
+    base = torch.randn(B, 2, 1, 17, generator=gen)
+    steps = torch.randn(B, 2, seg_len, 17, generator=gen) * 0.15
+    x = base + torch.cumsum(steps, dim=2)
+    return x.clamp_(-5, 5).float().contiguous()
+
+
+def fp16_round(t):
+    return t.half().float()
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def state_to_np(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def main():
+    _install_lightning_stub()
+    sys.path.insert(0, REF)
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    from models.mocodad import MoCoDAD  # noqa: E402
+    from utils.diffusion_utils import Diffusion  # noqa: E402
+    from utils.model_utils import processing_data  # noqa: E402
+
+    # ---------------------------------------------------------------- 5. schedules
+    sched = {}
+    for ns in (2, 10, 50):
+        d = Diffusion(noise_steps=ns, device="cpu", time=6, n_joints=17)
+        sched[f"beta_{ns}"] = d.beta
+        sched[f"alpha_{ns}"] = d.alpha
+        sched[f"alpha_hat_{ns}"] = d.alpha_hat
+    save("schedule.npz", **sched)
+
+    variants = {
+        # name: (strategy, seg_len, cond_idx)
+        "inject": ("inject", 6, (0, 1, 2)),
+        "concat": ("concat", 6, (0, 1, 2)),
+        "T12": ("inject", 24, 2),      # int 2 -> first 24//2 = 12 frames condition (mocodad.py:738-739,782)
+        "injtail": ("inject", 6, (3, 4, 5)),   # conditioning on the LAST frames (mocodad.py:786)
+    }
+    traj_cases = {
+        "inject": [(2, 1, 16), (10, 5, 16), (50, 8, 4)],
+        "concat": [(10, 5, 8)],
+        "T12": [(10, 2, 4)],
+        "injtail": [(10, 2, 4)],
+    }
+
+    for vname, (strategy, seg_len, cond_idx) in variants.items():
+        gen = torch.Generator().manual_seed(1234 + len(vname))
+        args, cfg = make_args(strategy=strategy, seg_len=seg_len, cond_idx=cond_idx)
+        torch.manual_seed(42 + len(vname))
+        model = MoCoDAD(args).eval()
+        perturb_(model, gen)
+        tame_(model, 0.25)
+        sd = state_to_np(model)
+        save(f"weights_{vname}.npz", __cfg__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **sd)
+
+        unet = model.model
+        Tu = model.input_n_frames
+        # ------------------------------------------------ 2. layer-level I/O (B=4)
+        if vname in ("inject", "concat"):
+            B = 4
+            lay = {}
+            e = torch.randn(B, 16, generator=gen)
+            lay["emb_in"] = e
+            blocks = [("st_gcnnsp1a", 0), ("st_gcnnsd1", 0), ("st_gcnnsd1", 1), ("st_gcnnsd2", 0),
+                      ("st_gcnnsd2", 1), ("st_gcnnsd3", 0), ("st_gcnnsd3", 1), ("st_gcnnsu4", 0),
+                      ("st_gcnnsu4", 1), ("st_gcnnsu3", 0), ("st_gcnnsu3", 1)]
+            for bi, (bn, li) in enumerate(blocks):
+                layer = getattr(unet, bn)[li]
+                x = torch.randn(B, layer.in_channels, Tu, layer.joints_dim, generator=gen)
+                lay[f"L{bi}_in"] = x
+                lay[f"L{bi}_out"] = layer(x, e)
+                lay[f"L{bi}_out_noemb"] = layer(x, None)
+                lay[f"L{bi}_gcn"] = layer.gcn(x)
+            for rn in ("down1", "down2", "up3", "up2"):
+                cl = getattr(unet, rn)
+                vin = cl.block[0].in_channels
+                ch = {"down1": 32, "down2": 64, "up3": 64, "up2": 32}[rn]
+                x = torch.randn(B, ch, Tu, vin, generator=gen)
+                lay[f"{rn}_in"] = x
+                # exactly the call pattern of stsae_unet.py:205,213,381,391
+                lay[f"{rn}_out"] = cl(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+            tt = torch.tensor([1.0, 2.0, 5.0, 9.0])[:, None]
+            lay["posenc_t"] = tt
+            lay["posenc_out"] = unet.pos_encoding(tt, 16)
+            if model.condition_encoder is not None:
+                cdat = synth_windows(B, model.n_frames_condition, gen)
+                lay["cond_in"] = cdat
+                emb, rec = model.condition_encoder(cdat, t=None)
+                lay["cond_emb"] = emb
+                lay["cond_rec"] = rec
+            save(f"layers_{vname}.npz", **lay)
+
+        # ------------------------------------------------ 3. pass-level (x, t, cond) -> eps
+        B = 8
+        ps = {}
+        x = torch.randn(B, 2, Tu, 17, generator=gen)
+        cond = torch.randn(B, 16, generator=gen) * 0.5 if strategy == "inject" else None
+        ps["x"] = x
+        if cond is not None:
+            ps["cond"] = cond
+        for tval in (1, 9):
+            t = torch.full((B,), tval, dtype=torch.long)
+            eps, _ = unet(x, t, condition_data=cond)
+            ps[f"eps_t{tval}"] = eps
+        save(f"pass_{vname}.npz", **ps)
+
+        # ------------------------------------------------ 4. trajectory-level
+        for (ns, S, B) in traj_cases[vname]:
+            args2, _ = make_args(strategy=strategy, seg_len=seg_len, cond_idx=cond_idx,
+                                 noise_steps=ns, n_gen=S, aggr="all", ret="all")
+            m2 = MoCoDAD(args2).eval()
+            m2.load_state_dict(model.state_dict())
+            data = synth_windows(B, seg_len, gen)
+            Tx = m2.n_frames_corrupt
+            noise = fp16_round(torch.randn(S, max(ns - 1, 1), B, 2, Tx, 17, generator=gen))
+            trans = torch.arange(B) % 5
+            meta = torch.stack([torch.ones(B), torch.arange(B) // 4 + 1, torch.arange(B) % 3 + 1,
+                                torch.arange(B) * 2 + 1], 1).long()
+            frames = (meta[:, 3:4] + torch.arange(seg_len)[None]).int()
+            batch = [data, trans, meta, frames]
+
+            # capture x after every reverse step through a hook on the U-Net input
+            xs_in = []
+            hook = m2.model.register_forward_pre_hook(lambda mod, inp: xs_in.append(inp[0].clone()))
+            feeder = NoiseFeeder(noise)
+            orig = torch.randn_like
+            torch.randn_like = feeder
+            try:
+                out_all = m2.forward(batch, aggr_strategy="all", return_="all")
+            finally:
+                torch.randn_like = orig
+                hook.remove()
+            assert feeder.calls == S * max(ns - 1, 1) if ns > 2 else feeder.calls == S, feeder.calls
+            loss_all, poses_all = out_all[0], out_all[1]          # (B,S), (B,S,2,Tx,17)
+            tr = dict(data=data, noise=noise.half(), trans=trans, meta=meta, frames=frames,
+                      loss_all=loss_all, poses_all=poses_all)
+            if B * S * ns <= 16 * 5 * 10:
+                tr["unet_inputs"] = torch.stack(xs_in)           # (S*(ns-1), B, 2, Tu, 17)
+            for aggr in ("best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3"):
+                feeder = NoiseFeeder(noise)
+                torch.randn_like = feeder
+                try:
+                    o = m2.forward(batch, aggr_strategy=aggr, return_="all")
+                finally:
+                    torch.randn_like = orig
+                key = aggr.replace(":", "_").replace(".", "p")
+                tr[f"loss_{key}"] = o[0]
+                if o[1] is not None:
+                    tr[f"pose_{key}"] = o[1]
+            if m2.condition_encoder is not None:
+                cd, _, _ = m2._select_frames(data)
+                tr["cond_emb"] = m2.condition_encoder(cd, t=None)[0]
+            save(f"traj_{vname}_ns{ns}_S{S}.npz", **tr)
+
+    # ---------------------------------------------------------------- 6. host post-processing
+    import tempfile
+    rng = np.random.default_rng(7)
+    gtdir = tempfile.mkdtemp(prefix="mocodad_gt_")
+    clips = [(1, 1, 60), (1, 2, 48)]           # (scene, clip, n_frames); clip ids 1,2 are HR-Avenue masked clips
+    # use clip ids that are NOT in get_avenue_mask() (eval_utils.py:152-166) so lengths are free
+    clips = [(1, 4, 60), (1, 5, 48)]
+    gts = {}
+    for sc, cl, nf in clips:
+        g = np.zeros(nf, dtype=np.int64)
+        a = rng.integers(5, nf - 15)
+        g[a:a + 10] = 1
+        gts[f"{sc:02d}_{cl:04d}"] = g
+        np.save(os.path.join(gtdir, f"{sc:02d}_{cl:04d}.npy"), g)
+    rows = []
+    seg_len = 6
+    for tr_i in range(5):
+        for sc, cl, nf in clips:
+            for person in (1, 2, 3):
+                start = int(rng.integers(1, 8))
+                stop = nf - int(rng.integers(0, 6))
+                for f0 in range(start, stop - seg_len + 2):
+                    rows.append((tr_i, sc, cl, person, f0))
+    rows = np.array(rows)
+    N = len(rows)
+    out = rng.gamma(2.0, 0.05, size=N).astype(np.float32)
+    trans = rows[:, 0].copy()
+    meta = rows[:, 1:5].copy()
+    frames = (rows[:, 4:5] + np.arange(seg_len)[None]).astype(np.int32)
+    gt_data = rng.standard_normal((N, 2, seg_len, 17)).astype(np.float32)
+    pp = dict(out=out, trans=trans, meta=meta, frames=frames, gt_data=gt_data)
+    for k, g in gts.items():
+        pp[f"gt_{k}"] = g
+    for tag, (dataset, pad, ks, shift) in {"avenue": ("HR-Avenue", 12, 30, 6), "stc": ("HR-STC", -1, 15, 9)}.items():
+        args3, _ = make_args(gt_path=gtdir, dataset=dataset)
+        args3.pad_size, args3.filter_kernel_size, args3.frames_shift = pad, ks, shift
+        m3 = MoCoDAD(args3).eval()
+        pp[f"auc_{tag}"] = np.float64(m3.post_processing(out.copy(), gt_data, trans, meta, frames))
+        pp[f"params_{tag}"] = np.array([pad, ks, shift])
+    # processing_data (utils/model_utils.py:110-137) on a 2-batch split
+    half = N // 2
+    lst = [[torch.from_numpy(a[:half]) for a in (out, gt_data, trans, meta, frames)],
+           [torch.from_numpy(a[half:]) for a in (out, gt_data, trans, meta, frames)]]
+    o2 = processing_data(lst)
+    assert all(np.array_equal(a, b) for a, b in zip(o2, (out, gt_data, trans, meta, frames)))
+    del pp["gt_data"]  # big and unused by post_processing's score path; regenerated in the test
+    save("postproc.npz", **pp)
+
+
+if __name__ == "__main__":
+    main()
