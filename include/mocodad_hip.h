@@ -1,0 +1,136 @@
+/*
+ * mocodad_hip.h — C ABI of the MI355X-native MoCoDAD anomaly-scoring path (libmocodad_hip.so).
+ *
+ * The reference (aleflabo/MoCoDAD) is pure Python/PyTorch and has no FFI; the seam it offers is the
+ * Python module surface of models/mocodad.py.  These entry points are what a maintainer binds with
+ * ctypes from that surface; each cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MCD_E* code; mcd_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI.
+ *   - the CALLER owns every buffer (device pointers unless stated "host"); the library owns only
+ *     mcd_weights_t.  All tensors are dense row-major float32 in the reference's own layouts.
+ *   - compute entry points are asynchronous on the caller's hipStream_t (passed as void*), perform no
+ *     allocation and no host synchronisation, and are re-entrant across streams and devices.
+ *   - there is NO CPU fallback: without a gfx950 device these calls fail with MCD_EDEVICE.
+ */
+#ifndef MOCODAD_HIP_H
+#define MOCODAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCD_ABI_VERSION 1
+
+enum {
+    MCD_OK = 0,
+    MCD_EINVAL = -1,      /* bad argument / unsupported shape */
+    MCD_EMISSING = -2,    /* a state_dict tensor is missing or has the wrong size */
+    MCD_EDEVICE = -3,     /* HIP error (no device, launch failure, ...) */
+    MCD_EUNSUPPORTED = -4 /* configuration the kernels do not cover (message says which) */
+};
+
+/* conditioning strategy of models/mocodad.py:24-29,100-126 (canonical names) */
+enum { MCD_STRATEGY_INJECT = 0, MCD_STRATEGY_CONCAT = 1, MCD_STRATEGY_NO_CONDITION = 2 };
+/* loss_fn of models/mocodad.py:24,66 (reduction='none', mean over C*Tx*V at :484) */
+enum { MCD_LOSS_SMOOTH_L1 = 0, MCD_LOSS_L1 = 1, MCD_LOSS_MSE = 2 };
+/* aggregation strategy of models/mocodad.py:454-520 */
+enum {
+    MCD_AGGR_ALL = 0, MCD_AGGR_BEST = 1, MCD_AGGR_WORST = 2, MCD_AGGR_MEAN = 3, MCD_AGGR_MEDIAN = 4,
+    MCD_AGGR_MEAN_POSE = 5, MCD_AGGR_MEDIAN_POSE = 6, MCD_AGGR_QUANTILE = 7
+};
+
+#define MCD_MAX_FRAMES 32
+#define MCD_MAX_COND_LAYERS 8
+
+/* One named fp32 tensor of the Lightning checkpoint's state_dict (HOST memory).  Names are the
+ * reference's own keys: "model.st_gcnnsd1.0.tcn.0.weight", "condition_encoder.btlnk.bias", ... */
+typedef struct {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} mcd_tensor_t;
+
+/* Architecture, as MoCoDAD.build_model derives it (models/mocodad.py:90-126, stsae_unet.py:254-357). */
+typedef struct {
+    int32_t num_coords;   /* C: 2 */
+    int32_t n_joints;     /* V: 17 (the U-Net hard-wires 17/12/10, stsae_unet.py:11) */
+    int32_t t_unet;       /* frames the U-Net runs on: n_frames_corrupt (inject) or seg_len (concat/no_condition) */
+    int32_t t_cond;       /* condition frames seen by the condition encoder (0 when there is none) */
+    int32_t emb_dim;      /* embedding_dim == latent_dim: 16 */
+    int32_t strategy;     /* MCD_STRATEGY_* */
+    int32_t cond_layers;  /* ST-GCN layers of the condition encoder: len(channels)+1 */
+    int32_t cond_channels[MCD_MAX_COND_LAYERS]; /* their output channels: channels + [h_dim] */
+} mcd_model_cfg_t;
+
+/* One scoring call = MoCoDAD.forward on one batch (models/mocodad.py:129-184). */
+typedef struct {
+    int32_t n_windows;    /* B */
+    int32_t n_samples;    /* n_generated_samples S */
+    int32_t noise_steps;  /* ns: ns-1 denoiser passes per sample (mocodad.py:163) */
+    int32_t seg_len;      /* T of the data tensor (B,C,T,V) */
+    int32_t n_cond;       /* len(cond_idx)   (0 for no_condition) */
+    int32_t n_corrupt;    /* len(corrupt_idx) */
+    int32_t cond_idx[MCD_MAX_FRAMES];     /* frame indices selected at mocodad.py:743-748 */
+    int32_t corrupt_idx[MCD_MAX_FRAMES];
+    int32_t loss_fn;      /* MCD_LOSS_* */
+} mcd_score_cfg_t;
+
+typedef struct mcd_weights mcd_weights_t;
+
+/* Replaces: LightningModule.load_state_dict + model.eval() (eval_MoCoDAD.py:36-38).
+ * Folds every eval-mode BatchNorm2d into the preceding 1x1 conv (stsgcn.py:57-80,181-182), repacks the
+ * channel-mixing matrices into MFMA fragment order and uploads them to `device`. */
+int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_model_cfg_t* cfg,
+                     int32_t device, mcd_weights_t** out);
+void mcd_free_weights(mcd_weights_t* w);
+
+/* Replaces: MoCoDAD._encode_condition -> STSAE/STSE.encode (mocodad.py:546-560, stsae.py:59-92).
+ * cond_data (B,C,t_cond,V) -> emb_out (B,emb_dim).  The AE decoder (dead work at eval) is not run. */
+int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_windows, float* emb_out,
+                    void* stream);
+
+/* Replaces: STSAE_Unet.forward (stsae_unet.py:406-438) for one timestep shared by the batch.
+ * x (B,C,t_unet,V), step_table row `t` (see mcd_score), cond (B,emb_dim) or NULL -> eps_out (B,C,t_unet,V). */
+int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table,
+                     int32_t t, int32_t n_windows, float* eps_out, void* stream);
+
+/* Bytes of caller-provided device scratch mcd_score needs (condition embeddings). */
+int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
+
+/* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.
+ *   data        (B,C,T,V) windows
+ *   noise       NULL -> in-kernel Philox4x32-10 keyed by (seed, first_window_id+b, s, step, element);
+ *               else (S, max(ns-1,1), B, C, Tx, V): slot 0 = x_T, slot k = z added at step i = ns-k
+ *               (what torch.randn_like returns at mocodad.py:162,176 in call order)
+ *   step_table  (ns, 4+emb_dim): row i = [1/sqrt(alpha_i), (1-alpha_i)/sqrt(1-alpha_hat_i), sqrt(beta_i), 0,
+ *               pos_encoding(i)[0..emb_dim)]  (mocodad.py:172-178, stsae_unet.py:173-179)
+ *   loss_out    (B,S)  per-sample window loss
+ *   pose_out    NULL or (B,S,C,Tx,V) generated x_0 */
+int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise,
+              uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+              float* loss_out, float* pose_out, void* stream);
+
+/* Replaces: MoCoDAD._aggregation_strategy (mocodad.py:454-520) on the (B,S) losses / (B,S,C,Tx,V) poses.
+ * data/cfg give the ground-truth corrupt frames for the *_pose strategies.  loss_agg (B,), pose_agg
+ * NULL or (B,C,Tx,V).  MCD_AGGR_ALL is the identity and is not handled here. */
+int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,
+                  const float* loss_all, const float* pose_all, const float* data, float* loss_agg,
+                  float* pose_agg, void* stream);
+
+/* Frame-score assembly that follows the path (mocodad.py:386-401 + eval_utils.py:27-34): scatter-max of
+ * window scores to their frames.  scores (N,), frames (N,seg_len) 1-based int32, row (N,) int32 = output
+ * row (one per (transform, clip, person)), out (n_rows, n_frames) pre-zeroed by the callee. */
+int mcd_scatter_max(const float* scores, const int32_t* frames, const int32_t* row, int64_t n, int32_t seg_len,
+                    int32_t n_rows, int32_t n_frames, float* out, void* stream);
+
+const char* mcd_last_error(void);
+int32_t mcd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCODAD_HIP_H */

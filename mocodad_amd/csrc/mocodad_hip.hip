@@ -1,0 +1,1143 @@
+// mocodad_hip.hip — MI355X (gfx950 / CDNA4) kernels + C ABI for the MoCoDAD anomaly-scoring path.
+//
+// What runs here (reference: /root/reference, Python/PyTorch):
+//   MoCoDAD.forward hot loop            models/mocodad.py:155-180      -> score_kernel (persistent, one
+//   STSAE_Unet.forward                  models/stsae/stsae_unet.py:406-438   launch for all S*(ns-1) passes)
+//   ST_GCNN_layer / ConvTemporalGraphical / CNN_layer  models/gcae/stsgcn.py:94-199
+//   DDPM ancestral update + SmoothL1    models/mocodad.py:172-178,484
+//   STSE.encode (condition encoder)     models/stsae/stsae.py:59-92    -> cond_encode_kernel
+//   _aggregation_strategy               models/mocodad.py:454-520      -> aggregate_kernel
+//
+// Design: one 512-thread workgroup owns NB reverse-diffusion chains (a chain = one
+// (window, sample) pair) for their whole trajectory.  Activations live in LDS as [column][channel]
+// (column = (chain, frame, joint), channel fastest, row stride = C+4 floats = 4*odd so that the b64
+// MFMA-operand reads and the b128 epilogue stores are bank-conflict free).  Per ST-GCN layer:
+//   mix     VALU: lane = (chain, channel), the learned time-mix T[v,t,q] and joint-mix A[q,v,w]
+//           coefficients are wave-uniform (scalar loads), data is lane-private
+//   GEMM    the 1x1 channel convolutions (tcn + residual, BatchNorm folded) as one K-concatenated
+//           [W_t | W_r] x [Z ; X] product on v_mfma_f32_16x16x4_f32 (exact fp32), weights pre-packed in
+//           fragment order and streamed from L2 straight into registers
+//   epilog  +bias, (+identity residual), PReLU, + SiLU-Linear embedding, b128 store back to LDS
+// U-Net skip tensors d1/d2 stay in the accumulator registers of the waves that produced them.
+// Everything is fp32 (the reverse chain amplifies error by up to 1e3).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+
+#include "../../include/mocodad_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NTHREADS = 512;
+constexpr int NWAVES = 8;
+constexpr int C0 = 2;        // num_coords
+constexpr int EDIM = 16;     // embedding_dim
+constexpr int NLAYERS = 11;  // ST-GCN layers of the U-Net
+constexpr int EMB_TOTAL = 532;  // sum of C_out over the 11 layers, last padded to 4
+constexpr int EMB_STRIDE = 536;
+
+__host__ __device__ constexpr int cs_of(int c) { return c + 4; }      // LDS row stride for c channels (4*odd)
+__host__ __device__ constexpr int ceil16(int x) { return (x + 15) / 16 * 16; }
+
+// channel plan of STSAE_Unet (stsae_unet.py:255-357 defaults; mocodad.py:121-124 never overrides them)
+struct LDesc { int cin, cout, V, res; };
+__host__ __device__ constexpr LDesc layer_desc(int l) {
+    return l == 0 ? LDesc{2, 16, 17, 1} : l == 1 ? LDesc{16, 32, 17, 1} : l == 2 ? LDesc{32, 32, 17, 0}
+         : l == 3 ? LDesc{32, 64, 12, 1} : l == 4 ? LDesc{64, 64, 12, 0} : l == 5 ? LDesc{64, 128, 10, 1}
+         : l == 6 ? LDesc{128, 64, 10, 1} : l == 7 ? LDesc{64, 64, 12, 0} : l == 8 ? LDesc{64, 32, 12, 1}
+         : l == 9 ? LDesc{32, 32, 17, 0} : LDesc{32, 2, 17, 1};
+}
+__host__ __device__ constexpr int emb_off(int l) {
+    return l == 0 ? 0 : l == 1 ? 16 : l == 2 ? 48 : l == 3 ? 80 : l == 4 ? 144 : l == 5 ? 208 : l == 6 ? 336
+         : l == 7 ? 400 : l == 8 ? 464 : l == 9 ? 496 : 528;
+}
+
+struct LayerW {
+    int tq;    // Tq[q][v][t]  (= gcn.T[v][t][q])
+    int am;    // A[q][v][w]
+    int wp;    // MFMA-packed [W_t' | W_r'] (layer 0: plain [16][4] = Wt(2) Wr(2))
+    int bias;  // folded bias, padded to 16
+    float slope;
+};
+struct UNetW {
+    const float* base;
+    LayerW L[NLAYERS];
+    int we, be;          // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
+    int rs_w[4], rs_b[4];  // down1, down2, up3, up2: Wd'[Vout][Vin], bd'[Vout]
+};
+
+struct ScoreParams {
+    UNetW w;
+    const float* data;        // (B,C,T,V)
+    const float* noise;       // (S,K,B,C,Tx,V) or null
+    const float* cond_emb;    // (B,16) or null
+    const float* step_table;  // (ns, 4+16)
+    const float* x_in;        // single-pass mode: (B,C,Tu,V)
+    float* loss_out;          // (B,S)
+    float* pose_out;          // (B,S,C,Tx,V) or null
+    float* eps_out;           // single-pass mode
+    unsigned long long seed;
+    long long first_window;
+    int B, S, ns, seg_len, n_corrupt, t_fixed, loss_fn, mode, step_single, n_chains;
+    int src_frame[12];        // data frame feeding U-Net frame t
+};
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller (perf mode noise; parity mode reads the caller's noise tensor)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
+
+// ------------------------------------------------------------------------------------------------
+// mix: Z[c,q,w] = sum_v ( sum_t X[c,t,v] T[v,t,q] ) A[q,v,w]          (stsgcn.py:154-155)
+// lane = (chain n, channel c); q is wave-uniform so every coefficient is a scalar operand.
+// EPI = false: store Z.  EPI = true (W-first layers): out = PReLU(Z + R + bias) + emb, stored in place of R.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int V, int T, int NB, bool EPI>
+__device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zout, int cs_z,
+                                          const float* __restrict__ Tq, const float* __restrict__ Am,
+                                          const float* __restrict__ bias, float slope, const float* emb,
+                                          int wave, int lane) {
+    constexpr int PAIRS = NB * CIN;
+    constexpr int PB = (PAIRS + 63) / 64;
+    constexpr int ITEMS = T * PB;
+    for (int it = wave; it < ITEMS; it += NWAVES) {
+        const int q = it / PB, pb = it % PB;
+        const int p = pb * 64 + lane;
+        if (p < PAIRS) {
+            const int n = p / CIN, c = p % CIN;
+            const float* xin = in + (n * T * V) * cs_in + c;
+            float acc[V];
+#pragma unroll
+            for (int w = 0; w < V; ++w) acc[w] = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float y = 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t) y = fmaf(xin[(t * V + v) * cs_in], Tq[(q * V + v) * T + t], y);
+#pragma unroll
+                for (int w = 0; w < V; ++w) acc[w] = fmaf(y, Am[(q * V + v) * V + w], acc[w]);
+            }
+            float* zo = zout + ((n * T + q) * V) * cs_z + c;
+            if (EPI) {
+                const float b = bias[c];
+                const float e = emb[n * EMB_STRIDE + c];
+#pragma unroll
+                for (int w = 0; w < V; ++w) zo[w * cs_z] = prelu(acc[w] + zo[w * cs_z] + b, slope) + e;
+            } else {
+#pragma unroll
+                for (int w = 0; w < V; ++w) zo[w * cs_z] = acc[w];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// joint resampling (CNN_layer over the joint axis, BN folded): out[n,c,t,v'] = b[v'] + sum_v W[v',v] X[n,c,t,v]
+// ------------------------------------------------------------------------------------------------
+template <int C, int VIN, int VOUT, int T, int NB>
+__device__ __forceinline__ void resample_stage(const float* in, int cs_in, float* out, int cs_out,
+                                               const float* __restrict__ Wd, const float* __restrict__ bd, int tid) {
+    constexpr int UNITS = NB * T * C;
+    for (int u = tid; u < UNITS; u += NTHREADS) {
+        const int c = u % C, nt = u / C;
+        float x[VIN];
+#pragma unroll
+        for (int v = 0; v < VIN; ++v) x[v] = in[(nt * VIN + v) * cs_in + c];
+#pragma unroll
+        for (int vo = 0; vo < VOUT; ++vo) {
+            float o = bd[vo];
+#pragma unroll
+            for (int v = 0; v < VIN; ++v) o = fmaf(Wd[vo * VIN + v], x[v], o);
+            out[(nt * VOUT + vo) * cs_out + c] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// channel GEMM on v_mfma_f32_16x16x4_f32.  D[c', col] = sum_k Wp[c', k] * B[k, col]
+//   A operand (weights): lane l holds W[m0 + (l&15)][k], pre-packed as float4 per 16-channel group
+//   B operand (activations in LDS [col][ch]): lane (j = l&15, g = l>>4) reads channels 16kq+8h+2g+{0,1}
+//   of column n0+j with one ds_read_b64 -> two k-steps.  The packer applies the same K permutation.
+// Wave w owns m-tile w % MT and n-tiles (w / MT) + i * (8 / MT).
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+struct Tiling {
+    static constexpr int NG = NWAVES / MT;
+    static constexpr int MAXN = (NT + NG - 1) / NG;
+};
+
+template <int MT, int NT, int KQ1, int KQ2, bool IDRES>
+__device__ __forceinline__ void gemm_stage(const float4* __restrict__ wp, const float* b1, int cs1, const float* b2,
+                                           int cs2, f32x4 (&acc)[Tiling<MT, NT>::MAXN], int wave, int lane) {
+    constexpr int KQ = KQ1 + KQ2;
+    constexpr int NG = Tiling<MT, NT>::NG;
+    constexpr int MAXN = Tiling<MT, NT>::MAXN;
+    const int mt = wave % MT, ng = wave / MT;
+    float4 a[KQ];
+    const float4* wpl = wp + (mt * KQ) * 64 + lane;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) a[kq] = wpl[kq * 64];
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const int nt = ng + i * NG;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        if (nt < NT) {
+            const int col = nt * 16 + j;
+            if (IDRES) {
+                const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + mt * 16 + 4 * g);
+                c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
+            }
+            const float* p1 = b1 + col * cs1 + 2 * g;
+#pragma unroll
+            for (int kq = 0; kq < KQ1; ++kq) {
+                const float2 u = *reinterpret_cast<const float2*>(p1 + kq * 16);
+                const float2 w = *reinterpret_cast<const float2*>(p1 + kq * 16 + 8);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, w.x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, w.y, c, 0, 0, 0);
+            }
+            if (KQ2 > 0) {
+                const float* p2 = b2 + col * cs2 + 2 * g;
+#pragma unroll
+                for (int kq = 0; kq < KQ2; ++kq) {
+                    const float2 u = *reinterpret_cast<const float2*>(p2 + kq * 16);
+                    const float2 w = *reinterpret_cast<const float2*>(p2 + kq * 16 + 8);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].x, u.x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].y, u.y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].z, w.x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].w, w.y, c, 0, 0, 0);
+                }
+            }
+        }
+        acc[i] = c;
+    }
+}
+
+// epilogue of a mix-first layer: out = PReLU(acc + bias) + emb   (stsgcn.py:109-114)
+template <int MT, int NT, int COUT, int COLS, int TV, bool RAW>
+__device__ __forceinline__ void epilogue_store(float* out, int cs_out, f32x4 (&acc)[Tiling<MT, NT>::MAXN],
+                                               const float* __restrict__ bias, float slope, const float* emb,
+                                               int wave, int lane) {
+    constexpr int NG = Tiling<MT, NT>::NG;
+    constexpr int MAXN = Tiling<MT, NT>::MAXN;
+    const int mt = wave % MT, ng = wave / MT;
+    const int j = lane & 15, g = lane >> 4;
+    const int c0 = mt * 16 + 4 * g;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!RAW && c0 < COUT) b = *reinterpret_cast<const float4*>(bias + c0);
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const int nt = ng + i * NG;
+        const int col = nt * 16 + j;
+        if (nt < NT && col < COLS && c0 < COUT) {
+            float4 v;
+            if (RAW) {
+                v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            } else {
+                const int n = col / TV;
+                const float4 e = *reinterpret_cast<const float4*>(emb + n * EMB_STRIDE + c0);
+                v.x = prelu(acc[i][0] + b.x, slope) + e.x;
+                v.y = prelu(acc[i][1] + b.y, slope) + e.y;
+                v.z = prelu(acc[i][2] + b.z, slope) + e.z;
+                v.w = prelu(acc[i][3] + b.w, slope) + e.w;
+                acc[i][0] = v.x; acc[i][1] = v.y; acc[i][2] = v.z; acc[i][3] = v.w;  // kept for skip capture
+            }
+            *reinterpret_cast<float4*>(out + col * cs_out + c0) = v;
+        }
+    }
+}
+
+// add a register-resident skip tensor (held in the accumulator layout of the layer that made it)
+template <int MT, int NT, int COLS>
+__device__ __forceinline__ void add_skip(const f32x4 (&skip)[Tiling<MT, NT>::MAXN], float* buf, int cs, int wave,
+                                         int lane) {
+    constexpr int NG = Tiling<MT, NT>::NG;
+    constexpr int MAXN = Tiling<MT, NT>::MAXN;
+    const int mt = wave % MT, ng = wave / MT;
+    const int j = lane & 15, g = lane >> 4;
+    const int c0 = mt * 16 + 4 * g;
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const int nt = ng + i * NG;
+        const int col = nt * 16 + j;
+        if (nt < NT && col < COLS) {
+            float4* p = reinterpret_cast<float4*>(buf + col * cs + c0);
+            float4 v = *p;
+            v.x += skip[i][0]; v.y += skip[i][1]; v.z += skip[i][2]; v.w += skip[i][3];
+            *p = v;
+        }
+    }
+}
+
+// one mix-first ST-GCN layer, LDS in -> LDS out (out may alias in / z: it is written after a barrier)
+template <int L, int T, int NB>
+__device__ __forceinline__ void layer_std(const UNetW& W, const float* in, float* z, float* out, const float* emb,
+                                          f32x4 (&acc)[Tiling<ceil16(layer_desc(L).cout) / 16,
+                                                              ceil16(NB * T * layer_desc(L).V) / 16>::MAXN],
+                                          int wave, int lane) {
+    constexpr LDesc D = layer_desc(L);
+    constexpr int MT = ceil16(D.cout) / 16;
+    constexpr int COLS = NB * T * D.V;
+    constexpr int NT = ceil16(COLS) / 16;
+    constexpr int CSI = cs_of(D.cin), CSO = cs_of(D.cout);
+    const LayerW lw = W.L[L];
+    mix_stage<D.cin, D.V, T, NB, false>(in, CSI, z, CSI, W.base + lw.tq, W.base + lw.am, nullptr, 0.f, nullptr, wave,
+                                        lane);
+    __syncthreads();
+    gemm_stage<MT, NT, D.cin / 16, D.res ? D.cin / 16 : 0, !D.res>(
+        reinterpret_cast<const float4*>(W.base + lw.wp), z, CSI, in, CSI, acc, wave, lane);
+    __syncthreads();
+    epilogue_store<MT, NT, D.cout, COLS, T * D.V, false>(out, CSO, acc, W.base + lw.bias, lw.slope,
+                                                         emb + emb_off(L), wave, lane);
+    __syncthreads();
+}
+
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int T, int NB>
+struct Plan {
+    static constexpr int NBT = NB * T;
+    static constexpr int P17 = ceil16(NBT * 17), P12 = ceil16(NBT * 12), P10 = ceil16(NBT * 10);
+    static constexpr int A0 = cmax(cmax(P10 * 132, P12 * 68), cmax(2 * P17 * 20, P17 * 36));
+    static constexpr int A1 = cmax(cmax(P17 * 36, P12 * 68), P10 * 68);
+    static constexpr int XT = P17 * 4;
+    static constexpr int EMB = NB * EMB_STRIDE;
+    static constexpr int SE = NB * EDIM;
+    static constexpr int TOTAL = A0 + A1 + XT + EMB + SE;
+    static constexpr size_t BYTES = (size_t)TOTAL * 4;
+};
+
+// ------------------------------------------------------------------------------------------------
+// The persistent scoring kernel.  mode 0: full reverse-diffusion trajectories + loss (mcd_score);
+// mode 1: one eps-prediction pass (mcd_unet_forward).
+// ------------------------------------------------------------------------------------------------
+template <int T, int NB>
+__global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
+    using PL = Plan<T, NB>;
+    constexpr int TV17 = T * 17;
+    constexpr int COLS17 = NB * TV17;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const A0 = smem;
+    float* const A1 = A0 + PL::A0;
+    float* const XT = A1 + PL::A1;
+    float* const EMB = XT + PL::XT;
+    float* const SE = EMB + PL::EMB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const UNetW& W = P.w;
+    const int chain0 = blockIdx.x * NB;
+    const int Tx = P.n_corrupt;
+    const int tf = P.t_fixed;
+    const int CTV = C0 * Tx * 17;          // elements of one generated pose
+    const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
+
+    // zero the whole activation area once: pad columns / pad channels must hold finite values
+    for (int u = tid; u < PL::A0 + PL::A1 + PL::XT; u += NTHREADS) smem[u] = 0.f;
+    __syncthreads();
+
+    // ---- x_T (or the given x in single-pass mode) -> XT[col] = (x0, x1, z0, z1)
+    for (int u = tid; u < COLS17; u += NTHREADS) {
+        const int n = u / TV17, t = (u / 17) % T, v = u % 17;
+        int chain = chain0 + n;
+        if (chain >= P.n_chains) chain = P.n_chains - 1;
+        const int b = chain / P.S, s = chain % P.S;
+        float xv[C0];
+#pragma unroll
+        for (int c = 0; c < C0; ++c) {
+            if (P.mode == 1) {
+                xv[c] = P.x_in[((b * C0 + c) * T + t) * 17 + v];
+            } else if (t < tf) {
+                xv[c] = P.data[((b * C0 + c) * P.seg_len + P.src_frame[t]) * 17 + v];
+            } else {
+                const int e = (c * Tx + (t - tf)) * 17 + v;
+                if (P.noise) xv[c] = P.noise[((size_t)(s * K + 0) * P.B + b) * CTV + e];
+                else xv[c] = philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
+            }
+        }
+        XT[u * 4 + 0] = xv[0];
+        XT[u * 4 + 1] = xv[1];
+    }
+    __syncthreads();
+
+    f32x4 skip1[Tiling<2, PL::P17 / 16>::MAXN];
+    f32x4 skip2[Tiling<4, PL::P12 / 16>::MAXN];
+
+    const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
+    const int i_last = P.mode == 1 ? P.step_single : 1;
+    for (int sidx = i_first; sidx >= i_last; --sidx) {
+        const float* srow = P.step_table + sidx * (4 + EDIM);
+        // ---- embeddings of this step: e' = W_e SiLU(pe(i) + cond) + b_e for all 11 layers
+        if (tid < NB * EDIM) {
+            const int n = tid / EDIM, k = tid % EDIM;
+            int chain = chain0 + n;
+            if (chain >= P.n_chains) chain = P.n_chains - 1;
+            const int b = chain / P.S;
+            float e = srow[4 + k];
+            if (P.cond_emb) e += P.cond_emb[b * EDIM + k];
+            SE[tid] = e / (1.f + expf(-e));
+        }
+        // ---- layer 0 mix on the 2 coordinate channels: thread = (col, c)
+        {
+            const float* Tq = W.base + W.L[0].tq;
+            const float* Am = W.base + W.L[0].am;
+            for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
+                const int c = u % C0, col = u / C0;
+                const int nq = col / 17, w = col % 17;  // nq = n*T + q
+                const int n = nq / T, q = nq % T;
+                float z = 0.f;
+                for (int v = 0; v < 17; ++v) {
+                    float y = 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) y = fmaf(XT[((n * T + t) * 17 + v) * 4 + c], Tq[(q * 17 + v) * T + t], y);
+                    z = fmaf(y, Am[(q * 17 + v) * 17 + w], z);
+                }
+                XT[col * 4 + 2 + c] = z;
+            }
+        }
+        __syncthreads();
+        for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
+            const int n = u / EMB_TOTAL, o = u % EMB_TOTAL;
+            const float4* wr = reinterpret_cast<const float4*>(W.base + W.we + o * EDIM);
+            const float* se = SE + n * EDIM;
+            float a = W.base[W.be + o];
+#pragma unroll
+            for (int k4 = 0; k4 < EDIM / 4; ++k4) {
+                const float4 w4 = wr[k4];
+                a = fmaf(w4.x, se[k4 * 4 + 0], a);
+                a = fmaf(w4.y, se[k4 * 4 + 1], a);
+                a = fmaf(w4.z, se[k4 * 4 + 2], a);
+                a = fmaf(w4.w, se[k4 * 4 + 3], a);
+            }
+            EMB[n * EMB_STRIDE + o] = a;
+        }
+        __syncthreads();
+        // ---- layer 0 (2 -> 16, V=17) on the VALU: thread = column
+        {
+            const LayerW lw = W.L[0];
+            const float* w0 = W.base + lw.wp;   // [16][4] = (Wt0, Wt1, Wr0, Wr1)
+            const float* b0 = W.base + lw.bias;
+            for (int col = tid; col < COLS17; col += NTHREADS) {
+                const float4 xz = *reinterpret_cast<const float4*>(XT + col * 4);
+                const int n = col / TV17;
+                float* o = A0 + col * cs_of(16);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int co = c4 * 4 + k;
+                        float a = b0[co];
+                        a = fmaf(w0[co * 4 + 0], xz.z, a);
+                        a = fmaf(w0[co * 4 + 1], xz.w, a);
+                        a = fmaf(w0[co * 4 + 2], xz.x, a);
+                        a = fmaf(w0[co * 4 + 3], xz.y, a);
+                        r[k] = prelu(a, lw.slope) + EMB[n * EMB_STRIDE + co];
+                    }
+                    *reinterpret_cast<float4*>(o + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- down path
+        {
+            f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
+            layer_std<1, T, NB>(W, A0, A0 + PL::P17 * 20, A1, EMB, acc, wave, lane);   // sd1.0: A16 -> B32 (A1)
+            layer_std<2, T, NB>(W, A1, A0, A0, EMB, skip1, wave, lane);                // sd1.1: B32 -> d1 (A0 + regs)
+        }
+        resample_stage<32, 17, 12, T, NB>(A0, 36, A1, 36, W.base + W.rs_w[0], W.base + W.rs_b[0], tid);  // down1
+        __syncthreads();
+        {
+            f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
+            layer_std<3, T, NB>(W, A1, A0, A0, EMB, acc, wave, lane);                  // sd2.0: C32 -> E64 (A0)
+            layer_std<4, T, NB>(W, A0, A1, A1, EMB, skip2, wave, lane);                // sd2.1: E64 -> d2 (A1 + regs)
+        }
+        resample_stage<64, 12, 10, T, NB>(A1, 68, A0, 68, W.base + W.rs_w[1], W.base + W.rs_b[1], tid);  // down2
+        __syncthreads();
+        {
+            f32x4 acc[Tiling<8, PL::P10 / 16>::MAXN];
+            layer_std<5, T, NB>(W, A0, A1, A0, EMB, acc, wave, lane);                  // sd3.0: F64 -> G128 (A0)
+        }
+        // ---- sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G  (in place), then mix(P_t) + P_r in place of P_r
+        {
+            constexpr int NT = PL::P10 / 16;
+            f32x4 acc[Tiling<8, NT>::MAXN];
+            const LayerW lw = W.L[6];
+            gemm_stage<8, NT, 8, 0, false>(reinterpret_cast<const float4*>(W.base + lw.wp), A0, 132, A0, 132, acc,
+                                           wave, lane);
+            __syncthreads();
+            epilogue_store<8, NT, 128, NB * T * 10, T * 10, true>(A0, 132, acc, nullptr, 0.f, nullptr, wave, lane);
+            __syncthreads();
+            mix_stage<64, 10, T, NB, true>(A0, 132, A0 + 64, 132, W.base + lw.tq, W.base + lw.am, W.base + lw.bias,
+                                           lw.slope, EMB + emb_off(6), wave, lane);
+            __syncthreads();
+        }
+        // ---- up path
+        resample_stage<64, 10, 12, T, NB>(A0 + 64, 132, A1, 68, W.base + W.rs_w[2], W.base + W.rs_b[2], tid);  // up3
+        __syncthreads();
+        add_skip<4, PL::P12 / 16, NB * T * 12>(skip2, A1, 68, wave, lane);
+        __syncthreads();
+        {
+            f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
+            layer_std<7, T, NB>(W, A1, A0, A0, EMB, acc, wave, lane);                  // su4.0: I64 -> J64 (A0)
+        }
+        {
+            f32x4 acc[Tiling<2, PL::P12 / 16>::MAXN];
+            layer_std<8, T, NB>(W, A0, A1, A1, EMB, acc, wave, lane);                  // su4.1: J64 -> K32 (A1)
+        }
+        resample_stage<32, 12, 17, T, NB>(A1, 36, A0, 36, W.base + W.rs_w[3], W.base + W.rs_b[3], tid);  // up2
+        __syncthreads();
+        add_skip<2, PL::P17 / 16, COLS17>(skip1, A0, 36, wave, lane);
+        __syncthreads();
+        {
+            f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
+            layer_std<9, T, NB>(W, A0, A1, A1, EMB, acc, wave, lane);                  // su3.0: L32 -> M32 (A1)
+        }
+        // ---- su3.1 (32 -> 2) + U-Net residual (+X) + DDPM update
+        {
+            constexpr int NT = PL::P17 / 16;
+            constexpr int NG = Tiling<1, NT>::NG, MAXN = Tiling<1, NT>::MAXN;
+            f32x4 acc[MAXN];
+            const LayerW lw = W.L[10];
+            mix_stage<32, 17, T, NB, false>(A1, 36, A0, 36, W.base + lw.tq, W.base + lw.am, nullptr, 0.f, nullptr, wave,
+                                            lane);
+            __syncthreads();
+            gemm_stage<1, NT, 2, 2, false>(reinterpret_cast<const float4*>(W.base + lw.wp), A0, 36, A1, 36, acc, wave,
+                                           lane);
+            const float ca = srow[0], cb = srow[1], csg = srow[2];
+            const float* bias = W.base + lw.bias;
+            const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i) {
+                const int nt = wave + i * NG;
+                const int col = nt * 16 + j;
+                if (nt < NT && col < COLS17 && g == 0) {
+                    const int n = col / TV17, t = (col / 17) % T, v = col % 17;
+                    int chain = chain0 + n;
+                    const bool valid = chain < P.n_chains;
+                    if (!valid) chain = P.n_chains - 1;
+                    const int b = chain / P.S, s = chain % P.S;
+#pragma unroll
+                    for (int c = 0; c < C0; ++c) {
+                        const float x = XT[col * 4 + c];
+                        const float eps = prelu(acc[i][c] + bias[c], lw.slope) + EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
+                        if (P.mode == 1) {
+                            if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
+                        } else if (t >= tf) {
+                            float z = 0.f;
+                            if (sidx > 1) {
+                                const int e = (c * Tx + (t - tf)) * 17 + v;
+                                const int k = P.ns - sidx;
+                                if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
+                                else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
+                            }
+                            XT[col * 4 + c] = ca * (x - cb * eps) + csg * z;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (P.mode == 1) return;
+
+    // ---- per-chain loss: mean over (C, Tx, V) of loss_fn(x_0 - corrupt)   (mocodad.py:484)
+    float* RED = A0;
+    const int per = CTV;
+    for (int u = tid; u < NB * per; u += NTHREADS) {
+        const int n = u / per, e = u % per;
+        const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
+        int chain = chain0 + n;
+        const bool valid = chain < P.n_chains;
+        if (!valid) chain = P.n_chains - 1;
+        const int b = chain / P.S, s = chain % P.S;
+        const float x0 = XT[((n * T + tf + tx) * 17 + v) * 4 + c];
+        const float gt = P.data[((b * C0 + c) * P.seg_len + P.src_frame[tf + tx]) * 17 + v];
+        const float d = fabsf(x0 - gt);
+        float l;
+        if (P.loss_fn == MCD_LOSS_SMOOTH_L1) l = d < 1.f ? 0.5f * d * d : d - 0.5f;
+        else if (P.loss_fn == MCD_LOSS_L1) l = d;
+        else l = d * d;
+        RED[u] = l;
+        if (valid && P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
+    }
+    __syncthreads();
+    if (wave < NB) {
+        float sum = 0.f;
+        for (int e = lane; e < per; e += 64) sum += RED[wave * per + e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+        const int chain = chain0 + wave;
+        if (lane == 0 && chain < P.n_chains) P.loss_out[chain] = sum / (float)per;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// condition encoder (runtime channel list; 0.3 % of the work): one workgroup per window, VALU only.
+// ------------------------------------------------------------------------------------------------
+struct CondW {
+    const float* base;
+    int n_layers, Tc, latent, cmax;
+    int cin[MCD_MAX_COND_LAYERS], cout[MCD_MAX_COND_LAYERS];
+    int tq[MCD_MAX_COND_LAYERS], am[MCD_MAX_COND_LAYERS], wt[MCD_MAX_COND_LAYERS], wr[MCD_MAX_COND_LAYERS];
+    int bias[MCD_MAX_COND_LAYERS];
+    float slope[MCD_MAX_COND_LAYERS];
+    int lw, lb;
+};
+
+__global__ __launch_bounds__(256) void cond_encode_kernel(const CondW W, const float* __restrict__ cond,
+                                                          float* __restrict__ emb_out, int B) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Tc = W.Tc, TV = Tc * 17;
+    float* X = smem;
+    float* Z = X + W.cmax * TV;
+    float* O = Z + W.cmax * TV;
+    float* RED = O + W.cmax * TV;  // latent * 16 partial sums
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int u = tid; u < C0 * TV; u += 256) X[u] = cond[(size_t)b * C0 * TV + u];  // (c, t, v) row-major
+    __syncthreads();
+    for (int l = 0; l < W.n_layers; ++l) {
+        const int cin = W.cin[l], cout = W.cout[l];
+        const float* Tq = W.base + W.tq[l];
+        const float* Am = W.base + W.am[l];
+        for (int u = tid; u < cin * TV; u += 256) {
+            const int c = u / TV, q = (u % TV) / 17, w = u % 17;
+            float z = 0.f;
+            for (int v = 0; v < 17; ++v) {
+                float y = 0.f;
+                for (int t = 0; t < Tc; ++t) y = fmaf(X[c * TV + t * 17 + v], Tq[(q * 17 + v) * Tc + t], y);
+                z = fmaf(y, Am[(q * 17 + v) * 17 + w], z);
+            }
+            Z[u] = z;
+        }
+        __syncthreads();
+        const float* wt = W.base + W.wt[l];
+        const float* wr = W.wr[l] >= 0 ? W.base + W.wr[l] : nullptr;
+        const float* bias = W.base + W.bias[l];
+        for (int u = tid; u < cout * TV; u += 256) {
+            const int co = u / TV, p = u % TV;
+            float a = bias[co];
+            for (int c = 0; c < cin; ++c) a = fmaf(wt[co * cin + c], Z[c * TV + p], a);
+            if (wr) {
+                for (int c = 0; c < cin; ++c) a = fmaf(wr[co * cin + c], X[c * TV + p], a);
+            } else {
+                a += X[co * TV + p];
+            }
+            O[u] = prelu(a, W.slope[l]);
+        }
+        __syncthreads();
+        float* tmp = X; X = O; O = tmp;
+    }
+    // bottleneck Linear over the (c,t,v) flattening (stsae.py:73-89)
+    const int hd = W.cout[W.n_layers - 1];
+    const int F = hd * TV;
+    const int jj = tid / 16, part = tid % 16;  // 16 partial sums per output
+    for (int j0 = 0; j0 < W.latent; j0 += 16) {
+        const int jo = j0 + jj;
+        float a = 0.f;
+        if (jo < W.latent) {
+            const float* wrow = W.base + W.lw + (size_t)jo * F;
+            for (int k = part; k < F; k += 16) a = fmaf(wrow[k], X[k], a);
+        }
+        RED[tid] = a;
+        __syncthreads();
+        if (part == 0 && jo < W.latent) {
+            float s = W.base[W.lb + jo];
+            for (int k = 0; k < 16; ++k) s += RED[jj * 16 + k];
+            emb_out[(size_t)b * W.latent + jo] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregation over the S samples (mocodad.py:454-520); one thread per window, S <= 64
+// ------------------------------------------------------------------------------------------------
+struct AggrParams {
+    const float* loss_all; const float* pose_all; const float* data; float* loss_agg; float* pose_agg;
+    int B, S, C, Tx, V, seg_len, strategy, loss_fn;
+    float q;
+    int corrupt_idx[MCD_MAX_FRAMES];
+};
+
+__device__ __forceinline__ float loss_elem(float a, float b, int fn) {
+    const float d = fabsf(a - b);
+    if (fn == MCD_LOSS_SMOOTH_L1) return d < 1.f ? 0.5f * d * d : d - 0.5f;
+    if (fn == MCD_LOSS_L1) return d;
+    return d * d;
+}
+
+__device__ __forceinline__ void sort_small(float* a, int n) {
+    for (int i = 1; i < n; ++i) {
+        const float x = a[i];
+        int k = i - 1;
+        while (k >= 0 && a[k] > x) { a[k + 1] = a[k]; --k; }
+        a[k + 1] = x;
+    }
+}
+
+__global__ void aggregate_kernel(const AggrParams P) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const int S = P.S, per = P.C * P.Tx * P.V;
+    const float* L = P.loss_all + (size_t)b * S;
+    float tmp[64];
+    if (P.strategy == MCD_AGGR_BEST || P.strategy == MCD_AGGR_WORST) {
+        const bool best = P.strategy == MCD_AGGR_BEST;
+        float cur = best ? 1e10f : -1.f;
+        int sel = -1;
+        for (int s = 0; s < S; ++s) {
+            const bool m = best ? (L[s] < cur) : (L[s] > cur);
+            if (m) { cur = L[s]; sel = s; }
+        }
+        P.loss_agg[b] = cur;
+        if (P.pose_agg) for (int e = 0; e < per; ++e)
+            P.pose_agg[(size_t)b * per + e] = sel >= 0 ? P.pose_all[((size_t)b * S + sel) * per + e] : 0.f;
+    } else if (P.strategy == MCD_AGGR_MEAN) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += L[k];
+        P.loss_agg[b] = s / (float)S;
+    } else if (P.strategy == MCD_AGGR_MEDIAN || P.strategy == MCD_AGGR_QUANTILE) {
+        for (int k = 0; k < S; ++k) tmp[k] = L[k];
+        sort_small(tmp, S);
+        if (P.strategy == MCD_AGGR_MEDIAN) {
+            P.loss_agg[b] = tmp[(S - 1) / 2];  // torch.median: lower of the two middle values
+        } else {
+            const float pos = P.q * (float)(S - 1);
+            const int lo = (int)floorf(pos);
+            const int hi = lo + 1 < S ? lo + 1 : S - 1;
+            const float wgt = pos - (float)lo;
+            const float a = tmp[lo], c = tmp[hi];
+            P.loss_agg[b] = wgt < 0.5f ? a + wgt * (c - a) : c - (c - a) * (1.f - wgt);  // torch.lerp
+        }
+    } else {  // mean_pose / median_pose
+        float acc = 0.f;
+        for (int e = 0; e < per; ++e) {
+            float val;
+            if (P.strategy == MCD_AGGR_MEAN_POSE) {
+                float s = 0.f;
+                for (int k = 0; k < S; ++k) s += P.pose_all[((size_t)b * S + k) * per + e];
+                val = s / (float)S;
+            } else {
+                for (int k = 0; k < S; ++k) tmp[k] = P.pose_all[((size_t)b * S + k) * per + e];
+                sort_small(tmp, S);
+                val = tmp[(S - 1) / 2];
+            }
+            if (P.pose_agg) P.pose_agg[(size_t)b * per + e] = val;
+            const int c = e / (P.Tx * P.V), tx = (e / P.V) % P.Tx, v = e % P.V;
+            const float gt = P.data[(((size_t)b * P.C + c) * P.seg_len + P.corrupt_idx[tx]) * P.V + v];
+            acc += loss_elem(val, gt, P.loss_fn);
+        }
+        P.loss_agg[b] = acc / (float)per;
+    }
+}
+
+// scatter-max of window scores to frames (mocodad.py:392-393 + eval_utils.py:27-34); scores >= 0
+__global__ void scatter_max_kernel(const float* __restrict__ scores, const int* __restrict__ frames,
+                                   const int* __restrict__ row, long long n, int seg_len, int n_frames,
+                                   float* __restrict__ out) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n * seg_len) return;
+    const long long i = u / seg_len;
+    const int f = frames[u] - 1;
+    if (f < 0 || f >= n_frames) return;
+    // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<int*>(out + (size_t)row[i] * n_frames + f), __float_as_int(fmaxf(scores[i], 0.f)));
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MCD_EDEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct TensorMap {
+    std::unordered_map<std::string, std::pair<const float*, int64_t>> m;
+    std::string missing;
+    const float* get(const std::string& name, int64_t numel) {
+        auto it = m.find(name);
+        if (it == m.end()) { if (missing.empty()) missing = "missing tensor " + name; return nullptr; }
+        if (it->second.second != numel) {
+            if (missing.empty()) missing = "tensor " + name + " has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel);
+            return nullptr;
+        }
+        return it->second.first;
+    }
+    bool has(const std::string& name) const { return m.count(name) != 0; }
+};
+
+struct Folded { std::vector<double> w, b; };  // BN-folded 1x1 conv: w[cout][cin], b[cout]
+
+// conv (cout,cin,1,1)+bias followed by eval BatchNorm2d (eps 1e-5): W' = s W, b' = s (b - mu) + beta
+bool fold_conv_bn(TensorMap& tm, const std::string& conv, const std::string& bn, int cout, int cin, Folded& f) {
+    const float* w = tm.get(conv + ".weight", (int64_t)cout * cin);
+    const float* b = tm.get(conv + ".bias", cout);
+    const float* g = tm.get(bn + ".weight", cout);
+    const float* be = tm.get(bn + ".bias", cout);
+    const float* mu = tm.get(bn + ".running_mean", cout);
+    const float* var = tm.get(bn + ".running_var", cout);
+    if (!w || !b || !g || !be || !mu || !var) return false;
+    f.w.resize((size_t)cout * cin); f.b.resize(cout);
+    for (int o = 0; o < cout; ++o) {
+        const double s = (double)g[o] / sqrt((double)var[o] + 1e-5);
+        for (int i = 0; i < cin; ++i) f.w[(size_t)o * cin + i] = s * (double)w[(size_t)o * cin + i];
+        f.b[o] = s * ((double)b[o] - (double)mu[o]) + (double)be[o];
+    }
+    return true;
+}
+
+struct Builder {
+    std::vector<float> buf;
+    int alloc(size_t n) { size_t o = (buf.size() + 3) & ~size_t(3); buf.resize(o + n, 0.f); return (int)o; }
+};
+
+// Tq[q][v][t] = T[v][t][q]; A copied
+bool pack_mix(TensorMap& tm, const std::string& p, int T, int V, Builder& B, int& tq, int& am) {
+    const float* Tm = tm.get(p + ".gcn.T", (int64_t)V * T * T);
+    const float* A = tm.get(p + ".gcn.A", (int64_t)T * V * V);
+    if (!Tm || !A) return false;
+    tq = B.alloc((size_t)T * V * T);
+    for (int q = 0; q < T; ++q) for (int v = 0; v < V; ++v) for (int t = 0; t < T; ++t)
+        B.buf[tq + (q * V + v) * T + t] = Tm[(v * T + t) * T + q];
+    am = B.alloc((size_t)T * V * V);
+    memcpy(&B.buf[am], A, sizeof(float) * T * V * V);
+    return true;
+}
+
+}  // namespace
+
+struct mcd_weights {
+    mcd_model_cfg_t cfg;
+    int device;
+    float* dbuf;
+    size_t n_floats;
+    UNetW unet;
+    CondW cond;
+    bool has_cond;
+};
+
+namespace {
+
+template <int T, int NB>
+int launch_score_t(const ScoreParams& P, hipStream_t st) {
+    using PL = Plan<T, NB>;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<T, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::BYTES));
+        attr_set[dev] = true;
+    }
+    const int nblocks = (P.n_chains + NB - 1) / NB;
+    hipLaunchKernelGGL((score_kernel<T, NB>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+
+int launch_score(int T, const ScoreParams& P, hipStream_t st) {
+    switch (T) {
+        case 3: return launch_score_t<3, 4>(P, st);
+        case 6: return launch_score_t<6, 2>(P, st);
+        case 12: return launch_score_t<12, 1>(P, st);
+        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mcd_last_error(void) { return g_err.c_str(); }
+int32_t mcd_abi_version(void) { return MCD_ABI_VERSION; }
+
+int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_model_cfg_t* cfg, int32_t device,
+                     mcd_weights_t** out) {
+    if (!tensors || !cfg || !out) return fail(MCD_EINVAL, "null argument");
+    if (cfg->num_coords != C0) return fail(MCD_EUNSUPPORTED, "num_coords must be 2");
+    if (cfg->n_joints != 17) return fail(MCD_EUNSUPPORTED, "n_joints must be 17 (the reference U-Net hard-wires 17/12/10 joints)");
+    if (cfg->emb_dim != EDIM) return fail(MCD_EUNSUPPORTED, "embedding_dim must be 16");
+    const int T = cfg->t_unet;
+    if (T != 3 && T != 6 && T != 12) return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
+
+    Builder B;
+    UNetW U;
+    memset(&U, 0, sizeof(U));
+    static const char* names[NLAYERS] = {"st_gcnnsp1a.0", "st_gcnnsd1.0", "st_gcnnsd1.1", "st_gcnnsd2.0", "st_gcnnsd2.1",
+                                         "st_gcnnsd3.0", "st_gcnnsd3.1", "st_gcnnsu4.0", "st_gcnnsu4.1", "st_gcnnsu3.0",
+                                         "st_gcnnsu3.1"};
+    U.we = B.alloc((size_t)EMB_TOTAL * EDIM);
+    U.be = B.alloc(EMB_TOTAL);
+    for (int l = 0; l < NLAYERS; ++l) {
+        const LDesc D = layer_desc(l);
+        const std::string p = std::string("model.") + names[l];
+        if (!pack_mix(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
+        Folded ft, fr;
+        if (!fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", D.cout, D.cin, ft)) return fail(MCD_EMISSING, tm.missing);
+        if (D.res && !fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", D.cout, D.cin, fr)) return fail(MCD_EMISSING, tm.missing);
+        const float* sl = tm.get(p + ".prelu.weight", 1);
+        const float* we = tm.get(p + ".emb_layer.1.weight", (int64_t)D.cout * EDIM);
+        const float* be = tm.get(p + ".emb_layer.1.bias", D.cout);
+        if (!sl || !we || !be) return fail(MCD_EMISSING, tm.missing);
+        U.L[l].slope = sl[0];
+        memcpy(&B.buf[U.we + (size_t)emb_off(l) * EDIM], we, sizeof(float) * D.cout * EDIM);
+        memcpy(&B.buf[U.be + emb_off(l)], be, sizeof(float) * D.cout);
+        const int mpad = ceil16(D.cout);
+        U.L[l].bias = B.alloc(mpad);
+        for (int o = 0; o < D.cout; ++o) B.buf[U.L[l].bias + o] = (float)(ft.b[o] + (D.res ? fr.b[o] : 0.0));
+        if (l == 0) {  // VALU layer: [16][4] = Wt(2), Wr(2)
+            U.L[l].wp = B.alloc(16 * 4);
+            for (int o = 0; o < 16; ++o) {
+                B.buf[U.L[l].wp + o * 4 + 0] = (float)ft.w[o * 2 + 0];
+                B.buf[U.L[l].wp + o * 4 + 1] = (float)ft.w[o * 2 + 1];
+                B.buf[U.L[l].wp + o * 4 + 2] = (float)fr.w[o * 2 + 0];
+                B.buf[U.L[l].wp + o * 4 + 3] = (float)fr.w[o * 2 + 1];
+            }
+            continue;
+        }
+        // MFMA fragment order.  Logical matrix Wcat[M][K]:
+        //   mix-first layers: M = cout, K = cin (W_t') + cin (W_r', when the layer has a residual conv)
+        //   layer 6 (W-first): M = 128 = [W_t' ; W_r'], K = cin
+        const bool wfirst = (l == 6);
+        const int M = wfirst ? 2 * D.cout : mpad;
+        const int Kc = wfirst ? D.cin : D.cin * (D.res ? 2 : 1);
+        auto wcat = [&](int r, int k) -> double {
+            if (wfirst) return r < D.cout ? ft.w[(size_t)r * D.cin + k] : fr.w[(size_t)(r - D.cout) * D.cin + k];
+            if (r >= D.cout) return 0.0;
+            return k < D.cin ? ft.w[(size_t)r * D.cin + k] : fr.w[(size_t)r * D.cin + (k - D.cin)];
+        };
+        const int MTn = M / 16, KQ = Kc / 16;
+        U.L[l].wp = B.alloc((size_t)MTn * KQ * 64 * 4);
+        for (int mt = 0; mt < MTn; ++mt) for (int kq = 0; kq < KQ; ++kq) for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) {
+                const int row = mt * 16 + (lane & 15), g = lane >> 4, h = e >> 1, r = e & 1;
+                const int k = kq * 16 + 8 * h + 2 * g + r;
+                B.buf[U.L[l].wp + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)wcat(row, k);
+            }
+    }
+    static const char* rs_names[4] = {"down1", "down2", "up3", "up2"};
+    static const int rs_in[4] = {17, 12, 10, 12}, rs_out[4] = {12, 10, 12, 17};
+    for (int r = 0; r < 4; ++r) {
+        Folded f;
+        const std::string p = std::string("model.") + rs_names[r];
+        if (!fold_conv_bn(tm, p + ".block.0", p + ".block.1", rs_out[r], rs_in[r], f)) return fail(MCD_EMISSING, tm.missing);
+        U.rs_w[r] = B.alloc(f.w.size());
+        U.rs_b[r] = B.alloc(f.b.size());
+        for (size_t i = 0; i < f.w.size(); ++i) B.buf[U.rs_w[r] + i] = (float)f.w[i];
+        for (size_t i = 0; i < f.b.size(); ++i) B.buf[U.rs_b[r] + i] = (float)f.b[i];
+    }
+    // condition encoder
+    CondW Cw;
+    memset(&Cw, 0, sizeof(Cw));
+    const bool has_cond = cfg->strategy == MCD_STRATEGY_INJECT;
+    if (has_cond) {
+        if (cfg->cond_layers < 1 || cfg->cond_layers > MCD_MAX_COND_LAYERS) return fail(MCD_EINVAL, "bad cond_layers");
+        if (cfg->t_cond < 1 || cfg->t_cond > 12) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1..12");
+        Cw.n_layers = cfg->cond_layers; Cw.Tc = cfg->t_cond; Cw.latent = EDIM; Cw.cmax = C0;
+        int cin = C0;
+        for (int l = 0; l < Cw.n_layers; ++l) {
+            const int cout = cfg->cond_channels[l];
+            if (cout < 1 || cout > 128) return fail(MCD_EUNSUPPORTED, "condition-encoder channels must be in 1..128");
+            const std::string p = "condition_encoder.encoder.model_layers." + std::to_string(l);
+            Cw.cin[l] = cin; Cw.cout[l] = cout; if (cout > Cw.cmax) Cw.cmax = cout;
+            if (!pack_mix(tm, p, Cw.Tc, 17, B, Cw.tq[l], Cw.am[l])) return fail(MCD_EMISSING, tm.missing);
+            Folded ft, fr;
+            if (!fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", cout, cin, ft)) return fail(MCD_EMISSING, tm.missing);
+            const bool res = cin != cout;
+            if (res && !fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", cout, cin, fr)) return fail(MCD_EMISSING, tm.missing);
+            const float* sl = tm.get(p + ".prelu.weight", 1);
+            if (!sl) return fail(MCD_EMISSING, tm.missing);
+            Cw.slope[l] = sl[0];
+            Cw.wt[l] = B.alloc(ft.w.size());
+            for (size_t i = 0; i < ft.w.size(); ++i) B.buf[Cw.wt[l] + i] = (float)ft.w[i];
+            Cw.wr[l] = -1;
+            if (res) { Cw.wr[l] = B.alloc(fr.w.size()); for (size_t i = 0; i < fr.w.size(); ++i) B.buf[Cw.wr[l] + i] = (float)fr.w[i]; }
+            Cw.bias[l] = B.alloc(cout);
+            for (int o = 0; o < cout; ++o) B.buf[Cw.bias[l] + o] = (float)(ft.b[o] + (res ? fr.b[o] : 0.0));
+            cin = cout;
+        }
+        const int64_t F = (int64_t)cin * Cw.Tc * 17;
+        const float* lw = tm.get("condition_encoder.btlnk.weight", F * EDIM);
+        const float* lb = tm.get("condition_encoder.btlnk.bias", EDIM);
+        if (!lw || !lb) return fail(MCD_EMISSING, tm.missing);
+        Cw.lw = B.alloc(F * EDIM); memcpy(&B.buf[Cw.lw], lw, sizeof(float) * F * EDIM);
+        Cw.lb = B.alloc(EDIM); memcpy(&B.buf[Cw.lb], lb, sizeof(float) * EDIM);
+        const size_t lds = ((size_t)3 * Cw.cmax * Cw.Tc * 17 + 256) * 4;
+        if (lds > 160 * 1024) return fail(MCD_EUNSUPPORTED, "condition encoder activations exceed LDS");
+    }
+    HIP_TRY(hipSetDevice(device));
+    mcd_weights* w = new mcd_weights();
+    w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
+    if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    e = hipMemcpy(w->dbuf, B.buf.data(), B.buf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(w->dbuf); delete w; return fail(MCD_EDEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+    U.base = w->dbuf; Cw.base = w->dbuf;
+    w->unet = U; w->cond = Cw;
+    *out = w;
+    return MCD_OK;
+}
+
+void mcd_free_weights(mcd_weights_t* w) {
+    if (!w) return;
+    if (w->dbuf) (void)hipFree(w->dbuf);
+    delete w;
+}
+
+int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_windows, float* emb_out, void* stream) {
+    if (!w) return fail(MCD_EINVAL, "null argument");
+    if (!w->has_cond) return fail(MCD_EINVAL, "model has no condition encoder");
+    if (n_windows <= 0) return MCD_OK;
+    if (!cond_data || !emb_out) return fail(MCD_EINVAL, "null argument");
+    const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(cond_encode_kernel, dim3(n_windows), dim3(256), lds, (hipStream_t)stream, w->cond, cond_data, emb_out, n_windows);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+
+int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table, int32_t t,
+                     int32_t n_windows, float* eps_out, void* stream) {
+    if (!w) return fail(MCD_EINVAL, "null argument");
+    if (n_windows <= 0) return MCD_OK;
+    if (!x || !step_table || !eps_out) return fail(MCD_EINVAL, "null argument");
+    ScoreParams P;
+    memset(&P, 0, sizeof(P));
+    P.w = w->unet; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
+    P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.t_fixed = 0;
+    P.mode = 1; P.step_single = t; P.n_chains = n_windows;
+    return launch_score(w->cfg.t_unet, P, (hipStream_t)stream);
+}
+
+int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg) {
+    if (!w || !cfg) return 0;
+    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V)
+    return (int64_t)cfg->n_windows * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
+}
+
+struct FrameIdx { int idx[MCD_MAX_FRAMES]; };
+__global__ void gather_frames_kernel(const float* __restrict__ data, float* __restrict__ out, int B, int C, int T, int V,
+                                     int n, const FrameIdx fi) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= B * C * n * V) return;
+    const int v = u % V, k = (u / V) % n, c = (u / (V * n)) % C, b = u / (V * n * C);
+    out[u] = data[(((size_t)b * C + c) * T + fi.idx[k]) * V + v];
+}
+
+int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise, uint64_t seed,
+              int64_t first_window_id, const float* step_table, void* workspace, float* loss_out, float* pose_out,
+              void* stream) {
+    if (!w || !cfg) return fail(MCD_EINVAL, "null argument");
+    const int B = cfg->n_windows, S = cfg->n_samples;
+    if (B <= 0) return MCD_OK;
+    if (!data || !step_table || !loss_out) return fail(MCD_EINVAL, "null argument");
+    if (S < 1 || cfg->noise_steps < 2) return fail(MCD_EINVAL, "need n_samples >= 1 and noise_steps >= 2");
+    if (cfg->n_corrupt < 1 || cfg->n_cond + cfg->n_corrupt != cfg->seg_len || cfg->seg_len > MCD_MAX_FRAMES)
+        return fail(MCD_EINVAL, "cond/corrupt index lists do not partition seg_len");
+    const int strat = w->cfg.strategy;
+    const int Tu = w->cfg.t_unet;
+    const int tf = strat == MCD_STRATEGY_CONCAT ? cfg->n_cond : 0;
+    if (tf + cfg->n_corrupt != Tu) return fail(MCD_EINVAL, "frame split does not match the packed U-Net (t_unet)");
+    if (strat == MCD_STRATEGY_INJECT && cfg->n_cond != w->cfg.t_cond) return fail(MCD_EINVAL, "n_cond does not match the packed condition encoder");
+    hipStream_t st = (hipStream_t)stream;
+    ScoreParams P;
+    memset(&P, 0, sizeof(P));
+    P.w = w->unet; P.data = data; P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
+    P.seed = seed; P.first_window = first_window_id;
+    P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt; P.t_fixed = tf;
+    P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
+    for (int t = 0; t < tf; ++t) P.src_frame[t] = cfg->cond_idx[t];
+    for (int t = 0; t < cfg->n_corrupt; ++t) P.src_frame[tf + t] = cfg->corrupt_idx[t];
+    if (strat == MCD_STRATEGY_INJECT) {
+        if (!workspace) return fail(MCD_EINVAL, "workspace required for the inject strategy");
+        float* emb = reinterpret_cast<float*>(workspace);
+        float* cbuf = emb + (size_t)B * EDIM + 16;
+        const int Tc = cfg->n_cond;
+        const int total = B * C0 * Tc * 17;
+        FrameIdx fi;
+        for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
+        hipLaunchKernelGGL(gather_frames_kernel, dim3((total + 255) / 256), dim3(256), 0, st, data, cbuf, B, C0, cfg->seg_len,
+                           17, Tc, fi);
+        HIP_TRY(hipGetLastError());
+        int rc = mcd_cond_encode(w, cbuf, B, emb, stream);
+        if (rc != MCD_OK) return rc;
+        P.cond_emb = emb;
+    }
+    return launch_score(Tu, P, st);
+}
+
+int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,
+                  const float* loss_all, const float* pose_all, const float* data, float* loss_agg, float* pose_agg,
+                  void* stream) {
+    if (!cfg) return fail(MCD_EINVAL, "null argument");
+    if (cfg->n_windows <= 0) return MCD_OK;
+    if (!loss_all || !loss_agg) return fail(MCD_EINVAL, "null argument");
+    if (cfg->n_samples > 64) return fail(MCD_EUNSUPPORTED, "aggregation supports n_generated_samples <= 64");
+    if (strategy < MCD_AGGR_BEST || strategy > MCD_AGGR_QUANTILE) return fail(MCD_EINVAL, "unknown aggregation strategy");
+    const bool need_pose = strategy == MCD_AGGR_MEAN_POSE || strategy == MCD_AGGR_MEDIAN_POSE;
+    if (need_pose && (!pose_all || !data)) return fail(MCD_EINVAL, "pose strategies need pose_all and data");
+    if (pose_agg && !pose_all) return fail(MCD_EINVAL, "pose_agg requested without pose_all");
+    if (cfg->n_windows <= 0) return MCD_OK;
+    AggrParams P;
+    memset(&P, 0, sizeof(P));
+    P.loss_all = loss_all; P.pose_all = pose_all; P.data = data; P.loss_agg = loss_agg; P.pose_agg = pose_agg;
+    P.B = cfg->n_windows; P.S = cfg->n_samples; P.C = num_coords; P.Tx = cfg->n_corrupt; P.V = n_joints;
+    P.seg_len = cfg->seg_len; P.strategy = strategy; P.loss_fn = cfg->loss_fn; P.q = quantile;
+    for (int t = 0; t < cfg->n_corrupt && t < MCD_MAX_FRAMES; ++t) P.corrupt_idx[t] = cfg->corrupt_idx[t];
+    hipLaunchKernelGGL(aggregate_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+
+int mcd_scatter_max(const float* scores, const int32_t* frames, const int32_t* row, int64_t n, int32_t seg_len,
+                    int32_t n_rows, int32_t n_frames, float* out, void* stream) {
+    if (!scores || !frames || !row || !out) return fail(MCD_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * n_frames * sizeof(float), st));
+    if (n <= 0) return MCD_OK;
+    const long long total = (long long)n * seg_len;
+    hipLaunchKernelGGL(scatter_max_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scores, frames, row,
+                       (long long)n, seg_len, n_frames, out);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""Host-side driver of the HIP scoring path: owns the packed weights handle and the small per-config
+device tables, and turns torch CUDA tensors into raw pointers for the C ABI (include/mocodad_hip.h).
+PyTorch is used for device memory and streams only; every FLOP of the path runs in libmocodad_hip.so."""
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils.diffusion_utils import step_table
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipScorer:
+    """One packed model on one GPU.
+
+    state_dict: the reference's Lightning-checkpoint keys ('model.*', 'condition_encoder.*') -> tensors.
+    strategy: canonical conditioning strategy ('inject' | 'concat' | 'no_condition').
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, strategy: str, seg_len: int, cond_idx: Sequence[int],
+                 corrupt_idx: Sequence[int], cond_channels: Sequence[int] = (), num_coords: int = 2, n_joints: int = 17,
+                 emb_dim: int = 16, device=None):
+        self.L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("mocodad_amd needs an MI355X (gfx950) GPU: the scoring path has no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.strategy = strategy
+        self.seg_len = int(seg_len)
+        self.cond_idx = [int(i) for i in cond_idx]
+        self.corrupt_idx = [int(i) for i in corrupt_idx]
+        self.num_coords, self.n_joints, self.emb_dim = num_coords, n_joints, emb_dim
+        self.t_cond = len(self.cond_idx) if strategy == "inject" else 0
+        self.t_unet = len(self.corrupt_idx) + (len(self.cond_idx) if strategy == "concat" else 0)
+        self._tables: Dict[int, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+
+        cfg = _lib.ModelCfg()
+        cfg.num_coords, cfg.n_joints, cfg.t_unet, cfg.t_cond = num_coords, n_joints, self.t_unet, self.t_cond
+        cfg.emb_dim, cfg.strategy = emb_dim, _lib.STRATEGY[strategy]
+        cfg.cond_layers = len(cond_channels) if strategy == "inject" else 0
+        for i, c in enumerate(cond_channels):
+            cfg.cond_channels[i] = int(c)
+        keep = []  # keep host copies alive during the call
+        arr = (_lib.Tensor * len(state_dict))()
+        n = 0
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            h = v.detach().to("cpu", torch.float32).contiguous()
+            keep.append(h)
+            arr[n].name = k.encode()
+            arr[n].data = h.data_ptr()
+            arr[n].numel = h.numel()
+            n += 1
+        handle = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.L.mcd_pack_weights(arr, n, C.byref(cfg), idx, C.byref(handle)))
+        self._h = handle
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self.L.mcd_free_weights(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers
+    def table(self, noise_steps: int) -> torch.Tensor:
+        t = self._tables.get(noise_steps)
+        if t is None:
+            t = step_table(noise_steps, self.emb_dim).to(self.device)
+            self._tables[noise_steps] = t
+        return t
+
+    def _score_cfg(self, B: int, S: int, ns: int, loss_fn: str) -> "_lib.ScoreCfg":
+        c = _lib.ScoreCfg()
+        c.n_windows, c.n_samples, c.noise_steps, c.seg_len = B, S, ns, self.seg_len
+        c.n_cond, c.n_corrupt = len(self.cond_idx), len(self.corrupt_idx)
+        for i, v in enumerate(self.cond_idx):
+            c.cond_idx[i] = v
+        for i, v in enumerate(self.corrupt_idx):
+            c.corrupt_idx[i] = v
+        c.loss_fn = _lib.LOSS[loss_fn]
+        return c
+
+    # ------------------------------------------------------------------ entry points
+    def cond_encode(self, cond_data: torch.Tensor) -> torch.Tensor:
+        x = _f32c(cond_data, self.device)
+        out = torch.empty(x.shape[0], self.emb_dim, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_cond_encode(self._h, _ptr(x), x.shape[0], _ptr(out), _stream()))
+        return out
+
+    def unet_forward(self, x: torch.Tensor, t: int, cond: Optional[torch.Tensor], noise_steps: Optional[int] = None) -> torch.Tensor:
+        x = _f32c(x, self.device)
+        cond = None if cond is None else _f32c(cond, self.device)
+        tab = self.table(noise_steps if noise_steps is not None else max(int(t) + 1, 2))
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_unet_forward(self._h, _ptr(x), _ptr(cond), _ptr(tab), int(t), x.shape[0], _ptr(out), _stream()))
+        return out
+
+    def score(self, data: torch.Tensor, *, n_samples: int, noise_steps: int, noise: Optional[torch.Tensor] = None,
+              seed: int = 0, first_window_id: int = 0, loss_fn: str = "smooth_l1", want_poses: bool = False
+              ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """data (B,C,T,V) -> (loss (B,S), poses (B,S,C,Tx,V) | None).  Asynchronous on the current stream."""
+        data = _f32c(data, self.device)
+        B = data.shape[0]
+        S = int(n_samples)
+        Tx = len(self.corrupt_idx)
+        cfg = self._score_cfg(B, S, int(noise_steps), loss_fn)
+        loss = torch.empty(B, S, device=self.device, dtype=torch.float32)
+        poses = torch.empty(B, S, self.num_coords, Tx, self.n_joints, device=self.device, dtype=torch.float32) if want_poses else None
+        if noise is not None:
+            noise = _f32c(noise, self.device)
+            exp = (S, max(noise_steps - 1, 1), B, self.num_coords, Tx, self.n_joints)
+            if tuple(noise.shape) != exp:
+                raise ValueError(f"noise must have shape {exp}, got {tuple(noise.shape)}")
+        need = int(self.L.mcd_score_workspace_bytes(self._h, C.byref(cfg)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_score(self._h, C.byref(cfg), _ptr(data), _ptr(noise), C.c_uint64(seed & (2**64 - 1)),
+                                        C.c_int64(first_window_id), _ptr(self.table(noise_steps)), _ptr(self._ws),
+                                        _ptr(loss), _ptr(poses), _stream()))
+        return loss, poses
+
+    def aggregate(self, data: torch.Tensor, loss_all: torch.Tensor, poses_all: Optional[torch.Tensor], strategy: str,
+                  *, noise_steps: int, loss_fn: str = "smooth_l1", want_pose: bool = True
+                  ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+        """_aggregation_strategy of the reference on device -> (selected pose | None, loss (B,))."""
+        B, S = loss_all.shape
+        q = 0.0
+        name = strategy
+        if "quantile" in strategy:
+            q = float(strategy.split(":")[-1])
+            name = "quantile"
+        if name not in _lib.AGGR or name == "all":
+            raise ValueError(f"Unknown aggregation strategy {strategy}")
+        cfg = self._score_cfg(B, S, int(noise_steps), loss_fn)
+        data = _f32c(data, self.device)
+        out = torch.empty(B, device=self.device, dtype=torch.float32)
+        gives_pose = name in ("best", "worst", "mean_pose", "median_pose")
+        pose = None
+        if gives_pose and want_pose and poses_all is not None:
+            pose = torch.empty(poses_all.shape[0], *poses_all.shape[2:], device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_aggregate(C.byref(cfg), self.num_coords, self.n_joints, _lib.AGGR[name], C.c_float(q),
+                                            _ptr(loss_all), _ptr(poses_all), _ptr(data), _ptr(out), _ptr(pose), _stream()))
+        return pose, out
+
+    def scatter_max(self, scores: torch.Tensor, frames: torch.Tensor, row: torch.Tensor, n_rows: int, n_frames: int) -> torch.Tensor:
+        scores = _f32c(scores, self.device)
+        frames = frames.to(self.device, torch.int32).contiguous()
+        row = row.to(self.device, torch.int32).contiguous()
+        out = torch.empty(n_rows, n_frames, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_scatter_max(_ptr(scores), _ptr(frames), _ptr(row), scores.numel(), frames.shape[1],
+                                              n_rows, n_frames, _ptr(out), _stream()))
+        return out
