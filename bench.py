@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MoCoDAD anomaly-scoring hot path on MI355X.
+
+A "step" = one MoCoDAD.forward-equivalent call of the HIP path (condition encoder + S*(ns-1) U-Net
+passes + DDPM updates + per-sample loss + 'best' aggregation) over one batch of synthetic pose windows
+that is already resident in HBM.  Workload = BASELINE.json configs[1]: HR-Avenue-shaped windows
+(B=1024 per step as in config/Avenue/mocodad_test.yaml, seg_len 6 = 3 condition + 3 denoised frames,
+17 joints), noise_steps=10, 5 generated samples, inject conditioning, in-kernel Philox noise.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the driver contract in the task description)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic FLOP per window (BASELINE.md §3 / SURVEY.md §8d): P * F_unet(T_u=3) + F_cond(T_c=3)
+F_UNET_T3 = 4_290_352
+F_COND_T3 = 545_904
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def load_weights():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "weights_inject.npz"))
+    w = {k: d[k] for k in d.files}
+    cfg = json.loads(bytes(w.pop("__cfg__")).decode())
+    return {k: torch.from_numpy(v) for k, v in w.items()}, cfg
+
+
+def synth_windows(n, seg_len, seed):
+    """HR-Avenue-shaped synthetic input: smooth per-joint random walks, robust-scaled-like, clipped to +-5."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(n, 2, 1, 17, generator=g)
+    steps = torch.randn(n, 2, seg_len, 17, generator=g) * 0.15
+    return (base + torch.cumsum(steps, dim=2)).clamp_(-5, 5).float().contiguous()
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(sd, ns, S, budget_s=15.0):
+    """The oracle (a PyTorch-CPU op-for-op port of the reference path) timed on this host's cores, on a
+    bounded sample: a 32-window probe sizes the timed sample to about `budget_s` seconds."""
+    from oracle import mocodad_oracle as O
+    threads = min(usable_cores(), 64)
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(123)
+
+    def run(n, seed):
+        data = synth_windows(n, 6, seed)
+        noise = torch.randn(S, ns - 1, n, 2, 3, 17, generator=g)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.score(sd, data, noise, noise_steps=ns, aggregation="best")
+        return time.perf_counter() - t0
+
+    run(32, 1)                      # warm-up (thread pool, allocator)
+    probe = run(32, 2)
+    n = int(min(2048, max(64, 32 * budget_s / max(probe, 1e-3))))
+    n = max(64, n // 64 * 64)
+    dt = run(n, 3)
+    return {"value": round(n / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"one batch of {n} windows, ns={ns}, S={S}, oracle/mocodad_oracle.py (PyTorch CPU, {threads} threads), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="windows per step per GPU")
+    ap.add_argument("--noise-steps", type=int, default=10)
+    ap.add_argument("--samples", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from mocodad_amd.engine import HipScorer
+    sd, cfg = load_weights()
+    ns, S, B = args.noise_steps, args.samples, args.batch
+    sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5],
+                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev)
+    # weak scaling: every rank owns its own shard of B windows per step (global window ids keep the
+    # Philox streams distinct and independent of the number of GPUs)
+    data = synth_windows(B, 6, 1000 + rank).to(dev)
+    gathered = torch.empty(world * B, device=dev, dtype=torch.float32) if world > 1 else None
+
+    def step(i):
+        loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=i, first_window_id=rank * B)
+        _, best = sc.aggregate(data, loss, None, "best", noise_steps=ns, want_pose=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, best)   # RCCL: reassemble per-window scores
+            return gathered
+        return best
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=100 + i, first_window_id=rank * B)
+        ev[i][1].record()   # brackets the scoring launches (cond encoder + persistent kernel) on this stream
+        _, best = sc.aggregate(data, loss, None, "best", noise_steps=ns, want_pose=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, best)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    assert torch.isfinite(best).all()
+
+    if rank == 0:
+        total = world * B * args.steps
+        P = S * (ns - 1)
+        flop_per_window = P * F_UNET_T3 + F_COND_T3
+        achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "pose-clips/sec (whole node) @ noise_steps=10, 5 samples",
+            "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: HR-Avenue-shaped windows (seg_len 6 = 3 cond + 3 denoised, 17 joints), "
+                                   f"noise_steps={ns}, {S} generated samples, inject conditioning, 'best' aggregation",
+                       "windows_per_step_per_gpu": B, "denoiser_passes_per_window": P, "weights": "seeded random init (tests/golden/weights_inject.npz)",
+                       "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), all-gather of scores"},
+            "roofline": {"bound": "mfma", "kernel": "score_kernel<3,4> (+cond_encode_kernel)", "achieved": round(achieved, 3),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                         "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
+                         "hbm_algorithmic_bytes_per_window": 820, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, ns, S, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
