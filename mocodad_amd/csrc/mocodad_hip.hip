@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string>
 #include <vector>
@@ -34,6 +35,10 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// read-only model coefficients addressed wave-uniformly go through the constant address space so that the
+// compiler emits scalar loads (s_load_dwordx16) and feeds them to v_fmac as SGPR operands
+typedef const float __attribute__((address_space(4))) cfloat;
+__device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)p; }
 
 constexpr int NTHREADS = 512;
 constexpr int NWAVES = 8;
@@ -59,22 +64,32 @@ __host__ __device__ constexpr int emb_off(int l) {
          : l == 7 ? 400 : l == 8 ? 464 : l == 9 ? 496 : 528;
 }
 
-struct LayerW {
-    int tq;    // Tq[q][v][t]  (= gcn.T[v][t][q])
-    int am;    // A[q][v][w]
-    int wp;    // MFMA-packed [W_t' | W_r'] (layer 0: plain [16][4] = Wt(2) Wr(2))
-    int bias;  // folded bias, padded to 16
-    float slope;
-};
-struct UNetW {
-    const float* base;
-    LayerW L[NLAYERS];
-    int we, be;          // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
-    int rs_w[4], rs_b[4];  // down1, down2, up3, up2: Wd'[Vout][Vin], bd'[Vout]
-};
+// Offset table stored in the first TAB_FLOATS words of the packed weight buffer (offsets in floats from the
+// buffer start).  The kernel scalar-loads an entry right where it is used; keeping the table out of the
+// kernarg segment stops the compiler from hoisting ~100 pointers into SGPRs for the whole trajectory loop.
+constexpr int TAB_FLOATS = 128;
+enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_STRIDE = 8 };
+//   tab[l*8 + F_TQ]    Tq[q][v][t]  (= gcn.T[v][t][q])
+//   tab[l*8 + F_AM]    A[q][v][w]
+//   tab[l*8 + F_WP]    MFMA-packed [W_t' | W_r'] (layer 0: plain [16][4] = Wt(2) Wr(2))
+//   tab[l*8 + F_BIAS]  folded bias, padded to 16
+//   tab[l*8 + F_SLOPE] PReLU slope (float bits)
+constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
+constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: Wd'[Vout][Vin], bd'[Vout]
+typedef const int __attribute__((address_space(4))) cint;
+__device__ __forceinline__ int tab_i(const float* base, int idx) { return ((cint*)base)[idx]; }
+__device__ __forceinline__ float tab_f(const float* base, int idx) { return ((cfloat*)base)[idx]; }
+struct LayerW { int tq, am, wp, bias; float slope; };
+__device__ __forceinline__ LayerW layer_w(const float* base, int l) {
+    LayerW w;
+    w.tq = tab_i(base, l * F_STRIDE + F_TQ); w.am = tab_i(base, l * F_STRIDE + F_AM);
+    w.wp = tab_i(base, l * F_STRIDE + F_WP); w.bias = tab_i(base, l * F_STRIDE + F_BIAS);
+    w.slope = tab_f(base, l * F_STRIDE + F_SLOPE);
+    return w;
+}
 
 struct ScoreParams {
-    UNetW w;
+    const float* wbuf;        // packed weights; first TAB_FLOATS words = offset table
     const float* data;        // (B,C,T,V)
     const float* noise;       // (S,K,B,C,Tx,V) or null
     const float* cond_emb;    // (B,16) or null
@@ -119,9 +134,11 @@ __device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x :
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int V, int T, int NB, bool EPI>
 __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zout, int cs_z,
-                                          const float* __restrict__ Tq, const float* __restrict__ Am,
+                                          const float* Tq_, const float* Am_,
                                           const float* __restrict__ bias, float slope, const float* emb,
                                           int wave, int lane) {
+    cfloat* Tq = as_const(Tq_);
+    cfloat* Am = as_const(Am_);
     constexpr int PAIRS = NB * CIN;
     constexpr int PB = (PAIRS + 63) / 64;
     constexpr int ITEMS = T * PB;
@@ -134,13 +151,28 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
             float acc[V];
 #pragma unroll
             for (int w = 0; w < V; ++w) acc[w] = 0.f;
+            if (T * V <= 64) {
+                // all LDS operands first (one wait), then a pure scalar-load + FMA stream
+                float x[T * V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                float y = 0.f;
+                for (int k = 0; k < T * V; ++k) x[k] = xin[k * cs_in];
 #pragma unroll
-                for (int t = 0; t < T; ++t) y = fmaf(xin[(t * V + v) * cs_in], Tq[(q * V + v) * T + t], y);
+                for (int v = 0; v < V; ++v) {
+                    float y = 0.f;
 #pragma unroll
-                for (int w = 0; w < V; ++w) acc[w] = fmaf(y, Am[(q * V + v) * V + w], acc[w]);
+                    for (int t = 0; t < T; ++t) y = fmaf(x[t * V + v], Tq[(q * V + v) * T + t], y);
+#pragma unroll
+                    for (int w = 0; w < V; ++w) acc[w] = fmaf(y, Am[(q * V + v) * V + w], acc[w]);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    float y = 0.f;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) y = fmaf(xin[(t * V + v) * cs_in], Tq[(q * V + v) * T + t], y);
+#pragma unroll
+                    for (int w = 0; w < V; ++w) acc[w] = fmaf(y, Am[(q * V + v) * V + w], acc[w]);
+                }
             }
             float* zo = zout + ((n * T + q) * V) * cs_z + c;
             if (EPI) {
@@ -161,7 +193,9 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
 // ------------------------------------------------------------------------------------------------
 template <int C, int VIN, int VOUT, int T, int NB>
 __device__ __forceinline__ void resample_stage(const float* in, int cs_in, float* out, int cs_out,
-                                               const float* __restrict__ Wd, const float* __restrict__ bd, int tid) {
+                                               const float* Wd_, const float* bd_, int tid) {
+    cfloat* Wd = as_const(Wd_);
+    cfloat* bd = as_const(bd_);
     constexpr int UNITS = NB * T * C;
     for (int u = tid; u < UNITS; u += NTHREADS) {
         const int c = u % C, nt = u / C;
@@ -298,7 +332,7 @@ __device__ __forceinline__ void add_skip(const f32x4 (&skip)[Tiling<MT, NT>::MAX
 
 // one mix-first ST-GCN layer, LDS in -> LDS out (out may alias in / z: it is written after a barrier)
 template <int L, int T, int NB>
-__device__ __forceinline__ void layer_std(const UNetW& W, const float* in, float* z, float* out, const float* emb,
+__device__ __forceinline__ void layer_std(const float* wb, const float* in, float* z, float* out, const float* emb,
                                           f32x4 (&acc)[Tiling<ceil16(layer_desc(L).cout) / 16,
                                                               ceil16(NB * T * layer_desc(L).V) / 16>::MAXN],
                                           int wave, int lane) {
@@ -307,15 +341,14 @@ __device__ __forceinline__ void layer_std(const UNetW& W, const float* in, float
     constexpr int COLS = NB * T * D.V;
     constexpr int NT = ceil16(COLS) / 16;
     constexpr int CSI = cs_of(D.cin), CSO = cs_of(D.cout);
-    const LayerW lw = W.L[L];
-    mix_stage<D.cin, D.V, T, NB, false>(in, CSI, z, CSI, W.base + lw.tq, W.base + lw.am, nullptr, 0.f, nullptr, wave,
-                                        lane);
+    const LayerW lw = layer_w(wb, L);
+    mix_stage<D.cin, D.V, T, NB, false>(in, CSI, z, CSI, wb + lw.tq, wb + lw.am, nullptr, 0.f, nullptr, wave, lane);
     __syncthreads();
     gemm_stage<MT, NT, D.cin / 16, D.res ? D.cin / 16 : 0, !D.res>(
-        reinterpret_cast<const float4*>(W.base + lw.wp), z, CSI, in, CSI, acc, wave, lane);
+        reinterpret_cast<const float4*>(wb + lw.wp), z, CSI, in, CSI, acc, wave, lane);
     __syncthreads();
-    epilogue_store<MT, NT, D.cout, COLS, T * D.V, false>(out, CSO, acc, W.base + lw.bias, lw.slope,
-                                                         emb + emb_off(L), wave, lane);
+    epilogue_store<MT, NT, D.cout, COLS, T * D.V, false>(out, CSO, acc, wb + lw.bias, lw.slope, emb + emb_off(L), wave,
+                                                         lane);
     __syncthreads();
 }
 
@@ -338,8 +371,8 @@ struct Plan {
 // The persistent scoring kernel.  mode 0: full reverse-diffusion trajectories + loss (mcd_score);
 // mode 1: one eps-prediction pass (mcd_unet_forward).
 // ------------------------------------------------------------------------------------------------
-template <int T, int NB>
-__global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
+template <int T, int NB, int MINW>
+__global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams P) {
     using PL = Plan<T, NB>;
     constexpr int TV17 = T * 17;
     constexpr int COLS17 = NB * TV17;
@@ -350,10 +383,10 @@ __global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
     float* const EMB = XT + PL::XT;
     float* const SE = EMB + PL::EMB;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const UNetW& W = P.w;
+    const int tid0 = threadIdx.x;
+    int tid = tid0;
+    int lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chain0 = blockIdx.x * NB;
     const int Tx = P.n_corrupt;
     const int tf = P.t_fixed;
@@ -395,6 +428,14 @@ __global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
     const int i_last = P.mode == 1 ? P.step_single : 1;
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
+        const float* wb = P.wbuf;
+        asm volatile("" : "+s"(wb));   // opaque per step: offset-table loads stay inside the loop
+        // same for the thread id: otherwise every per-lane LDS address of every stage is hoisted out of the
+        // step loop (loop-invariant) and the ~250 resulting VGPRs are spilled to scratch
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // ---- embeddings of this step: e' = W_e SiLU(pe(i) + cond) + b_e for all 11 layers
         if (tid < NB * EDIM) {
             const int n = tid / EDIM, k = tid % EDIM;
@@ -407,8 +448,8 @@ __global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
         }
         // ---- layer 0 mix on the 2 coordinate channels: thread = (col, c)
         {
-            const float* Tq = W.base + W.L[0].tq;
-            const float* Am = W.base + W.L[0].am;
+            const float* Tq = wb + tab_i(wb, F_TQ);
+            const float* Am = wb + tab_i(wb, F_AM);
             for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
                 const int c = u % C0, col = u / C0;
                 const int nq = col / 17, w = col % 17;  // nq = n*T + q
@@ -426,9 +467,9 @@ __global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
         __syncthreads();
         for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
             const int n = u / EMB_TOTAL, o = u % EMB_TOTAL;
-            const float4* wr = reinterpret_cast<const float4*>(W.base + W.we + o * EDIM);
+            const float4* wr = reinterpret_cast<const float4*>(wb + tab_i(wb, TAB_WE) + o * EDIM);
             const float* se = SE + n * EDIM;
-            float a = W.base[W.be + o];
+            float a = wb[tab_i(wb, TAB_BE) + o];
 #pragma unroll
             for (int k4 = 0; k4 < EDIM / 4; ++k4) {
                 const float4 w4 = wr[k4];
@@ -442,9 +483,9 @@ __global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
         __syncthreads();
         // ---- layer 0 (2 -> 16, V=17) on the VALU: thread = column
         {
-            const LayerW lw = W.L[0];
-            const float* w0 = W.base + lw.wp;   // [16][4] = (Wt0, Wt1, Wr0, Wr1)
-            const float* b0 = W.base + lw.bias;
+            const LayerW lw = layer_w(wb, 0);
+            cfloat* w0 = as_const(wb + lw.wp);   // [16][4] = (Wt0, Wt1, Wr0, Wr1)
+            cfloat* b0 = as_const(wb + lw.bias);
             for (int col = tid; col < COLS17; col += NTHREADS) {
                 const float4 xz = *reinterpret_cast<const float4*>(XT + col * 4);
                 const int n = col / TV17;
@@ -470,70 +511,67 @@ __global__ __launch_bounds__(NTHREADS) void score_kernel(const ScoreParams P) {
         // ---- down path
         {
             f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
-            layer_std<1, T, NB>(W, A0, A0 + PL::P17 * 20, A1, EMB, acc, wave, lane);   // sd1.0: A16 -> B32 (A1)
-            layer_std<2, T, NB>(W, A1, A0, A0, EMB, skip1, wave, lane);                // sd1.1: B32 -> d1 (A0 + regs)
+            layer_std<1, T, NB>(wb, A0, A0 + PL::P17 * 20, A1, EMB, acc, wave, lane);   // sd1.0: A16 -> B32 (A1)
+            layer_std<2, T, NB>(wb, A1, A0, A0, EMB, skip1, wave, lane);                // sd1.1: B32 -> d1 (A0 + regs)
         }
-        resample_stage<32, 17, 12, T, NB>(A0, 36, A1, 36, W.base + W.rs_w[0], W.base + W.rs_b[0], tid);  // down1
+        resample_stage<32, 17, 12, T, NB>(A0, 36, A1, 36, wb + tab_i(wb, TAB_RSW + 0), wb + tab_i(wb, TAB_RSB + 0), tid);  // down1
         __syncthreads();
         {
             f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
-            layer_std<3, T, NB>(W, A1, A0, A0, EMB, acc, wave, lane);                  // sd2.0: C32 -> E64 (A0)
-            layer_std<4, T, NB>(W, A0, A1, A1, EMB, skip2, wave, lane);                // sd2.1: E64 -> d2 (A1 + regs)
+            layer_std<3, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane);                  // sd2.0: C32 -> E64 (A0)
+            layer_std<4, T, NB>(wb, A0, A1, A1, EMB, skip2, wave, lane);                // sd2.1: E64 -> d2 (A1 + regs)
         }
-        resample_stage<64, 12, 10, T, NB>(A1, 68, A0, 68, W.base + W.rs_w[1], W.base + W.rs_b[1], tid);  // down2
+        resample_stage<64, 12, 10, T, NB>(A1, 68, A0, 68, wb + tab_i(wb, TAB_RSW + 1), wb + tab_i(wb, TAB_RSB + 1), tid);  // down2
         __syncthreads();
         {
             f32x4 acc[Tiling<8, PL::P10 / 16>::MAXN];
-            layer_std<5, T, NB>(W, A0, A1, A0, EMB, acc, wave, lane);                  // sd3.0: F64 -> G128 (A0)
+            layer_std<5, T, NB>(wb, A0, A1, A0, EMB, acc, wave, lane);                  // sd3.0: F64 -> G128 (A0)
         }
         // ---- sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G  (in place), then mix(P_t) + P_r in place of P_r
         {
             constexpr int NT = PL::P10 / 16;
             f32x4 acc[Tiling<8, NT>::MAXN];
-            const LayerW lw = W.L[6];
-            gemm_stage<8, NT, 8, 0, false>(reinterpret_cast<const float4*>(W.base + lw.wp), A0, 132, A0, 132, acc,
-                                           wave, lane);
+            const LayerW lw = layer_w(wb, 6);
+            gemm_stage<8, NT, 8, 0, false>(reinterpret_cast<const float4*>(wb + lw.wp), A0, 132, A0, 132, acc, wave, lane);
             __syncthreads();
             epilogue_store<8, NT, 128, NB * T * 10, T * 10, true>(A0, 132, acc, nullptr, 0.f, nullptr, wave, lane);
             __syncthreads();
-            mix_stage<64, 10, T, NB, true>(A0, 132, A0 + 64, 132, W.base + lw.tq, W.base + lw.am, W.base + lw.bias,
-                                           lw.slope, EMB + emb_off(6), wave, lane);
+            mix_stage<64, 10, T, NB, true>(A0, 132, A0 + 64, 132, wb + lw.tq, wb + lw.am, wb + lw.bias, lw.slope,
+                                           EMB + emb_off(6), wave, lane);
             __syncthreads();
         }
         // ---- up path
-        resample_stage<64, 10, 12, T, NB>(A0 + 64, 132, A1, 68, W.base + W.rs_w[2], W.base + W.rs_b[2], tid);  // up3
+        resample_stage<64, 10, 12, T, NB>(A0 + 64, 132, A1, 68, wb + tab_i(wb, TAB_RSW + 2), wb + tab_i(wb, TAB_RSB + 2), tid);  // up3
         __syncthreads();
         add_skip<4, PL::P12 / 16, NB * T * 12>(skip2, A1, 68, wave, lane);
         __syncthreads();
         {
             f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
-            layer_std<7, T, NB>(W, A1, A0, A0, EMB, acc, wave, lane);                  // su4.0: I64 -> J64 (A0)
+            layer_std<7, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane);                  // su4.0: I64 -> J64 (A0)
         }
         {
             f32x4 acc[Tiling<2, PL::P12 / 16>::MAXN];
-            layer_std<8, T, NB>(W, A0, A1, A1, EMB, acc, wave, lane);                  // su4.1: J64 -> K32 (A1)
+            layer_std<8, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane);                  // su4.1: J64 -> K32 (A1)
         }
-        resample_stage<32, 12, 17, T, NB>(A1, 36, A0, 36, W.base + W.rs_w[3], W.base + W.rs_b[3], tid);  // up2
+        resample_stage<32, 12, 17, T, NB>(A1, 36, A0, 36, wb + tab_i(wb, TAB_RSW + 3), wb + tab_i(wb, TAB_RSB + 3), tid);  // up2
         __syncthreads();
         add_skip<2, PL::P17 / 16, COLS17>(skip1, A0, 36, wave, lane);
         __syncthreads();
         {
             f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
-            layer_std<9, T, NB>(W, A0, A1, A1, EMB, acc, wave, lane);                  // su3.0: L32 -> M32 (A1)
+            layer_std<9, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane);                  // su3.0: L32 -> M32 (A1)
         }
         // ---- su3.1 (32 -> 2) + U-Net residual (+X) + DDPM update
         {
             constexpr int NT = PL::P17 / 16;
             constexpr int NG = Tiling<1, NT>::NG, MAXN = Tiling<1, NT>::MAXN;
             f32x4 acc[MAXN];
-            const LayerW lw = W.L[10];
-            mix_stage<32, 17, T, NB, false>(A1, 36, A0, 36, W.base + lw.tq, W.base + lw.am, nullptr, 0.f, nullptr, wave,
-                                            lane);
+            const LayerW lw = layer_w(wb, 10);
+            mix_stage<32, 17, T, NB, false>(A1, 36, A0, 36, wb + lw.tq, wb + lw.am, nullptr, 0.f, nullptr, wave, lane);
             __syncthreads();
-            gemm_stage<1, NT, 2, 2, false>(reinterpret_cast<const float4*>(W.base + lw.wp), A0, 36, A1, 36, acc, wave,
-                                           lane);
+            gemm_stage<1, NT, 2, 2, false>(reinterpret_cast<const float4*>(wb + lw.wp), A0, 36, A1, 36, acc, wave, lane);
             const float ca = srow[0], cb = srow[1], csg = srow[2];
-            const float* bias = W.base + lw.bias;
+            const float* bias = wb + lw.bias;
             const int j = lane & 15, g = lane >> 4;
 #pragma unroll
             for (int i = 0; i < MAXN; ++i) {
@@ -841,35 +879,38 @@ struct mcd_weights {
     int device;
     float* dbuf;
     size_t n_floats;
-    UNetW unet;
     CondW cond;
     bool has_cond;
 };
 
 namespace {
 
-template <int T, int NB>
+template <int T, int NB, int MINW>
 int launch_score_t(const ScoreParams& P, hipStream_t st) {
     using PL = Plan<T, NB>;
     static bool attr_set[16] = {false};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<T, NB>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::BYTES));
         attr_set[dev] = true;
     }
     const int nblocks = (P.n_chains + NB - 1) / NB;
-    hipLaunchKernelGGL((score_kernel<T, NB>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
+    hipLaunchKernelGGL((score_kernel<T, NB, MINW>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
 
 int launch_score(int T, const ScoreParams& P, hipStream_t st) {
+    static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
     switch (T) {
-        case 3: return launch_score_t<3, 4>(P, st);
-        case 6: return launch_score_t<6, 2>(P, st);
-        case 12: return launch_score_t<12, 1>(P, st);
+        case 3:
+            if (variant == 1) return launch_score_t<3, 2, 4>(P, st);   // 2 chains / WG, 2 WGs per CU
+            if (variant == 2) return launch_score_t<3, 2, 2>(P, st);
+            return launch_score_t<3, 4, 2>(P, st);
+        case 6: return launch_score_t<6, 2, 2>(P, st);
+        case 12: return launch_score_t<12, 1, 2>(P, st);
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
     }
 }
@@ -893,8 +934,10 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
 
     Builder B;
-    UNetW U;
+    struct HostLayer { int tq, am, wp, bias; float slope; };
+    struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4]; } U;
     memset(&U, 0, sizeof(U));
+    B.alloc(TAB_FLOATS);  // offset table lives at the start of the buffer
     static const char* names[NLAYERS] = {"st_gcnnsp1a.0", "st_gcnnsd1.0", "st_gcnnsd1.1", "st_gcnnsd2.0", "st_gcnnsd2.1",
                                          "st_gcnnsd3.0", "st_gcnnsd3.1", "st_gcnnsu4.0", "st_gcnnsu4.1", "st_gcnnsu3.0",
                                          "st_gcnnsu3.1"};
@@ -997,6 +1040,16 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         const size_t lds = ((size_t)3 * Cw.cmax * Cw.Tc * 17 + 256) * 4;
         if (lds > 160 * 1024) return fail(MCD_EUNSUPPORTED, "condition encoder activations exceed LDS");
     }
+    {
+        int* tab = reinterpret_cast<int*>(B.buf.data());
+        for (int l = 0; l < NLAYERS; ++l) {
+            tab[l * F_STRIDE + F_TQ] = U.L[l].tq; tab[l * F_STRIDE + F_AM] = U.L[l].am;
+            tab[l * F_STRIDE + F_WP] = U.L[l].wp; tab[l * F_STRIDE + F_BIAS] = U.L[l].bias;
+            memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
+        }
+        tab[TAB_WE] = U.we; tab[TAB_BE] = U.be;
+        for (int r = 0; r < 4; ++r) { tab[TAB_RSW + r] = U.rs_w[r]; tab[TAB_RSB + r] = U.rs_b[r]; }
+    }
     HIP_TRY(hipSetDevice(device));
     mcd_weights* w = new mcd_weights();
     w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond;
@@ -1004,8 +1057,8 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(w->dbuf, B.buf.data(), B.buf.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(w->dbuf); delete w; return fail(MCD_EDEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
-    U.base = w->dbuf; Cw.base = w->dbuf;
-    w->unet = U; w->cond = Cw;
+    Cw.base = w->dbuf;
+    w->cond = Cw;
     *out = w;
     return MCD_OK;
 }
@@ -1041,7 +1094,7 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     if (!x || !step_table || !eps_out) return fail(MCD_EINVAL, "null argument");
     ScoreParams P;
     memset(&P, 0, sizeof(P));
-    P.w = w->unet; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
+    P.wbuf = w->dbuf; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
     P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.t_fixed = 0;
     P.mode = 1; P.step_single = t; P.n_chains = n_windows;
     return launch_score(w->cfg.t_unet, P, (hipStream_t)stream);
@@ -1080,7 +1133,7 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
     hipStream_t st = (hipStream_t)stream;
     ScoreParams P;
     memset(&P, 0, sizeof(P));
-    P.w = w->unet; P.data = data; P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
+    P.wbuf = w->dbuf; P.data = data; P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
     P.seed = seed; P.first_window = first_window_id;
     P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt; P.t_fixed = tf;
     P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
