@@ -29,6 +29,8 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <utility>
+#include <type_traits>
 
 #include "../../include/mocodad_hip.h"
 
@@ -68,27 +70,48 @@ __host__ __device__ constexpr int emb_off(int l) {
 // buffer start).  The kernel scalar-loads an entry right where it is used; keeping the table out of the
 // kernarg segment stops the compiler from hoisting ~100 pointers into SGPRs for the whole trajectory loop.
 constexpr int TAB_FLOATS = 128;
-enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_STRIDE = 8 };
-//   tab[l*8 + F_TQ]    Tq[q][v][t]  (= gcn.T[v][t][q])
-//   tab[l*8 + F_AM]    A[q][v][w]
+enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_TQT = 5, F_AMT = 6, F_STRIDE = 8 };
+//   tab[l*8 + F_TQ]    layer 0: Tq[q][v][t] (= gcn.T[v][t][q]);  layers 1..10: time-mix coefficients packed 16 per
+//                      VGPR for DPP row broadcast, TQD[q][r][64]: lane 16g+i = T[v=4s+g][t][q] with s*T+t = 16r+i
+//   tab[l*8 + F_AM]    layer 0: A[q][v][w];  layers 1..10: MFMA A-operand fragments of A_q^T,
+//                      AF[q][mt][s][64]: lane (i=j, g) = A[q][v=4s+g][w=16mt+j]  (0 outside V x V)
 //   tab[l*8 + F_WP]    MFMA-packed [W_t' | W_r'] (layer 0: plain [16][4] = Wt(2) Wr(2))
 //   tab[l*8 + F_BIAS]  folded bias, padded to 16
 //   tab[l*8 + F_SLOPE] PReLU slope (float bits)
 constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
-constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: Wd'[Vout][Vin], bd'[Vout]
+constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: lane-spread WdP[Vout][16] (lane i = Wd'[vo][v=i]), bd'P[32]
+constexpr int TAB_RST = 98;               // down1 only (Vin=17): tail[16], lane i = Wd'[vo=i][16]
 typedef const int __attribute__((address_space(4))) cint;
 __device__ __forceinline__ int tab_i(const float* base, int idx) { return ((cint*)base)[idx]; }
 __device__ __forceinline__ float tab_f(const float* base, int idx) { return ((cfloat*)base)[idx]; }
-struct LayerW { int tq, am, wp, bias; float slope; };
+struct LayerW { int tq, am, wp, bias, tqt, amt; float slope; };
 __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
     LayerW w;
     w.tq = tab_i(base, l * F_STRIDE + F_TQ); w.am = tab_i(base, l * F_STRIDE + F_AM);
     w.wp = tab_i(base, l * F_STRIDE + F_WP); w.bias = tab_i(base, l * F_STRIDE + F_BIAS);
+    w.tqt = tab_i(base, l * F_STRIDE + F_TQT); w.amt = tab_i(base, l * F_STRIDE + F_AMT);
     w.slope = tab_f(base, l * F_STRIDE + F_SLOPE);
     return w;
 }
 
+// Optional in-kernel stage timing (build with -DMCD_PROFILE; tools/stage_profile.py): thread 0 of block 0
+// accumulates s_memtime deltas between stage boundaries into P.prof[stage].
+struct Prof {
+#ifdef MCD_PROFILE
+    unsigned long long* p;
+    unsigned long long tlast;
+    bool on;
+    __device__ __forceinline__ void mark(int id) {
+        if (on) { const unsigned long long t = __builtin_readcyclecounter(); p[id] += t - tlast; tlast = t; }
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+#define STAGE(id) prof.mark(id)
+
 struct ScoreParams {
+    unsigned long long* prof; // stage timing accumulators (MCD_PROFILE builds) or null
     const float* wbuf;        // packed weights; first TAB_FLOATS words = offset table
     const float* data;        // (B,C,T,V)
     const float* noise;       // (S,K,B,C,Tx,V) or null
@@ -128,87 +151,162 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 __device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
 
 // ------------------------------------------------------------------------------------------------
+// DPP helpers.  A coefficient row (<= 16 values) lives in ONE VGPR, value i in lane i of every 16-lane row
+// (a single coalesced 64 B vector load); each FMA picks its coefficient with the DPP row_newbcast modifier:
+//     acc += bcast_L(coef) * y        ->  v_fmac_f32_dpp acc, coef, y row_newbcast:L
+// This keeps the learned time/joint mixing matrices out of the scalar cache (16 KB, thrashed by the ~40 KB
+// of tables a pass touches) and costs 1/16 of the loads of a broadcast-read scheme.  EXEC must be full.
+// ------------------------------------------------------------------------------------------------
+// PAD = true appends `s_nop 1`: hipcc does not model the instructions inside an asm statement, so when the
+// result feeds an MFMA operand next (VALU write -> MFMA SrcA/B read hazard) the wait states must be ours.
+template <int L, bool PAD = false>
+__device__ __forceinline__ void fmac_bc(float& acc, float coef, float y) {
+    if (PAD)
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(acc) : "v"(coef), "v"(y), "n"(L));
+    else
+        asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(coef), "v"(y), "n"(L));
+}
+template <int L, bool PAD = false>
+__device__ __forceinline__ float mul_bc(float coef, float y) {
+    float r;
+    if (PAD)
+        asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "=v"(r) : "v"(coef), "v"(y), "n"(L));
+    else
+        asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(coef), "v"(y), "n"(L));
+    return r;
+}
+template <int L>
+__device__ __forceinline__ float mov_bc(float coef) {
+    float r;
+    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(coef), "n"(L));
+    return r;
+}
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// ------------------------------------------------------------------------------------------------
 // mix: Z[c,q,w] = sum_v ( sum_t X[c,t,v] T[v,t,q] ) A[q,v,w]          (stsgcn.py:154-155)
-// lane = (chain n, channel c); q is wave-uniform so every coefficient is a scalar operand.
-// EPI = false: store Z.  EPI = true (W-first layers): out = PReLU(Z + R + bias) + emb, stored in place of R.
+// The joint mix runs on the matrix cores: for one (chain n, output frame q, block of 16 channels)
+//     D[w][c] = sum_v A_q[v][w] * Y[v][c]        A operand = A_q^T fragments (pre-packed, from L2/L1)
+//                                                 B operand = Y[v][c], built in registers by the time mix:
+//     Y[v][c] = sum_t X[(n,t,v)][c] * T[v][t][q]  lane (j = c, g): v = 4s + g for k-step s  (T LDS reads + T FMAs)
+// V is padded to KS*4 rows (zero weights) and 16*MT output joints.  The D fragment (lane: channel j,
+// joints 4g..4g+3) is stored to Z[(n,q,w)][c].
+// EPI = true (W-first layers): out = PReLU(D + R + bias) + emb, stored in place of R (= zout).
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int V, int T, int NB, bool EPI>
 __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zout, int cs_z,
-                                          const float* Tq_, const float* Am_,
+                                          const float* __restrict__ tqd, const float* __restrict__ af,
                                           const float* __restrict__ bias, float slope, const float* emb,
                                           int wave, int lane) {
-    cfloat* Tq = as_const(Tq_);
-    cfloat* Am = as_const(Am_);
-    constexpr int PAIRS = NB * CIN;
-    constexpr int PB = (PAIRS + 63) / 64;
-    constexpr int ITEMS = T * PB;
-    for (int it = wave; it < ITEMS; it += NWAVES) {
-        const int q = it / PB, pb = it % PB;
-        const int p = pb * 64 + lane;
-        if (p < PAIRS) {
-            const int n = p / CIN, c = p % CIN;
-            const float* xin = in + (n * T * V) * cs_in + c;
-            float acc[V];
+    constexpr int KS = (V + 3) / 4;
+    constexpr int MT = (V + 15) / 16;
+    constexpr int CB = CIN / 16;
+    constexpr int UNITS = NB * CB;                       // one unit = (chain, 16-channel block), all frames
+    constexpr int QC = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;   // output frames computed together
+    constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
+    const int j = lane & 15, g = lane >> 4;
+    for (int u = wave; u < UNITS; u += NWAVES) {
+        const int cb = u % CB, n = u / CB;
+        const float* xin = in + (n * T * V + g) * cs_in + cb * 16 + j;
+#pragma unroll 1
+        for (int q0 = 0; q0 < T; q0 += QC) {
+            float tq[QC][NR], aop[QC][MT][KS];
 #pragma unroll
-            for (int w = 0; w < V; ++w) acc[w] = 0.f;
-            if (T * V <= 64) {
-                // all LDS operands first (one wait), then a pure scalar-load + FMA stream
-                float x[T * V];
+            for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
-                for (int k = 0; k < T * V; ++k) x[k] = xin[k * cs_in];
+                for (int r = 0; r < NR; ++r) tq[qi][r] = tqd[((q0 + qi) * NR + r) * 64 + lane];
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    float y = 0.f;
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int t = 0; t < T; ++t) y = fmaf(x[t * V + v], Tq[(q * V + v) * T + t], y);
-#pragma unroll
-                    for (int w = 0; w < V; ++w) acc[w] = fmaf(y, Am[(q * V + v) * V + w], acc[w]);
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    float y = 0.f;
-#pragma unroll
-                    for (int t = 0; t < T; ++t) y = fmaf(xin[(t * V + v) * cs_in], Tq[(q * V + v) * T + t], y);
-#pragma unroll
-                    for (int w = 0; w < V; ++w) acc[w] = fmaf(y, Am[(q * V + v) * V + w], acc[w]);
-                }
+                    for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
             }
-            float* zo = zout + ((n * T + q) * V) * cs_z + c;
-            if (EPI) {
-                const float b = bias[c];
-                const float e = emb[n * EMB_STRIDE + c];
+            float* zo = zout + ((n * T + q0) * V + 4 * g) * cs_z + cb * 16 + j;
+            f32x4 acc[QC][MT];
 #pragma unroll
-                for (int w = 0; w < V; ++w) zo[w * cs_z] = prelu(acc[w] + zo[w * cs_z] + b, slope) + e;
-            } else {
+            for (int qi = 0; qi < QC; ++qi)
 #pragma unroll
-                for (int w = 0; w < V; ++w) zo[w * cs_z] = acc[w];
-            }
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[qi][mt][r] = 0.f;
+                        if (EPI) { if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = zo[(qi * V + mt * 16 + r) * cs_z]; }
+                    }
+            static_for<KS>([&](auto si) {
+                constexpr int ks = decltype(si)::value;
+                float x[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) x[t] = xin[(t * V + 4 * ks) * cs_in];
+                static_for<QC>([&](auto qq) {
+                    constexpr int qi = decltype(qq)::value;
+                    // y = sum_t X[t, v=4ks+g] * T[v, t, q]   (coefficient (ks,t) = lane ks*T+t of this DPP row)
+                    float y = mul_bc<(ks * T) % 16, T == 1>(tq[qi][(ks * T) / 16], x[0]);
+                    static_for<T - 1>([&](auto ti) {
+                        constexpr int t = decltype(ti)::value + 1;
+                        fmac_bc<(ks * T + t) % 16, t == T - 1>(y, tq[qi][(ks * T + t) / 16], x[t]);
+                    });
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
+                });
+            });
+            float b = 0.f, e = 0.f;
+            if (EPI) { b = bias[cb * 16 + j]; e = emb[n * EMB_STRIDE + cb * 16 + j]; }
+#pragma unroll
+            for (int qi = 0; qi < QC; ++qi)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mt * 16 + 4 * g + r < V)
+                            zo[(qi * V + mt * 16 + r) * cs_z] = EPI ? prelu(acc[qi][mt][r] + b, slope) + e : acc[qi][mt][r];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // joint resampling (CNN_layer over the joint axis, BN folded): out[n,c,t,v'] = b[v'] + sum_v W[v',v] X[n,c,t,v]
+// thread = (n, t, c); W rows lane-spread as in the mix (row vo: lane i = W[vo][v=i]).
 // ------------------------------------------------------------------------------------------------
 template <int C, int VIN, int VOUT, int T, int NB>
 __device__ __forceinline__ void resample_stage(const float* in, int cs_in, float* out, int cs_out,
-                                               const float* Wd_, const float* bd_, int tid) {
-    cfloat* Wd = as_const(Wd_);
-    cfloat* bd = as_const(bd_);
+                                               const float* __restrict__ wdp, const float* __restrict__ bdp,
+                                               const float* __restrict__ wtail, int tid) {
     constexpr int UNITS = NB * T * C;
-    for (int u = tid; u < UNITS; u += NTHREADS) {
-        const int c = u % C, nt = u / C;
+    constexpr int VM = VIN < 16 ? VIN : 16;
+    constexpr int ROUNDS = (UNITS + NTHREADS - 1) / NTHREADS;
+    const int l15 = tid & 15;
+    float wr[VOUT];
+#pragma unroll
+    for (int vo = 0; vo < VOUT; ++vo) wr[vo] = wdp[vo * 16 + l15];
+    const float b0 = bdp[l15], b1 = bdp[16 + l15];
+    float wt = 0.f;
+    if (VIN == 17) wt = wtail[l15];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = tid + r * NTHREADS;
+        const bool live = u < UNITS;
+        const int uc = live ? u : UNITS - 1;
+        const int c = uc % C, nt = uc / C;
         float x[VIN];
 #pragma unroll
         for (int v = 0; v < VIN; ++v) x[v] = in[(nt * VIN + v) * cs_in + c];
-#pragma unroll
-        for (int vo = 0; vo < VOUT; ++vo) {
-            float o = bd[vo];
-#pragma unroll
-            for (int v = 0; v < VIN; ++v) o = fmaf(Wd[vo * VIN + v], x[v], o);
-            out[(nt * VOUT + vo) * cs_out + c] = o;
-        }
+        static_for<VOUT>([&](auto oi) {
+            constexpr int vo = decltype(oi)::value;
+            float o;
+            if constexpr (vo < 16) o = mov_bc<vo>(b0);
+            else o = mov_bc<vo - 16>(b1);
+            static_for<VM>([&](auto vi) {
+                constexpr int v = decltype(vi)::value;
+                fmac_bc<v>(o, wr[vo], x[v]);
+            });
+            if constexpr (VIN == 17) fmac_bc<vo>(o, wt, x[16]);
+            if (live) out[(nt * VOUT + vo) * cs_out + c] = o;
+        });
     }
 }
 
@@ -335,7 +433,7 @@ template <int L, int T, int NB>
 __device__ __forceinline__ void layer_std(const float* wb, const float* in, float* z, float* out, const float* emb,
                                           f32x4 (&acc)[Tiling<ceil16(layer_desc(L).cout) / 16,
                                                               ceil16(NB * T * layer_desc(L).V) / 16>::MAXN],
-                                          int wave, int lane) {
+                                          int wave, int lane, Prof& prof) {
     constexpr LDesc D = layer_desc(L);
     constexpr int MT = ceil16(D.cout) / 16;
     constexpr int COLS = NB * T * D.V;
@@ -344,9 +442,11 @@ __device__ __forceinline__ void layer_std(const float* wb, const float* in, floa
     const LayerW lw = layer_w(wb, L);
     mix_stage<D.cin, D.V, T, NB, false>(in, CSI, z, CSI, wb + lw.tq, wb + lw.am, nullptr, 0.f, nullptr, wave, lane);
     __syncthreads();
+    prof.mark(32 + 3 * L);
     gemm_stage<MT, NT, D.cin / 16, D.res ? D.cin / 16 : 0, !D.res>(
         reinterpret_cast<const float4*>(wb + lw.wp), z, CSI, in, CSI, acc, wave, lane);
     __syncthreads();
+    prof.mark(33 + 3 * L);
     epilogue_store<MT, NT, D.cout, COLS, T * D.V, false>(out, CSO, acc, wb + lw.bias, lw.slope, emb + emb_off(L), wave,
                                                          lane);
     __syncthreads();
@@ -421,6 +521,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }
     __syncthreads();
 
+    Prof prof;
+#ifdef MCD_PROFILE
+    prof.p = P.prof; prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
+#endif
     f32x4 skip1[Tiling<2, PL::P17 / 16>::MAXN];
     f32x4 skip2[Tiling<4, PL::P12 / 16>::MAXN];
 
@@ -465,6 +569,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             }
         }
         __syncthreads();
+        STAGE(0);
         for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
             const int n = u / EMB_TOTAL, o = u % EMB_TOTAL;
             const float4* wr = reinterpret_cast<const float4*>(wb + tab_i(wb, TAB_WE) + o * EDIM);
@@ -481,6 +586,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             EMB[n * EMB_STRIDE + o] = a;
         }
         __syncthreads();
+        STAGE(1);
         // ---- layer 0 (2 -> 16, V=17) on the VALU: thread = column
         {
             const LayerW lw = layer_w(wb, 0);
@@ -508,24 +614,32 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             }
         }
         __syncthreads();
+        STAGE(2);
         // ---- down path
         {
             f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
-            layer_std<1, T, NB>(wb, A0, A0 + PL::P17 * 20, A1, EMB, acc, wave, lane);   // sd1.0: A16 -> B32 (A1)
-            layer_std<2, T, NB>(wb, A1, A0, A0, EMB, skip1, wave, lane);                // sd1.1: B32 -> d1 (A0 + regs)
+            layer_std<1, T, NB>(wb, A0, A0 + PL::P17 * 20, A1, EMB, acc, wave, lane, prof);   // sd1.0: A16 -> B32 (A1)
+            STAGE(3);
+            layer_std<2, T, NB>(wb, A1, A0, A0, EMB, skip1, wave, lane, prof);                // sd1.1: B32 -> d1 (A0 + regs)
+            STAGE(4);
         }
-        resample_stage<32, 17, 12, T, NB>(A0, 36, A1, 36, wb + tab_i(wb, TAB_RSW + 0), wb + tab_i(wb, TAB_RSB + 0), tid);  // down1
+        resample_stage<32, 17, 12, T, NB>(A0, 36, A1, 36, wb + tab_i(wb, TAB_RSW + 0), wb + tab_i(wb, TAB_RSB + 0), wb + tab_i(wb, TAB_RST), tid);  // down1
         __syncthreads();
+        STAGE(5);
         {
             f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
-            layer_std<3, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane);                  // sd2.0: C32 -> E64 (A0)
-            layer_std<4, T, NB>(wb, A0, A1, A1, EMB, skip2, wave, lane);                // sd2.1: E64 -> d2 (A1 + regs)
+            layer_std<3, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane, prof);                  // sd2.0: C32 -> E64 (A0)
+            STAGE(6);
+            layer_std<4, T, NB>(wb, A0, A1, A1, EMB, skip2, wave, lane, prof);                // sd2.1: E64 -> d2 (A1 + regs)
+            STAGE(7);
         }
-        resample_stage<64, 12, 10, T, NB>(A1, 68, A0, 68, wb + tab_i(wb, TAB_RSW + 1), wb + tab_i(wb, TAB_RSB + 1), tid);  // down2
+        resample_stage<64, 12, 10, T, NB>(A1, 68, A0, 68, wb + tab_i(wb, TAB_RSW + 1), wb + tab_i(wb, TAB_RSB + 1), wb + tab_i(wb, TAB_RST), tid);  // down2
         __syncthreads();
+        STAGE(8);
         {
             f32x4 acc[Tiling<8, PL::P10 / 16>::MAXN];
-            layer_std<5, T, NB>(wb, A0, A1, A0, EMB, acc, wave, lane);                  // sd3.0: F64 -> G128 (A0)
+            layer_std<5, T, NB>(wb, A0, A1, A0, EMB, acc, wave, lane, prof);                  // sd3.0: F64 -> G128 (A0)
+            STAGE(9);
         }
         // ---- sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G  (in place), then mix(P_t) + P_r in place of P_r
         {
@@ -536,30 +650,37 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             __syncthreads();
             epilogue_store<8, NT, 128, NB * T * 10, T * 10, true>(A0, 132, acc, nullptr, 0.f, nullptr, wave, lane);
             __syncthreads();
+            STAGE(10);
             mix_stage<64, 10, T, NB, true>(A0, 132, A0 + 64, 132, wb + lw.tq, wb + lw.am, wb + lw.bias, lw.slope,
                                            EMB + emb_off(6), wave, lane);
             __syncthreads();
+            STAGE(11);
         }
         // ---- up path
-        resample_stage<64, 10, 12, T, NB>(A0 + 64, 132, A1, 68, wb + tab_i(wb, TAB_RSW + 2), wb + tab_i(wb, TAB_RSB + 2), tid);  // up3
+        resample_stage<64, 10, 12, T, NB>(A0 + 64, 132, A1, 68, wb + tab_i(wb, TAB_RSW + 2), wb + tab_i(wb, TAB_RSB + 2), wb + tab_i(wb, TAB_RST), tid);  // up3
         __syncthreads();
         add_skip<4, PL::P12 / 16, NB * T * 12>(skip2, A1, 68, wave, lane);
         __syncthreads();
+        STAGE(12);
         {
             f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
-            layer_std<7, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane);                  // su4.0: I64 -> J64 (A0)
+            layer_std<7, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane, prof);                  // su4.0: I64 -> J64 (A0)
+            STAGE(13);
         }
         {
             f32x4 acc[Tiling<2, PL::P12 / 16>::MAXN];
-            layer_std<8, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane);                  // su4.1: J64 -> K32 (A1)
+            layer_std<8, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane, prof);                  // su4.1: J64 -> K32 (A1)
+            STAGE(14);
         }
-        resample_stage<32, 12, 17, T, NB>(A1, 36, A0, 36, wb + tab_i(wb, TAB_RSW + 3), wb + tab_i(wb, TAB_RSB + 3), tid);  // up2
+        resample_stage<32, 12, 17, T, NB>(A1, 36, A0, 36, wb + tab_i(wb, TAB_RSW + 3), wb + tab_i(wb, TAB_RSB + 3), wb + tab_i(wb, TAB_RST), tid);  // up2
         __syncthreads();
         add_skip<2, PL::P17 / 16, COLS17>(skip1, A0, 36, wave, lane);
         __syncthreads();
+        STAGE(15);
         {
             f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
-            layer_std<9, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane);                  // su3.0: L32 -> M32 (A1)
+            layer_std<9, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane, prof);                  // su3.0: L32 -> M32 (A1)
+            STAGE(16);
         }
         // ---- su3.1 (32 -> 2) + U-Net residual (+X) + DDPM update
         {
@@ -603,6 +724,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 }
             }
             __syncthreads();
+            STAGE(17);
         }
     }
     if (P.mode == 1) return;
@@ -872,6 +994,29 @@ bool pack_mix(TensorMap& tm, const std::string& p, int T, int V, Builder& B, int
     return true;
 }
 
+// fragment-order coefficients for the MFMA mix (see mix_stage)
+bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B, int& tqf, int& af) {
+    const float* Tm = tm.get(p + ".gcn.T", (int64_t)V * T * T);
+    const float* A = tm.get(p + ".gcn.A", (int64_t)T * V * V);
+    if (!Tm || !A) return false;
+    const int KS = (V + 3) / 4, MT = (V + 15) / 16;
+    const int NR = (KS * T + 15) / 16;
+    tqf = B.alloc((size_t)T * NR * 64);
+    af = B.alloc((size_t)T * MT * KS * 64);
+    for (int q = 0; q < T; ++q) for (int r = 0; r < NR; ++r) for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, g = lane >> 4, idx = r * 16 + i, s = idx / T, t = idx % T, v = 4 * s + g;
+        B.buf[tqf + (q * NR + r) * 64 + lane] = (idx < KS * T && v < V) ? Tm[(v * T + t) * T + q] : 0.f;
+    }
+    for (int q = 0; q < T; ++q) for (int s = 0; s < KS; ++s) for (int lane = 0; lane < 64; ++lane) {
+        const int j = lane & 15, g = lane >> 4, v = 4 * s + g;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int w = mt * 16 + j;
+            B.buf[af + ((q * MT + mt) * KS + s) * 64 + lane] = (v < V && w < V) ? A[(q * V + v) * V + w] : 0.f;
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 struct mcd_weights {
@@ -906,9 +1051,9 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
     static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
     switch (T) {
         case 3:
-            if (variant == 1) return launch_score_t<3, 2, 4>(P, st);   // 2 chains / WG, 2 WGs per CU
+            if (variant == 1) return launch_score_t<3, 4, 2>(P, st);   // 4 chains / WG, 1 WG per CU
             if (variant == 2) return launch_score_t<3, 2, 2>(P, st);
-            return launch_score_t<3, 4, 2>(P, st);
+            return launch_score_t<3, 2, 4>(P, st);                     // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
         case 6: return launch_score_t<6, 2, 2>(P, st);
         case 12: return launch_score_t<12, 1, 2>(P, st);
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
@@ -917,7 +1062,11 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
 
 }  // namespace
 
+static unsigned long long* g_prof = nullptr;  // MCD_PROFILE builds: device buffer of 32 accumulators
+
 extern "C" {
+
+void mcd_debug_set_prof(void* p) { g_prof = reinterpret_cast<unsigned long long*>(p); }
 
 const char* mcd_last_error(void) { return g_err.c_str(); }
 int32_t mcd_abi_version(void) { return MCD_ABI_VERSION; }
@@ -934,8 +1083,8 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
 
     Builder B;
-    struct HostLayer { int tq, am, wp, bias; float slope; };
-    struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4]; } U;
+    struct HostLayer { int tq, am, wp, bias, tqt, amt; float slope; };
+    struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4], rs_t; } U;
     memset(&U, 0, sizeof(U));
     B.alloc(TAB_FLOATS);  // offset table lives at the start of the buffer
     static const char* names[NLAYERS] = {"st_gcnnsp1a.0", "st_gcnnsd1.0", "st_gcnnsd1.1", "st_gcnnsd2.0", "st_gcnnsd2.1",
@@ -946,7 +1095,11 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     for (int l = 0; l < NLAYERS; ++l) {
         const LDesc D = layer_desc(l);
         const std::string p = std::string("model.") + names[l];
-        if (!pack_mix(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
+        if (l == 0) {
+            if (!pack_mix(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
+        } else {
+            if (!pack_mix_mfma(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
+        }
         Folded ft, fr;
         if (!fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", D.cout, D.cin, ft)) return fail(MCD_EMISSING, tm.missing);
         if (D.res && !fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", D.cout, D.cin, fr)) return fail(MCD_EMISSING, tm.missing);
@@ -996,10 +1149,15 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         Folded f;
         const std::string p = std::string("model.") + rs_names[r];
         if (!fold_conv_bn(tm, p + ".block.0", p + ".block.1", rs_out[r], rs_in[r], f)) return fail(MCD_EMISSING, tm.missing);
-        U.rs_w[r] = B.alloc(f.w.size());
-        U.rs_b[r] = B.alloc(f.b.size());
-        for (size_t i = 0; i < f.w.size(); ++i) B.buf[U.rs_w[r] + i] = (float)f.w[i];
-        for (size_t i = 0; i < f.b.size(); ++i) B.buf[U.rs_b[r] + i] = (float)f.b[i];
+        const int vin = rs_in[r], vout = rs_out[r], vm = vin < 16 ? vin : 16;
+        U.rs_w[r] = B.alloc((size_t)vout * 16);
+        U.rs_b[r] = B.alloc(32);
+        for (int vo = 0; vo < vout; ++vo) for (int i = 0; i < vm; ++i) B.buf[U.rs_w[r] + vo * 16 + i] = (float)f.w[(size_t)vo * vin + i];
+        for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_b[r] + vo] = (float)f.b[vo];
+        if (r == 0) {  // down1: Vin = 17 -> tail column
+            U.rs_t = B.alloc(16);
+            for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_t + vo] = (float)f.w[(size_t)vo * vin + 16];
+        }
     }
     // condition encoder
     CondW Cw;
@@ -1045,10 +1203,12 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         for (int l = 0; l < NLAYERS; ++l) {
             tab[l * F_STRIDE + F_TQ] = U.L[l].tq; tab[l * F_STRIDE + F_AM] = U.L[l].am;
             tab[l * F_STRIDE + F_WP] = U.L[l].wp; tab[l * F_STRIDE + F_BIAS] = U.L[l].bias;
+            tab[l * F_STRIDE + F_TQT] = U.L[l].tqt; tab[l * F_STRIDE + F_AMT] = U.L[l].amt;
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
         }
         tab[TAB_WE] = U.we; tab[TAB_BE] = U.be;
         for (int r = 0; r < 4; ++r) { tab[TAB_RSW + r] = U.rs_w[r]; tab[TAB_RSB + r] = U.rs_b[r]; }
+        tab[TAB_RST] = U.rs_t;
     }
     HIP_TRY(hipSetDevice(device));
     mcd_weights* w = new mcd_weights();
@@ -1133,7 +1293,7 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
     hipStream_t st = (hipStream_t)stream;
     ScoreParams P;
     memset(&P, 0, sizeof(P));
-    P.wbuf = w->dbuf; P.data = data; P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
+    P.wbuf = w->dbuf; P.prof = g_prof; P.data = data; P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
     P.seed = seed; P.first_window = first_window_id;
     P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt; P.t_fixed = tf;
     P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;

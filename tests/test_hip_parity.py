@@ -72,7 +72,7 @@ def test_trajectory_vs_golden(variant, ns, S):
 
 @pytest.mark.parametrize("B", [1, 3, 4, 5, 37])
 def test_ragged_batch_vs_oracle(B):
-    """Batch sizes that do not fill the last workgroup's chain slots (NB=4): parity vs. the oracle."""
+    """Batch sizes that do not fill the last workgroup's chain slots: parity vs. the oracle."""
     from oracle import mocodad_oracle as O
     sc, sd, cfg = _scorer("inject")
     gen = torch.Generator().manual_seed(100 + B)

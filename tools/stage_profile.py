@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-stage cycle breakdown of one workgroup of score_kernel (needs a -DMCD_PROFILE build).
+usage (GPU box): python tools/stage_profile.py [variant]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "mocodad_amd", "libmocodad_hip_prof.so")
+if not os.path.exists(so):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMCD_PROFILE",
+                           "-o", so, os.path.join(ROOT, "mocodad_amd", "csrc", "mocodad_hip.hip")])
+if len(sys.argv) > 1:
+    os.environ["MCD_VARIANT"] = sys.argv[1]
+import torch
+from mocodad_amd import _lib
+_lib.LIB_PATH = so
+import bench
+from mocodad_amd.engine import HipScorer
+
+sd, cfg = bench.load_weights()
+sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5],
+               cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+L = _lib.lib()
+L.mcd_debug_set_prof.argtypes = [C.c_void_p]
+prof = torch.zeros(96, dtype=torch.int64, device="cuda:0")
+data = bench.synth_windows(1024, 6, 1).cuda()
+sc.score(data, n_samples=5, noise_steps=10, seed=1)
+torch.cuda.synchronize()
+L.mcd_debug_set_prof(C.c_void_p(prof.data_ptr()))
+sc.score(data, n_samples=5, noise_steps=10, seed=1)
+torch.cuda.synchronize()
+p = prof.cpu().numpy().astype(float)
+names = ["emb-se+L0mix", "emb table", "L0 2->16", "L1 sd1.0", "L2 sd1.1", "down1", "L3 sd2.0", "L4 sd2.1", "down2", "L5 sd3.0",
+         "L6 gemm(P)", "L6 mix+epi", "up3+skip", "L7 su4.0", "L8 su4.1", "up2+skip", "L9 su3.0", "L10+ddpm"]
+sub = p[32:32 + 33].reshape(11, 3)   # per layer: mix, gemm (epilogue time is accounted to the stage ids below)
+for l in range(11):
+    if sub[l, :2].sum() > 0:
+        idx = {1: 3, 2: 4, 3: 6, 4: 7, 5: 9, 7: 13, 8: 14, 9: 16}[l]
+        p[idx] += sub[l, 0] + sub[l, 1]
+tot = p[:18].sum()
+print(f"variant={os.environ.get('MCD_VARIANT','0')}  cycles per pass (9 passes): total {tot/9:.0f}")
+lay = {3: 1, 4: 2, 6: 3, 7: 4, 9: 5, 13: 7, 14: 8, 16: 9}
+for i, (n, v) in enumerate(zip(names, p)):
+    extra = ""
+    if i in lay:
+        l = lay[i]
+        extra = f"   mix {sub[l,0]/9:7.0f}  gemm {sub[l,1]/9:7.0f}  epilogue {(v - sub[l,0] - sub[l,1])/9:7.0f}"
+    print(f"  {n:14s} {v/9:9.0f}  {100*v/tot:5.1f}%{extra}")
