@@ -1,0 +1,122 @@
+"""GPU: the drop-in module surface (MoCoDAD.forward / test_step / on_test_epoch_end) against golden vectors and the
+oracle, the device scatter-max, and size-independent properties at the BASELINE batch size."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import golden_weights, make_args
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def _model(variant, **over):
+    from mocodad_amd.models.mocodad import MoCoDAD
+    sd, cfg = golden_weights(variant)
+    m = MoCoDAD(make_args(cfg, **over)).to("cuda:0")
+    m.load_state_dict(sd)
+    return m, sd, cfg
+
+
+@pytest.mark.parametrize("variant,ns,S", [("inject", 10, 5), ("concat", 10, 5), ("injtail", 10, 2), ("T12", 10, 2)])
+def test_forward_matches_reference_outputs(variant, ns, S):
+    g = load_golden(f"traj_{variant}_ns{ns}_S{S}.npz")
+    m, _, _ = _model(variant, noise_steps=ns, n_generated_samples=S)
+    batch = [torch.from_numpy(g[k]) for k in ("data", "trans", "meta", "frames")]
+    noise = torch.from_numpy(g["noise"].astype(np.float32))
+    for aggr in ("best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3", "all"):
+        key = aggr.replace(":", "_").replace(".", "p")
+        out = m.forward(batch, aggr_strategy=aggr, return_="all", noise=noise)
+        assert len(out) == 6 and out[2].shape == batch[0].shape and out[3] is batch[1]
+        np.testing.assert_allclose(out[0].cpu().numpy(), g[f"loss_{key}"], atol=ATOL, rtol=0, err_msg=aggr)
+        if f"pose_{key}" in g:
+            np.testing.assert_allclose(out[1].cpu().numpy(), g[f"pose_{key}"], atol=ATOL, rtol=1e-5, err_msg=aggr)
+        elif aggr == "all":
+            np.testing.assert_allclose(out[1].cpu().numpy(), g["poses_all"], atol=ATOL, rtol=1e-5)
+        else:
+            assert out[1] is None
+    only_loss = m.forward(batch, aggr_strategy="best", return_="loss", noise=noise)
+    assert len(only_loss) == 5
+    with pytest.raises(ValueError):
+        m.forward(batch, aggr_strategy="nope", noise=noise)
+    m.model_return_value = None
+    with pytest.raises(ValueError):
+        m.forward(batch, noise=noise)
+
+
+def test_reload_state_dict_repacks():
+    m, sd, _ = _model("inject", noise_steps=4, n_generated_samples=2)
+    gen = torch.Generator().manual_seed(3)
+    batch = [torch.randn(8, 2, 6, 17, generator=gen), torch.zeros(8), torch.zeros(8, 4), torch.zeros(8, 6)]
+    noise = torch.randn(2, 3, 8, 2, 3, 17, generator=gen)
+    a = m.forward(batch, noise=noise)[0].clone()
+    sd2 = {k: (v * 1.01 if v.dtype.is_floating_point and "running_var" not in k else v) for k, v in sd.items()}
+    m.load_state_dict(sd2)
+    b = m.forward(batch, noise=noise)[0]
+    assert not torch.allclose(a, b)
+    m.load_state_dict(sd)
+    assert torch.equal(a, m.forward(batch, noise=noise)[0])
+
+
+def test_test_loop_end_to_end_auc_vs_oracle(tmp_path):
+    """test_step -> on_test_epoch_end -> AUC, against the oracle's scores pushed through the oracle's
+    post-processing (the reference's own loop: mocodad.py:230-274)."""
+    from mocodad_amd.data import synthetic
+    from oracle import mocodad_oracle as O
+    data, trans, meta, frames, gts = synthetic.make_dataset(n_clips=2, frames_per_clip=40, persons_per_clip=2, num_transform=2)
+    synthetic.write_gt(str(tmp_path), gts)
+    ns, S = 4, 2
+    m, sd, _ = _model("inject", noise_steps=ns, n_generated_samples=S, gt_path=str(tmp_path), num_transform=2,
+                      dataset_choice="HR-STC", pad_size=-1, filter_kernel_size=3, frames_shift=2, save_tensors=False)
+    gen = torch.Generator().manual_seed(11)
+    m.on_test_epoch_start()
+    ref_scores = []
+    for batch in synthetic.batches((data, trans, meta, frames), 100):
+        B = batch[0].shape[0]
+        noise = torch.randn(S, ns - 1, B, 2, 3, 17, generator=gen)
+        m._test_output_list.append(m.forward(batch, noise=noise))
+        with torch.no_grad():
+            ref_scores.append(O.score(sd, batch[0], noise, noise_steps=ns, aggregation="best")[1].numpy())
+    auc = m.on_test_epoch_end()
+    ref = np.concatenate(ref_scores)
+    auc_ref, _, _ = O.post_processing(ref, trans.numpy(), meta.numpy(), frames.numpy(), gts, num_transform=2, pad_size=-1,
+                                      filter_kernel_size=3, frames_shift=2)
+    assert abs(auc - auc_ref) < 1e-3, (auc, auc_ref)     # north_star: AUC within +-0.1 points (0.001 absolute)
+    assert m.logged["AUC"] == auc
+
+
+def test_device_scatter_max_matches_numpy():
+    from mocodad_amd.utils import eval_utils as EU
+    m, _, _ = _model("inject")
+    sc = m.scorer()
+    g = load_golden("postproc.npz")
+    gts = {}
+    for k in g:
+        if k.startswith("gt_"):
+            s_, c_ = k[3:].split("_")
+            gts[(int(s_), int(c_))] = g[k]
+    a, ka = EU.frame_score_rows(g["out"], g["trans"], g["meta"], g["frames"], gts, 5, scatter_max=None)
+    b, kb = EU.frame_score_rows(g["out"], g["trans"], g["meta"], g["frames"], gts, 5, scatter_max=sc.scatter_max)
+    assert np.array_equal(ka, kb)
+    np.testing.assert_allclose(a, b, rtol=1e-7, atol=0)
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] batch (1024 windows, ns=10, S=5): deterministic, invariant to how the batch is split
+    (noise keyed by global window id), finite, and best <= mean <= worst over the S samples."""
+    m, _, _ = _model("inject", noise_steps=10, n_generated_samples=5)
+    sc = m.scorer()
+    gen = torch.Generator().manual_seed(0)
+    data = torch.randn(1024, 2, 6, 17, generator=gen).clamp_(-5, 5)
+    loss, _ = sc.score(data, n_samples=5, noise_steps=10, seed=7)
+    loss2, _ = sc.score(data, n_samples=5, noise_steps=10, seed=7)
+    assert torch.equal(loss, loss2) and torch.isfinite(loss).all()
+    lo, _ = sc.score(data[:300], n_samples=5, noise_steps=10, seed=7, first_window_id=0)
+    hi, _ = sc.score(data[300:], n_samples=5, noise_steps=10, seed=7, first_window_id=300)
+    assert torch.equal(torch.cat([lo, hi]), loss)
+    best = sc.aggregate(data, loss, None, "best", noise_steps=10)[1]
+    mean = sc.aggregate(data, loss, None, "mean", noise_steps=10)[1]
+    worst = sc.aggregate(data, loss, None, "worst", noise_steps=10)[1]
+    assert torch.equal(best, loss.min(1)[0]) and torch.equal(worst, loss.max(1)[0])
+    assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
