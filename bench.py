@@ -82,7 +82,7 @@ def cpu_baseline(sd, ns, S, budget_s=15.0):
 
     run(32, 1)                      # warm-up (thread pool, allocator)
     probe = run(32, 2)
-    n = int(min(2048, max(64, 32 * budget_s / max(probe, 1e-3))))
+    n = int(min(16384, max(64, 32 * budget_s / max(probe, 1e-3))))
     n = max(64, n // 64 * 64)
     dt = run(n, 3)
     return {"value": round(n / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
