@@ -66,7 +66,7 @@ def usable_cores():
 
 def cpu_baseline(sd, ns, S, budget_s=15.0):
     """The oracle (a PyTorch-CPU op-for-op port of the reference path) timed on this host's cores, on a
-    bounded sample: a 32-window probe sizes the timed sample to about `budget_s` seconds."""
+    bounded sample: a 256-window probe sizes the timed sample to about `budget_s` seconds."""
     from oracle import mocodad_oracle as O
     threads = min(usable_cores(), 64)
     torch.set_num_threads(threads)
@@ -80,10 +80,10 @@ def cpu_baseline(sd, ns, S, budget_s=15.0):
             O.score(sd, data, noise, noise_steps=ns, aggregation="best")
         return time.perf_counter() - t0
 
-    run(32, 1)                      # warm-up (thread pool, allocator)
-    probe = run(32, 2)
-    n = int(min(16384, max(64, 32 * budget_s / max(probe, 1e-3))))
-    n = max(64, n // 64 * 64)
+    run(64, 1)                      # warm-up (thread pool, allocator)
+    probe = run(256, 2)
+    n = int(min(16384, max(256, 256 * budget_s / max(probe, 1e-3))))
+    n = max(256, n // 256 * 256)
     dt = run(n, 3)
     return {"value": round(n / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": f"one batch of {n} windows, ns={ns}, S={S}, oracle/mocodad_oracle.py (PyTorch CPU, {threads} threads), {dt:.1f}s"}

@@ -56,6 +56,8 @@ def main():
                          "pass --synthetic N here, or feed your DataLoader's batches to MoCoDAD.test_step")
 
     model = MoCoDAD(args).to(dev)
+    if cli.synthetic:
+        model.dataset_name = "synthetic"      # synthetic clips have their own lengths: no HR-Avenue / UBnormal frame masks
     ckpt = os.path.join(args.ckpt_dir, args.load_ckpt)
     if os.path.exists(ckpt):
         model.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"])
