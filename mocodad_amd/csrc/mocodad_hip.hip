@@ -79,8 +79,8 @@ enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_TQT = 5, F_AMT =
 //   tab[l*8 + F_BIAS]  folded bias, padded to 16
 //   tab[l*8 + F_SLOPE] PReLU slope (float bits)
 constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
-constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: lane-spread WdP[Vout][16] (lane i = Wd'[vo][v=i]), bd'P[32]
-constexpr int TAB_RST = 98;               // down1 only (Vin=17): tail[16], lane i = Wd'[vo=i][16]
+constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: MFMA A fragments WF[mt][ks][64] (lane (i,g) =
+                                          // Wd'[16mt+i][rs_vmap(ks,g)]) and bd' padded to 32
 typedef const int __attribute__((address_space(4))) cint;
 __device__ __forceinline__ int tab_i(const float* base, int idx) { return ((cint*)base)[idx]; }
 __device__ __forceinline__ float tab_f(const float* base, int idx) { return ((cfloat*)base)[idx]; }
@@ -188,6 +188,13 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// Joint handled by lane group g at k-step ks of the mix.  K-steps are paired over 8 consecutive joints so that the two
+// lane groups sharing an LDS access phase (g = 0,1 and g = 2,3) read rows 4 apart: with a row stride of 4*odd floats
+// that is a 16-bank shift, i.e. conflict-free ds_read_b32.  A trailing unpaired k-step uses joints 8p+g.
+__host__ __device__ constexpr int mix_vmap(int V, int ks, int g) {
+    return ks < 2 * (((V + 3) / 4) / 2) ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 8 * (((V + 3) / 4) / 2) + g;
+}
+
 // ------------------------------------------------------------------------------------------------
 // mix: Z[c,q,w] = sum_v ( sum_t X[c,t,v] T[v,t,q] ) A[q,v,w]          (stsgcn.py:154-155)
 // The joint mix runs on the matrix cores: for one (chain n, output frame q, block of 16 channels)
@@ -204,110 +211,152 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
                                           const float* __restrict__ bias, float slope, const float* emb,
                                           int wave, int lane) {
     constexpr int KS = (V + 3) / 4;
+    constexpr int KP = 2 * (KS / 2);                     // paired k-steps (see mix_vmap)
     constexpr int MT = (V + 15) / 16;
     constexpr int CB = CIN / 16;
-    constexpr int UNITS = NB * CB;                       // one unit = (chain, 16-channel block), all frames
-    constexpr int QC = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;   // output frames computed together
+    // output frames computed together by one unit: all of them (shared X reads) when that still gives every wave
+    // work, otherwise one frame per unit
+    constexpr int QALL = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;
+    constexpr int QC = (NB * CB * (T / QALL) >= NWAVES) ? QALL : 1;
+    constexpr int NQ = T / QC;
+    constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
     constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
     const int j = lane & 15, g = lane >> 4;
+    const int voff_pair = 4 * (g & 1) + (g >> 1);
     for (int u = wave; u < UNITS; u += NWAVES) {
-        const int cb = u % CB, n = u / CB;
-        const float* xin = in + (n * T * V + g) * cs_in + cb * 16 + j;
-#pragma unroll 1
-        for (int q0 = 0; q0 < T; q0 += QC) {
-            float tq[QC][NR], aop[QC][MT][KS];
+        const int q0 = (u % NQ) * QC, rest = u / NQ;
+        const int cb = rest % CB, n = rest / CB;
+        const float* xin_p = in + (n * T * V + voff_pair) * cs_in + cb * 16 + j;
+        const float* xin_l = in + (n * T * V + g) * cs_in + cb * 16 + j;
+        float tq[QC][NR], aop[QC][MT][KS];
 #pragma unroll
-            for (int qi = 0; qi < QC; ++qi) {
+        for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) tq[qi][r] = tqd[((q0 + qi) * NR + r) * 64 + lane];
+            for (int r = 0; r < NR; ++r) tq[qi][r] = tqd[((q0 + qi) * NR + r) * 64 + lane];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
-            }
-            float* zo = zout + ((n * T + q0) * V + 4 * g) * cs_z + cb * 16 + j;
-            f32x4 acc[QC][MT];
-#pragma unroll
-            for (int qi = 0; qi < QC; ++qi)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[qi][mt][r] = 0.f;
-                        if (EPI) { if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = zo[(qi * V + mt * 16 + r) * cs_z]; }
-                    }
-            static_for<KS>([&](auto si) {
-                constexpr int ks = decltype(si)::value;
-                float x[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) x[t] = xin[(t * V + 4 * ks) * cs_in];
-                static_for<QC>([&](auto qq) {
-                    constexpr int qi = decltype(qq)::value;
-                    // y = sum_t X[t, v=4ks+g] * T[v, t, q]   (coefficient (ks,t) = lane ks*T+t of this DPP row)
-                    float y = mul_bc<(ks * T) % 16, T == 1>(tq[qi][(ks * T) / 16], x[0]);
-                    static_for<T - 1>([&](auto ti) {
-                        constexpr int t = decltype(ti)::value + 1;
-                        fmac_bc<(ks * T + t) % 16, t == T - 1>(y, tq[qi][(ks * T + t) / 16], x[t]);
-                    });
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
-                });
-            });
-            float b = 0.f, e = 0.f;
-            if (EPI) { b = bias[cb * 16 + j]; e = emb[n * EMB_STRIDE + cb * 16 + j]; }
-#pragma unroll
-            for (int qi = 0; qi < QC; ++qi)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (mt * 16 + 4 * g + r < V)
-                            zo[(qi * V + mt * 16 + r) * cs_z] = EPI ? prelu(acc[qi][mt][r] + b, slope) + e : acc[qi][mt][r];
+                for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
         }
+        float* zo = zout + ((n * T + q0) * V + 4 * g) * cs_z + cb * 16 + j;
+        f32x4 acc[QC][MT];
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[qi][mt][r] = 0.f;
+                    if (EPI) { if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = zo[(qi * V + mt * 16 + r) * cs_z]; }
+                }
+        static_for<KS>([&](auto si) {
+            constexpr int ks = decltype(si)::value;
+            constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
+            const float* xb = ks < KP ? xin_p : xin_l;
+            float x[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) x[t] = xb[(t * V + vbase) * cs_in];
+            static_for<QC>([&](auto qq) {
+                constexpr int qi = decltype(qq)::value;
+                // y = sum_t X[t, v] * T[v, t, q]   (coefficient (ks,t) = lane ks*T+t of this DPP row)
+                float y = mul_bc<(ks * T) % 16, T == 1>(tq[qi][(ks * T) / 16], x[0]);
+                static_for<T - 1>([&](auto ti) {
+                    constexpr int t = decltype(ti)::value + 1;
+                    fmac_bc<(ks * T + t) % 16, t == T - 1>(y, tq[qi][(ks * T + t) / 16], x[t]);
+                });
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
+            });
+        });
+        float b = 0.f, e = 0.f;
+        if (EPI) { b = bias[cb * 16 + j]; e = emb[n * EMB_STRIDE + cb * 16 + j]; }
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mt * 16 + 4 * g + r < V)
+                        zo[(qi * V + mt * 16 + r) * cs_z] = EPI ? prelu(acc[qi][mt][r] + b, slope) + e : acc[qi][mt][r];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // joint resampling (CNN_layer over the joint axis, BN folded): out[n,c,t,v'] = b[v'] + sum_v W[v',v] X[n,c,t,v]
-// thread = (n, t, c); W rows lane-spread as in the mix (row vo: lane i = W[vo][v=i]).
+// on the matrix cores, one unit = (frame (n,t), 16-channel block):  D[v'][c] = sum_v W[v'][v] X[v][c].
+//   A operand: W fragments (pre-packed), B operand: X rows straight from LDS (one ds_read_b32 per k-step).
+// CAPTURE (down-samplers): the k-map is v = 4g + ks (ks < 4), 16 + g (ks = 4), so the B values a lane reads are
+//   exactly the rows {4g..4g+3 (,16)} it would own in an MFMA D fragment -> they are returned in `skip`
+//   (this IS the U-Net skip tensor d1 / d2, kept in registers; rows 4 apart -> conflict-free reads).
+// ADD (up-samplers): `skip` (captured by the matching down-sampler with the same unit -> wave mapping) is added
+//   to the D fragment before the store: no separate skip-add stage, no extra barrier.
 // ------------------------------------------------------------------------------------------------
-template <int C, int VIN, int VOUT, int T, int NB>
+template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE>
+struct RsCfg {
+    static constexpr int KS = CAPTURE ? (VIN > 16 ? 5 : 4) : (VIN + 3) / 4;
+    static constexpr int MT = (VOUT + 15) / 16;
+    static constexpr int CB = C / 16;
+    static constexpr int UNITS = NB * T * CB;
+    static constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;   // units per wave
+    static constexpr int VS = CAPTURE ? VIN : VOUT;              // joints of the skip tensor
+    static constexpr int SK = VS > 16 ? 5 : 4;                   // skip registers per unit
+};
+__host__ __device__ constexpr int rs_vmap(bool capture, int vin, int ks, int g) {
+    return capture ? (ks < 4 ? 4 * g + ks : 16 + g) : mix_vmap(vin, ks, g);
+}
+
+template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, int NSK>
 __device__ __forceinline__ void resample_stage(const float* in, int cs_in, float* out, int cs_out,
-                                               const float* __restrict__ wdp, const float* __restrict__ bdp,
-                                               const float* __restrict__ wtail, int tid) {
-    constexpr int UNITS = NB * T * C;
-    constexpr int VM = VIN < 16 ? VIN : 16;
-    constexpr int ROUNDS = (UNITS + NTHREADS - 1) / NTHREADS;
-    const int l15 = tid & 15;
-    float wr[VOUT];
+                                               const float* __restrict__ wf, const float* __restrict__ bdp,
+                                               float (&skip)[NSK], int wave, int lane) {
+    using RC = RsCfg<C, VIN, VOUT, T, NB, CAPTURE>;
+    constexpr int KS = RC::KS, MT = RC::MT, CB = RC::CB, UNITS = RC::UNITS, PER = RC::PER, SK = RC::SK;
+    static_assert(!(CAPTURE || ADD) || NSK == PER * SK, "skip register count");
+    constexpr int KP = 2 * (((VIN + 3) / 4) / 2);
+    const int j = lane & 15, g = lane >> 4;
+    float aop[MT][KS];
 #pragma unroll
-    for (int vo = 0; vo < VOUT; ++vo) wr[vo] = wdp[vo * 16 + l15];
-    const float b0 = bdp[l15], b1 = bdp[16 + l15];
-    float wt = 0.f;
-    if (VIN == 17) wt = wtail[l15];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int u = tid + r * NTHREADS;
-        const bool live = u < UNITS;
-        const int uc = live ? u : UNITS - 1;
-        const int c = uc % C, nt = uc / C;
-        float x[VIN];
+        for (int ks = 0; ks < KS; ++ks) aop[mt][ks] = wf[(mt * KS + ks) * 64 + lane];
+    float bias[MT][4];
 #pragma unroll
-        for (int v = 0; v < VIN; ++v) x[v] = in[(nt * VIN + v) * cs_in + c];
-        static_for<VOUT>([&](auto oi) {
-            constexpr int vo = decltype(oi)::value;
-            float o;
-            if constexpr (vo < 16) o = mov_bc<vo>(b0);
-            else o = mov_bc<vo - 16>(b1);
-            static_for<VM>([&](auto vi) {
-                constexpr int v = decltype(vi)::value;
-                fmac_bc<v>(o, wr[vo], x[v]);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mt][r] = bdp[mt * 16 + 4 * g + r];
+    static_for<PER>([&](auto pi) {
+        constexpr int i = decltype(pi)::value;
+        const int u = wave + i * NWAVES;
+        if (u < UNITS) {
+            const int cb = u % CB, nt = u / CB;
+            const float* xin = in + (nt * VIN) * cs_in + cb * 16 + j;
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+            static_for<KS>([&](auto si) {
+                constexpr int ks = decltype(si)::value;
+                int row;
+                if (CAPTURE) row = ks < 4 ? 4 * g + ks : 16 + g;
+                else row = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 4 * KP + g;
+                const float x = xin[row * cs_in];
+                if (CAPTURE) skip[i * SK + ks] = x;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
             });
-            if constexpr (VIN == 17) fmac_bc<vo>(o, wt, x[16]);
-            if (live) out[(nt * VOUT + vo) * cs_out + c] = o;
-        });
-    }
+            if (ADD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
+                if (SK == 5) acc[MT - 1][0] += skip[i * SK + 4];     // joint 16 lives in lane group g = 0, row 0 of m-tile 1
+            }
+            float* zo = out + (nt * VOUT + 4 * g) * cs_out + cb * 16 + j;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mt * 16 + 4 * g + r < VOUT) zo[(mt * 16 + r) * cs_out] = acc[mt][r];
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -317,32 +366,43 @@ __device__ __forceinline__ void resample_stage(const float* in, int cs_in, float
 //   of column n0+j with one ds_read_b64 -> two k-steps.  The packer applies the same K permutation.
 // Wave w owns m-tile w % MT and n-tiles (w / MT) + i * (8 / MT).
 // ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
 template <int MT, int NT>
 struct Tiling {
     static constexpr int NG = NWAVES / MT;
     static constexpr int MAXN = (NT + NG - 1) / NG;
 };
 
-template <int MT, int NT, int KQ1, int KQ2, bool IDRES>
-__device__ __forceinline__ void gemm_stage(const float4* __restrict__ wp, const float* b1, int cs1, const float* b2,
-                                           int cs2, f32x4 (&acc)[Tiling<MT, NT>::MAXN], int wave, int lane) {
-    constexpr int KQ = KQ1 + KQ2;
+// One 16x16 output tile at a time: accumulate over K (Z part from b1, X part from b2), then hand the accumulator
+// fragment to `epi(i, col, c0, acc)` (i = static tile slot of this wave, col = column of this lane, c0 = first of the
+// lane's 4 consecutive output channels).  The output buffer never aliases b1/b2 (3-region plan), so the epilogue
+// runs right behind the tile's MFMAs and no barrier separates GEMM and epilogue.
+// weight fragments of this wave's m-tile: issued early (before the barrier that precedes the GEMM) so that their L2
+// latency overlaps the mix stage
+template <int MT, int KQ>
+__device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int wave, int lane, float4 (&a)[KQ]) {
+    const float4* wpl = wp + ((wave % MT) * KQ) * 64 + lane;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) a[kq] = wpl[kq * 64];
+}
+
+template <int MT, int NT, int KQ1, int KQ2, bool IDRES, class Epi>
+__device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* b1, int cs1, const float* b2,
+                                           int cs2, int wave, int lane, Epi&& epi) {
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
     const int mt = wave % MT, ng = wave / MT;
-    float4 a[KQ];
-    const float4* wpl = wp + (mt * KQ) * 64 + lane;
-#pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) a[kq] = wpl[kq * 64];
     const int j = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < MAXN; ++i) {
+    const int c0 = mt * 16 + 4 * g;
+    static_for<MAXN>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
         const int nt = ng + i * NG;
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
         if (nt < NT) {
             const int col = nt * 16 + j;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
             if (IDRES) {
-                const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + mt * 16 + 4 * g);
+                const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + c0);
                 c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
             }
             const float* p1 = b1 + col * cs1 + 2 * g;
@@ -367,103 +427,80 @@ __device__ __forceinline__ void gemm_stage(const float4* __restrict__ wp, const 
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].w, w.y, c, 0, 0, 0);
                 }
             }
+            epi(ii, col, c0, c);
         }
-        acc[i] = c;
-    }
+    });
 }
 
-// epilogue of a mix-first layer: out = PReLU(acc + bias) + emb   (stsgcn.py:109-114)
-template <int MT, int NT, int COUT, int COLS, int TV, bool RAW>
-__device__ __forceinline__ void epilogue_store(float* out, int cs_out, f32x4 (&acc)[Tiling<MT, NT>::MAXN],
-                                               const float* __restrict__ bias, float slope, const float* emb,
-                                               int wave, int lane) {
-    constexpr int NG = Tiling<MT, NT>::NG;
-    constexpr int MAXN = Tiling<MT, NT>::MAXN;
-    const int mt = wave % MT, ng = wave / MT;
-    const int j = lane & 15, g = lane >> 4;
-    const int c0 = mt * 16 + 4 * g;
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!RAW && c0 < COUT) b = *reinterpret_cast<const float4*>(bias + c0);
-#pragma unroll
-    for (int i = 0; i < MAXN; ++i) {
-        const int nt = ng + i * NG;
-        const int col = nt * 16 + j;
-        if (nt < NT && col < COLS && c0 < COUT) {
-            float4 v;
-            if (RAW) {
-                v = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-            } else {
-                const int n = col / TV;
-                const float4 e = *reinterpret_cast<const float4*>(emb + n * EMB_STRIDE + c0);
-                v.x = prelu(acc[i][0] + b.x, slope) + e.x;
-                v.y = prelu(acc[i][1] + b.y, slope) + e.y;
-                v.z = prelu(acc[i][2] + b.z, slope) + e.z;
-                v.w = prelu(acc[i][3] + b.w, slope) + e.w;
-                acc[i][0] = v.x; acc[i][1] = v.y; acc[i][2] = v.z; acc[i][3] = v.w;  // kept for skip capture
-            }
-            *reinterpret_cast<float4*>(out + col * cs_out + c0) = v;
-        }
-    }
-}
-
-// add a register-resident skip tensor (held in the accumulator layout of the layer that made it)
-template <int MT, int NT, int COLS>
-__device__ __forceinline__ void add_skip(const f32x4 (&skip)[Tiling<MT, NT>::MAXN], float* buf, int cs, int wave,
-                                         int lane) {
-    constexpr int NG = Tiling<MT, NT>::NG;
-    constexpr int MAXN = Tiling<MT, NT>::MAXN;
-    const int mt = wave % MT, ng = wave / MT;
-    const int j = lane & 15, g = lane >> 4;
-    const int c0 = mt * 16 + 4 * g;
-#pragma unroll
-    for (int i = 0; i < MAXN; ++i) {
-        const int nt = ng + i * NG;
-        const int col = nt * 16 + j;
-        if (nt < NT && col < COLS) {
-            float4* p = reinterpret_cast<float4*>(buf + col * cs + c0);
-            float4 v = *p;
-            v.x += skip[i][0]; v.y += skip[i][1]; v.z += skip[i][2]; v.w += skip[i][3];
-            *p = v;
-        }
-    }
-}
-
-// one mix-first ST-GCN layer, LDS in -> LDS out (out may alias in / z: it is written after a barrier)
+// one mix-first ST-GCN layer: LDS `in` -> `out`, with `z` as scratch; the three regions are disjoint.
 template <int L, int T, int NB>
 __device__ __forceinline__ void layer_std(const float* wb, const float* in, float* z, float* out, const float* emb,
-                                          f32x4 (&acc)[Tiling<ceil16(layer_desc(L).cout) / 16,
-                                                              ceil16(NB * T * layer_desc(L).V) / 16>::MAXN],
                                           int wave, int lane, Prof& prof) {
     constexpr LDesc D = layer_desc(L);
     constexpr int MT = ceil16(D.cout) / 16;
     constexpr int COLS = NB * T * D.V;
     constexpr int NT = ceil16(COLS) / 16;
+    constexpr int TV = T * D.V;
     constexpr int CSI = cs_of(D.cin), CSO = cs_of(D.cout);
+    constexpr int KQ1 = D.cin / 16, KQ2 = D.res ? D.cin / 16 : 0;
     const LayerW lw = layer_w(wb, L);
+    float4 afr[KQ1 + KQ2];
+    load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     mix_stage<D.cin, D.V, T, NB, false>(in, CSI, z, CSI, wb + lw.tq, wb + lw.am, nullptr, 0.f, nullptr, wave, lane);
     __syncthreads();
     prof.mark(32 + 3 * L);
-    gemm_stage<MT, NT, D.cin / 16, D.res ? D.cin / 16 : 0, !D.res>(
-        reinterpret_cast<const float4*>(wb + lw.wp), z, CSI, in, CSI, acc, wave, lane);
+    const float* bias = wb + lw.bias;
+    const float slope = lw.slope;
+    const float* embl = emb + emb_off(L);
+    gemm_tiles<MT, NT, KQ1, KQ2, !D.res>(
+        afr, z, CSI, in, CSI, wave, lane,
+        [&](auto, int col, int c0, f32x4 acc) {
+            if (col < COLS && c0 < D.cout) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + c0);
+                const float4 e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
+                float4 v;
+                v.x = prelu(acc[0] + b.x, slope) + e.x;
+                v.y = prelu(acc[1] + b.y, slope) + e.y;
+                v.z = prelu(acc[2] + b.z, slope) + e.z;
+                v.w = prelu(acc[3] + b.w, slope) + e.w;
+                *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
+            }
+        });
     __syncthreads();
     prof.mark(33 + 3 * L);
-    epilogue_store<MT, NT, D.cout, COLS, T * D.V, false>(out, CSO, acc, wb + lw.bias, lw.slope, emb + emb_off(L), wave,
-                                                         lane);
-    __syncthreads();
 }
 
-__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
-
+// LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
+// tables.  Sizes follow the padded column counts P17/P12/P10 and the row strides C+4.
 template <int T, int NB>
 struct Plan {
     static constexpr int NBT = NB * T;
     static constexpr int P17 = ceil16(NBT * 17), P12 = ceil16(NBT * 12), P10 = ceil16(NBT * 10);
-    static constexpr int A0 = cmax(cmax(P10 * 132, P12 * 68), cmax(2 * P17 * 20, P17 * 36));
-    static constexpr int A1 = cmax(cmax(P17 * 36, P12 * 68), P10 * 68);
+    static constexpr int s16 = P17 * 20, s32a = P17 * 36, s32b = P12 * 36, s64b = P12 * 68, s64c = P10 * 68, s128 = P10 * 132;
+    // (in, z, out) offsets of every stage
+    static constexpr int L0_out = 2 * s16;
+    static constexpr int L1_in = 2 * s16, L1_z = 0, L1_out = 3 * s16;
+    static constexpr int L2_in = 3 * s16, L2_z = 0, L2_out = 3 * s16 + s32a;
+    static constexpr int DN1_out = 0;
+    static constexpr int L3_in = 0, L3_z = s32b, L3_out = 2 * s32b;
+    static constexpr int L4_in = 2 * s32b, L4_z = 2 * s32b + s64b, L4_out = 0;
+    static constexpr int DN2_out = s128 + s64c;
+    static constexpr int L5_in = s128 + s64c, L5_z = s128, L5_out = 0;
+    static constexpr int L6_in = 0, L6_p = s128;
+    static constexpr int UP3_out = 0;
+    static constexpr int L7_in = 0, L7_z = s64b, L7_out = 2 * s64b;
+    static constexpr int L8_in = 2 * s64b, L8_z = 0, L8_out = s64b;
+    static constexpr int UP2_out = s64b + s32b;
+    static constexpr int L9_in = s64b + s32b, L9_z = 0, L9_out = s32a;
+    static constexpr int L10_in = s32a, L10_z = 2 * s32a;
+    static constexpr int R = cmax(cmax(cmax(s128 + 2 * s64c, 2 * s128), cmax(3 * s16 + 2 * s32a, 2 * s32b + 2 * s64b)),
+                                  cmax(3 * s64b, 3 * s32a));
+    static_assert(s32a <= 3 * s16 && s64b <= 2 * s32b && 2 * s32a <= s64b + s32b && s32a <= s64b && s64b <= s128,
+                  "LDS plan: regions would overlap");
     static constexpr int XT = P17 * 4;
     static constexpr int EMB = NB * EMB_STRIDE;
     static constexpr int SE = NB * EDIM;
-    static constexpr int TOTAL = A0 + A1 + XT + EMB + SE;
+    static constexpr int TOTAL = R + XT + EMB + SE;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -477,9 +514,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     constexpr int TV17 = T * 17;
     constexpr int COLS17 = NB * TV17;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const A0 = smem;
-    float* const A1 = A0 + PL::A0;
-    float* const XT = A1 + PL::A1;
+    float* const RG = smem;                 // work region (see Plan)
+    float* const XT = RG + PL::R;
     float* const EMB = XT + PL::XT;
     float* const SE = EMB + PL::EMB;
 
@@ -494,7 +530,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
 
     // zero the whole activation area once: pad columns / pad channels must hold finite values
-    for (int u = tid; u < PL::A0 + PL::A1 + PL::XT; u += NTHREADS) smem[u] = 0.f;
+    for (int u = tid; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
     __syncthreads();
 
     // ---- x_T (or the given x in single-pass mode) -> XT[col] = (x0, x1, z0, z1)
@@ -525,8 +561,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #ifdef MCD_PROFILE
     prof.p = P.prof; prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
-    f32x4 skip1[Tiling<2, PL::P17 / 16>::MAXN];
-    f32x4 skip2[Tiling<4, PL::P12 / 16>::MAXN];
+    // U-Net skip tensors d1 / d2, register-resident between the down- and the up-samplers
+    using RS1 = RsCfg<32, 17, 12, T, NB, true>;
+    using RS2 = RsCfg<64, 12, 10, T, NB, true>;
+    float skip1[RS1::PER * RS1::SK];
+    float skip2[RS2::PER * RS2::SK];
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
@@ -595,7 +634,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             for (int col = tid; col < COLS17; col += NTHREADS) {
                 const float4 xz = *reinterpret_cast<const float4*>(XT + col * 4);
                 const int n = col / TV17;
-                float* o = A0 + col * cs_of(16);
+                float* o = RG + PL::L0_out + col * cs_of(16);
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     float r[4];
@@ -616,89 +655,81 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         __syncthreads();
         STAGE(2);
         // ---- down path
-        {
-            f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
-            layer_std<1, T, NB>(wb, A0, A0 + PL::P17 * 20, A1, EMB, acc, wave, lane, prof);   // sd1.0: A16 -> B32 (A1)
-            STAGE(3);
-            layer_std<2, T, NB>(wb, A1, A0, A0, EMB, skip1, wave, lane, prof);                // sd1.1: B32 -> d1 (A0 + regs)
-            STAGE(4);
-        }
-        resample_stage<32, 17, 12, T, NB>(A0, 36, A1, 36, wb + tab_i(wb, TAB_RSW + 0), wb + tab_i(wb, TAB_RSB + 0), wb + tab_i(wb, TAB_RST), tid);  // down1
+        layer_std<1, T, NB>(wb, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof);  // sd1.0
+        STAGE(3);
+        layer_std<2, T, NB>(wb, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof);   // sd1.1 -> d1
+        STAGE(4);
+        resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, wb + tab_i(wb, TAB_RSW + 0),
+                                                       wb + tab_i(wb, TAB_RSB + 0), skip1, wave, lane);  // down1 (captures d1)
         __syncthreads();
         STAGE(5);
-        {
-            f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
-            layer_std<3, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane, prof);                  // sd2.0: C32 -> E64 (A0)
-            STAGE(6);
-            layer_std<4, T, NB>(wb, A0, A1, A1, EMB, skip2, wave, lane, prof);                // sd2.1: E64 -> d2 (A1 + regs)
-            STAGE(7);
-        }
-        resample_stage<64, 12, 10, T, NB>(A1, 68, A0, 68, wb + tab_i(wb, TAB_RSW + 1), wb + tab_i(wb, TAB_RSB + 1), wb + tab_i(wb, TAB_RST), tid);  // down2
+        layer_std<3, T, NB>(wb, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof);  // sd2.0
+        STAGE(6);
+        layer_std<4, T, NB>(wb, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof);   // sd2.1 -> d2
+        STAGE(7);
+        resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, wb + tab_i(wb, TAB_RSW + 1),
+                                                       wb + tab_i(wb, TAB_RSB + 1), skip2, wave, lane);  // down2 (captures d2)
         __syncthreads();
         STAGE(8);
         {
-            f32x4 acc[Tiling<8, PL::P10 / 16>::MAXN];
-            layer_std<5, T, NB>(wb, A0, A1, A0, EMB, acc, wave, lane, prof);                  // sd3.0: F64 -> G128 (A0)
+            layer_std<5, T, NB>(wb, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof);  // sd3.0
             STAGE(9);
         }
-        // ---- sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G  (in place), then mix(P_t) + P_r in place of P_r
+        // ---- sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G, then out = PReLU(mix(P_t) + P_r + b) + e in place of P_r
         {
             constexpr int NT = PL::P10 / 16;
-            f32x4 acc[Tiling<8, NT>::MAXN];
+            constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
-            gemm_stage<8, NT, 8, 0, false>(reinterpret_cast<const float4*>(wb + lw.wp), A0, 132, A0, 132, acc, wave, lane);
-            __syncthreads();
-            epilogue_store<8, NT, 128, NB * T * 10, T * 10, true>(A0, 132, acc, nullptr, 0.f, nullptr, wave, lane);
+            float* Pb = RG + PL::L6_p;
+            float4 afr[8];
+            load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+            gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132,
+                                           wave, lane, [&](auto, int col, int c0, f32x4 acc) {
+                if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            });
             __syncthreads();
             STAGE(10);
-            mix_stage<64, 10, T, NB, true>(A0, 132, A0 + 64, 132, wb + lw.tq, wb + lw.am, wb + lw.bias, lw.slope,
+            mix_stage<64, 10, T, NB, true>(Pb, 132, Pb + 64, 132, wb + lw.tq, wb + lw.am, wb + lw.bias, lw.slope,
                                            EMB + emb_off(6), wave, lane);
             __syncthreads();
             STAGE(11);
         }
         // ---- up path
-        resample_stage<64, 10, 12, T, NB>(A0 + 64, 132, A1, 68, wb + tab_i(wb, TAB_RSW + 2), wb + tab_i(wb, TAB_RSB + 2), wb + tab_i(wb, TAB_RST), tid);  // up3
-        __syncthreads();
-        add_skip<4, PL::P12 / 16, NB * T * 12>(skip2, A1, 68, wave, lane);
+        resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, wb + tab_i(wb, TAB_RSW + 2),
+                                                       wb + tab_i(wb, TAB_RSB + 2), skip2, wave, lane);  // up3 (+ d2)
         __syncthreads();
         STAGE(12);
         {
-            f32x4 acc[Tiling<4, PL::P12 / 16>::MAXN];
-            layer_std<7, T, NB>(wb, A1, A0, A0, EMB, acc, wave, lane, prof);                  // su4.0: I64 -> J64 (A0)
+            layer_std<7, T, NB>(wb, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof);  // su4.0
             STAGE(13);
         }
         {
-            f32x4 acc[Tiling<2, PL::P12 / 16>::MAXN];
-            layer_std<8, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane, prof);                  // su4.1: J64 -> K32 (A1)
+            layer_std<8, T, NB>(wb, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof);  // su4.1
             STAGE(14);
         }
-        resample_stage<32, 12, 17, T, NB>(A1, 36, A0, 36, wb + tab_i(wb, TAB_RSW + 3), wb + tab_i(wb, TAB_RSB + 3), wb + tab_i(wb, TAB_RST), tid);  // up2
-        __syncthreads();
-        add_skip<2, PL::P17 / 16, COLS17>(skip1, A0, 36, wave, lane);
+        resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, wb + tab_i(wb, TAB_RSW + 3),
+                                                       wb + tab_i(wb, TAB_RSB + 3), skip1, wave, lane);  // up2 (+ d1)
         __syncthreads();
         STAGE(15);
         {
-            f32x4 acc[Tiling<2, PL::P17 / 16>::MAXN];
-            layer_std<9, T, NB>(wb, A0, A1, A1, EMB, acc, wave, lane, prof);                  // su3.0: L32 -> M32 (A1)
+            layer_std<9, T, NB>(wb, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof);  // su3.0
             STAGE(16);
         }
         // ---- su3.1 (32 -> 2) + U-Net residual (+X) + DDPM update
         {
             constexpr int NT = PL::P17 / 16;
-            constexpr int NG = Tiling<1, NT>::NG, MAXN = Tiling<1, NT>::MAXN;
-            f32x4 acc[MAXN];
             const LayerW lw = layer_w(wb, 10);
-            mix_stage<32, 17, T, NB, false>(A1, 36, A0, 36, wb + lw.tq, wb + lw.am, nullptr, 0.f, nullptr, wave, lane);
+            float4 afr[4];
+            load_afrags<1, 4>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+            mix_stage<32, 17, T, NB, false>(RG + PL::L10_in, 36, RG + PL::L10_z, 36, wb + lw.tq, wb + lw.am, nullptr, 0.f,
+                                            nullptr, wave, lane);
             __syncthreads();
-            gemm_stage<1, NT, 2, 2, false>(reinterpret_cast<const float4*>(wb + lw.wp), A0, 36, A1, 36, acc, wave, lane);
             const float ca = srow[0], cb = srow[1], csg = srow[2];
             const float* bias = wb + lw.bias;
-            const int j = lane & 15, g = lane >> 4;
-#pragma unroll
-            for (int i = 0; i < MAXN; ++i) {
-                const int nt = wave + i * NG;
-                const int col = nt * 16 + j;
-                if (nt < NT && col < COLS17 && g == 0) {
+            const float slope10 = lw.slope;
+            gemm_tiles<1, NT, 2, 2, false>(afr, RG + PL::L10_z, 36, RG + PL::L10_in, 36,
+                                           wave, lane, [&](auto, int col, int c0, f32x4 acc) {
+                if (col < COLS17 && c0 == 0) {
                     const int n = col / TV17, t = (col / 17) % T, v = col % 17;
                     int chain = chain0 + n;
                     const bool valid = chain < P.n_chains;
@@ -707,7 +738,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
                     for (int c = 0; c < C0; ++c) {
                         const float x = XT[col * 4 + c];
-                        const float eps = prelu(acc[i][c] + bias[c], lw.slope) + EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
+                        const float eps = prelu(acc[c] + bias[c], slope10) + EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
                         if (P.mode == 1) {
                             if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
                         } else if (t >= tf) {
@@ -722,7 +753,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                         }
                     }
                 }
-            }
+            });
             __syncthreads();
             STAGE(17);
         }
@@ -730,7 +761,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     if (P.mode == 1) return;
 
     // ---- per-chain loss: mean over (C, Tx, V) of loss_fn(x_0 - corrupt)   (mocodad.py:484)
-    float* RED = A0;
+    float* RED = RG;
     const int per = CTV;
     for (int u = tid; u < NB * per; u += NTHREADS) {
         const int n = u / per, e = u % per;
@@ -1004,11 +1035,11 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
     tqf = B.alloc((size_t)T * NR * 64);
     af = B.alloc((size_t)T * MT * KS * 64);
     for (int q = 0; q < T; ++q) for (int r = 0; r < NR; ++r) for (int lane = 0; lane < 64; ++lane) {
-        const int i = lane & 15, g = lane >> 4, idx = r * 16 + i, s = idx / T, t = idx % T, v = 4 * s + g;
+        const int i = lane & 15, g = lane >> 4, idx = r * 16 + i, s = idx / T, t = idx % T, v = mix_vmap(V, s, g);
         B.buf[tqf + (q * NR + r) * 64 + lane] = (idx < KS * T && v < V) ? Tm[(v * T + t) * T + q] : 0.f;
     }
     for (int q = 0; q < T; ++q) for (int s = 0; s < KS; ++s) for (int lane = 0; lane < 64; ++lane) {
-        const int j = lane & 15, g = lane >> 4, v = 4 * s + g;
+        const int j = lane & 15, g = lane >> 4, v = mix_vmap(V, s, g);
         for (int mt = 0; mt < MT; ++mt) {
             const int w = mt * 16 + j;
             B.buf[af + ((q * MT + mt) * KS + s) * 64 + lane] = (v < V && w < V) ? A[(q * V + v) * V + w] : 0.f;
@@ -1084,7 +1115,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
 
     Builder B;
     struct HostLayer { int tq, am, wp, bias, tqt, amt; float slope; };
-    struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4], rs_t; } U;
+    struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4]; } U;
     memset(&U, 0, sizeof(U));
     B.alloc(TAB_FLOATS);  // offset table lives at the start of the buffer
     static const char* names[NLAYERS] = {"st_gcnnsp1a.0", "st_gcnnsd1.0", "st_gcnnsd1.1", "st_gcnnsd2.0", "st_gcnnsd2.1",
@@ -1149,15 +1180,16 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         Folded f;
         const std::string p = std::string("model.") + rs_names[r];
         if (!fold_conv_bn(tm, p + ".block.0", p + ".block.1", rs_out[r], rs_in[r], f)) return fail(MCD_EMISSING, tm.missing);
-        const int vin = rs_in[r], vout = rs_out[r], vm = vin < 16 ? vin : 16;
-        U.rs_w[r] = B.alloc((size_t)vout * 16);
+        const int vin = rs_in[r], vout = rs_out[r];
+        const bool capture = r < 2;   // the down-samplers capture the skip tensors (see resample_stage)
+        const int KS = capture ? (vin > 16 ? 5 : 4) : (vin + 3) / 4, MTr = (vout + 15) / 16;
+        U.rs_w[r] = B.alloc((size_t)MTr * KS * 64);
         U.rs_b[r] = B.alloc(32);
-        for (int vo = 0; vo < vout; ++vo) for (int i = 0; i < vm; ++i) B.buf[U.rs_w[r] + vo * 16 + i] = (float)f.w[(size_t)vo * vin + i];
-        for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_b[r] + vo] = (float)f.b[vo];
-        if (r == 0) {  // down1: Vin = 17 -> tail column
-            U.rs_t = B.alloc(16);
-            for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_t + vo] = (float)f.w[(size_t)vo * vin + 16];
+        for (int mt = 0; mt < MTr; ++mt) for (int ks = 0; ks < KS; ++ks) for (int lane = 0; lane < 64; ++lane) {
+            const int vo = mt * 16 + (lane & 15), v = rs_vmap(capture, vin, ks, lane >> 4);
+            B.buf[U.rs_w[r] + (mt * KS + ks) * 64 + lane] = (vo < vout && v < vin) ? (float)f.w[(size_t)vo * vin + v] : 0.f;
         }
+        for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_b[r] + vo] = (float)f.b[vo];
     }
     // condition encoder
     CondW Cw;
@@ -1208,7 +1240,6 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         }
         tab[TAB_WE] = U.we; tab[TAB_BE] = U.be;
         for (int r = 0; r < 4; ++r) { tab[TAB_RSW + r] = U.rs_w[r]; tab[TAB_RSB + r] = U.rs_b[r]; }
-        tab[TAB_RST] = U.rs_t;
     }
     HIP_TRY(hipSetDevice(device));
     mcd_weights* w = new mcd_weights();
