@@ -40,6 +40,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // read-only model coefficients addressed wave-uniformly go through the constant address space so that the
 // compiler emits scalar loads (s_load_dwordx16) and feeds them to v_fmac as SGPR operands
 typedef const float __attribute__((address_space(4))) cfloat;
+// Explicit global address space for the packed-weight pointers: after the per-step laundering of the base pointer
+// the compiler can no longer infer it and would emit FLAT loads, which tick vmcnt AND lgkmcnt and force every
+// LDS wait to also drain the outstanding weight loads.
+typedef const float __attribute__((address_space(1))) gfloat;
+typedef const f32x4 __attribute__((address_space(1))) gf32x4;
+__device__ __forceinline__ gfloat* as_global(const float* p) { return (gfloat*)p; }
+__device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byte aligned global load
+    const f32x4 v = *(gf32x4*)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)p; }
 
 constexpr int NTHREADS = 512;
@@ -221,6 +231,9 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
     constexpr int NQ = T / QC;
     constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
     constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
+    gfloat* tqd_g = as_global(tqd);
+    gfloat* af_g = as_global(af);
+    gfloat* bias_g = as_global(bias);
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
     for (int u = wave; u < UNITS; u += NWAVES) {
@@ -232,11 +245,11 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) tq[qi][r] = tqd[((q0 + qi) * NR + r) * 64 + lane];
+            for (int r = 0; r < NR; ++r) tq[qi][r] = tqd_g[((q0 + qi) * NR + r) * 64 + lane];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
+                for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
         }
         float* zo = zout + ((n * T + q0) * V + 4 * g) * cs_z + cb * 16 + j;
         f32x4 acc[QC][MT];
@@ -270,7 +283,7 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
             });
         });
         float b = 0.f, e = 0.f;
-        if (EPI) { b = bias[cb * 16 + j]; e = emb[n * EMB_STRIDE + cb * 16 + j]; }
+        if (EPI) { b = bias_g[cb * 16 + j]; e = emb[n * EMB_STRIDE + cb * 16 + j]; }
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi)
 #pragma unroll
@@ -314,17 +327,19 @@ __device__ __forceinline__ void resample_stage(const float* in, int cs_in, float
     constexpr int KS = RC::KS, MT = RC::MT, CB = RC::CB, UNITS = RC::UNITS, PER = RC::PER, SK = RC::SK;
     static_assert(!(CAPTURE || ADD) || NSK == PER * SK, "skip register count");
     constexpr int KP = 2 * (((VIN + 3) / 4) / 2);
+    gfloat* wf_g = as_global(wf);
+    gfloat* bdp_g = as_global(bdp);
     const int j = lane & 15, g = lane >> 4;
     float aop[MT][KS];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) aop[mt][ks] = wf[(mt * KS + ks) * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) aop[mt][ks] = wf_g[(mt * KS + ks) * 64 + lane];
     float bias[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[mt][r] = bdp[mt * 16 + 4 * g + r];
+        for (int r = 0; r < 4; ++r) bias[mt][r] = bdp_g[mt * 16 + 4 * g + r];
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
@@ -382,9 +397,9 @@ struct Tiling {
 // latency overlaps the mix stage
 template <int MT, int KQ>
 __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int wave, int lane, float4 (&a)[KQ]) {
-    const float4* wpl = wp + ((wave % MT) * KQ) * 64 + lane;
+    const float* wpl = reinterpret_cast<const float*>(wp + ((wave % MT) * KQ) * 64 + lane);
 #pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) a[kq] = wpl[kq * 64];
+    for (int kq = 0; kq < KQ; ++kq) a[kq] = load_global4(wpl + kq * 256);
 }
 
 template <int MT, int NT, int KQ1, int KQ2, bool IDRES, class Epi>
@@ -456,7 +471,7 @@ __device__ __forceinline__ void layer_std(const float* wb, const float* in, floa
         afr, z, CSI, in, CSI, wave, lane,
         [&](auto, int col, int c0, f32x4 acc) {
             if (col < COLS && c0 < D.cout) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + c0);
+                const float4 b = load_global4(bias + c0);
                 const float4 e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
                 float4 v;
                 v.x = prelu(acc[0] + b.x, slope) + e.x;
@@ -591,8 +606,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         // ---- layer 0 mix on the 2 coordinate channels: thread = (col, c)
         {
-            const float* Tq = wb + tab_i(wb, F_TQ);
-            const float* Am = wb + tab_i(wb, F_AM);
+            gfloat* Tq = as_global(wb + tab_i(wb, F_TQ));
+            gfloat* Am = as_global(wb + tab_i(wb, F_AM));
             for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
                 const int c = u % C0, col = u / C0;
                 const int nq = col / 17, w = col % 17;  // nq = n*T + q
@@ -611,12 +626,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(0);
         for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
             const int n = u / EMB_TOTAL, o = u % EMB_TOTAL;
-            const float4* wr = reinterpret_cast<const float4*>(wb + tab_i(wb, TAB_WE) + o * EDIM);
+            const float* wr = wb + tab_i(wb, TAB_WE) + o * EDIM;
             const float* se = SE + n * EDIM;
-            float a = wb[tab_i(wb, TAB_BE) + o];
+            float a = as_global(wb)[tab_i(wb, TAB_BE) + o];
 #pragma unroll
             for (int k4 = 0; k4 < EDIM / 4; ++k4) {
-                const float4 w4 = wr[k4];
+                const float4 w4 = load_global4(wr + k4 * 4);
                 a = fmaf(w4.x, se[k4 * 4 + 0], a);
                 a = fmaf(w4.y, se[k4 * 4 + 1], a);
                 a = fmaf(w4.z, se[k4 * 4 + 2], a);
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                             nullptr, wave, lane);
             __syncthreads();
             const float ca = srow[0], cb = srow[1], csg = srow[2];
-            const float* bias = wb + lw.bias;
+            gfloat* bias = as_global(wb + lw.bias);
             const float slope10 = lw.slope;
             gemm_tiles<1, NT, 2, 2, false>(afr, RG + PL::L10_z, 36, RG + PL::L10_in, 36,
                                            wave, lane, [&](auto, int col, int c0, f32x4 acc) {
