@@ -66,7 +66,7 @@ __host__ __device__ constexpr int ceil16(int x) { return (x + 15) / 16 * 16; }
 // channel plan of STSAE_Unet (stsae_unet.py:255-357 defaults; mocodad.py:121-124 never overrides them)
 struct LDesc { int cin, cout, V, res; };
 __host__ __device__ constexpr LDesc layer_desc(int l) {
-    return l == 0 ? LDesc{2, 16, 17, 1} : l == 1 ? LDesc{16, 32, 17, 1} : l == 2 ? LDesc{32, 32, 17, 0}
+    return l == 0 ? LDesc{16, 16, 17, 1} /* 2 real input channels, K zero-padded */ : l == 1 ? LDesc{16, 32, 17, 1} : l == 2 ? LDesc{32, 32, 17, 0}
          : l == 3 ? LDesc{32, 64, 12, 1} : l == 4 ? LDesc{64, 64, 12, 0} : l == 5 ? LDesc{64, 128, 10, 1}
          : l == 6 ? LDesc{128, 64, 10, 1} : l == 7 ? LDesc{64, 64, 12, 0} : l == 8 ? LDesc{64, 32, 12, 1}
          : l == 9 ? LDesc{32, 32, 17, 0} : LDesc{32, 2, 17, 1};
@@ -89,6 +89,7 @@ enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_TQT = 5, F_AMT =
 //   tab[l*8 + F_BIAS]  folded bias, padded to 16
 //   tab[l*8 + F_SLOPE] PReLU slope (float bits)
 constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
+constexpr int TAB_WEF = 100;             // embedding Linear as MFMA A fragments WEF[34][4][64]
 constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: MFMA A fragments WF[mt][ks][64] (lane (i,g) =
                                           // Wd'[16mt+i][rs_vmap(ks,g)]) and bd' padded to 32
 typedef const int __attribute__((address_space(4))) cint;
@@ -213,13 +214,12 @@ __host__ __device__ constexpr int mix_vmap(int V, int ks, int g) {
 //     Y[v][c] = sum_t X[(n,t,v)][c] * T[v][t][q]  lane (j = c, g): v = 4s + g for k-step s  (T LDS reads + T FMAs)
 // V is padded to KS*4 rows (zero weights) and 16*MT output joints.  The D fragment (lane: channel j,
 // joints 4g..4g+3) is stored to Z[(n,q,w)][c].
-// EPI = true (W-first layers): out = PReLU(D + R + bias) + emb, stored in place of R (= zout).
+// init(n,q,w,c) seeds the accumulator (0, or the residual term of a W-first layer); store(n,q,w,c,val) consumes the
+// result (plain Z store, in-place PReLU epilogue of layer 6, or the fused DDPM update of layer 10).
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int V, int T, int NB, bool EPI>
-__device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zout, int cs_z,
-                                          const float* __restrict__ tqd, const float* __restrict__ af,
-                                          const float* __restrict__ bias, float slope, const float* emb,
-                                          int wave, int lane) {
+template <int CIN, int V, int T, int NB, class Init, class Store>
+__device__ __forceinline__ void mix_stage(const float* in, int cs_in, const float* __restrict__ tqd,
+                                          const float* __restrict__ af, int wave, int lane, Init&& init, Store&& store) {
     constexpr int KS = (V + 3) / 4;
     constexpr int KP = 2 * (KS / 2);                     // paired k-steps (see mix_vmap)
     constexpr int MT = (V + 15) / 16;
@@ -233,7 +233,6 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
     constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
     gfloat* tqd_g = as_global(tqd);
     gfloat* af_g = as_global(af);
-    gfloat* bias_g = as_global(bias);
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
     for (int u = wave; u < UNITS; u += NWAVES) {
@@ -251,7 +250,6 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
         }
-        float* zo = zout + ((n * T + q0) * V + 4 * g) * cs_z + cb * 16 + j;
         f32x4 acc[QC][MT];
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi)
@@ -260,7 +258,7 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[qi][mt][r] = 0.f;
-                    if (EPI) { if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = zo[(qi * V + mt * 16 + r) * cs_z]; }
+                    if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = init(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j);
                 }
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
@@ -282,16 +280,13 @@ __device__ __forceinline__ void mix_stage(const float* in, int cs_in, float* zou
                     acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
             });
         });
-        float b = 0.f, e = 0.f;
-        if (EPI) { b = bias_g[cb * 16 + j]; e = emb[n * EMB_STRIDE + cb * 16 + j]; }
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (mt * 16 + 4 * g + r < V)
-                        zo[(qi * V + mt * 16 + r) * cs_z] = EPI ? prelu(acc[qi][mt][r] + b, slope) + e : acc[qi][mt][r];
+                    if (mt * 16 + 4 * g + r < V) store(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j, acc[qi][mt][r]);
     }
 }
 
@@ -461,7 +456,9 @@ __device__ __forceinline__ void layer_std(const float* wb, const float* in, floa
     const LayerW lw = layer_w(wb, L);
     float4 afr[KQ1 + KQ2];
     load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
-    mix_stage<D.cin, D.V, T, NB, false>(in, CSI, z, CSI, wb + lw.tq, wb + lw.am, nullptr, 0.f, nullptr, wave, lane);
+    mix_stage<D.cin, D.V, T, NB>(in, CSI, wb + lw.tq, wb + lw.am, wave, lane,
+                                 [](int, int, int, int) { return 0.f; },
+                                 [&](int n, int q, int w, int c, float v) { z[((n * T + q) * D.V + w) * CSI + c] = v; });
     __syncthreads();
     prof.mark(32 + 3 * L);
     const float* bias = wb + lw.bias;
@@ -493,7 +490,7 @@ struct Plan {
     static constexpr int P17 = ceil16(NBT * 17), P12 = ceil16(NBT * 12), P10 = ceil16(NBT * 10);
     static constexpr int s16 = P17 * 20, s32a = P17 * 36, s32b = P12 * 36, s64b = P12 * 68, s64c = P10 * 68, s128 = P10 * 132;
     // (in, z, out) offsets of every stage
-    static constexpr int L0_out = 2 * s16;
+    static constexpr int L0_in = 0, L0_z = s16, L0_out = 2 * s16;
     static constexpr int L1_in = 2 * s16, L1_z = 0, L1_out = 3 * s16;
     static constexpr int L2_in = 3 * s16, L2_z = 0, L2_out = 3 * s16 + s32a;
     static constexpr int DN1_out = 0;
@@ -507,7 +504,7 @@ struct Plan {
     static constexpr int L8_in = 2 * s64b, L8_z = 0, L8_out = s64b;
     static constexpr int UP2_out = s64b + s32b;
     static constexpr int L9_in = s64b + s32b, L9_z = 0, L9_out = s32a;
-    static constexpr int L10_in = s32a, L10_z = 2 * s32a;
+    static constexpr int L10_in = s32a, L10_p = 2 * s32a;
     static constexpr int R = cmax(cmax(cmax(s128 + 2 * s64c, 2 * s128), cmax(3 * s16 + 2 * s32a, 2 * s32b + 2 * s64b)),
                                   cmax(3 * s64b, 3 * s32a));
     static_assert(s32a <= 3 * s16 && s64b <= 2 * s32b && 2 * s32a <= s64b + s32b && s32a <= s64b && s64b <= s128,
@@ -515,7 +512,8 @@ struct Plan {
     static constexpr int XT = P17 * 4;
     static constexpr int EMB = NB * EMB_STRIDE;
     static constexpr int SE = NB * EDIM;
-    static constexpr int TOTAL = R + XT + EMB + SE;
+    static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
+    static constexpr int TOTAL = R + XT + EMB + SE + ZN;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -533,6 +531,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     float* const XT = RG + PL::R;
     float* const EMB = XT + PL::XT;
     float* const SE = EMB + PL::EMB;
+    float* const ZN = SE + PL::SE;
 
     const int tid0 = threadIdx.x;
     int tid = tid0;
@@ -594,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // ---- embeddings of this step: e' = W_e SiLU(pe(i) + cond) + b_e for all 11 layers
+        // ---- step prologue: SE = SiLU(pe(i) + cond) and the U-Net input as a 16-channel block X20 (x in ch 0,1)
         if (tid < NB * EDIM) {
             const int n = tid / EDIM, k = tid % EDIM;
             int chain = chain0 + n;
@@ -604,70 +603,60 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (P.cond_emb) e += P.cond_emb[b * EDIM + k];
             SE[tid] = e / (1.f + expf(-e));
         }
-        // ---- layer 0 mix on the 2 coordinate channels: thread = (col, c)
-        {
-            gfloat* Tq = as_global(wb + tab_i(wb, F_TQ));
-            gfloat* Am = as_global(wb + tab_i(wb, F_AM));
+        // this step's noise z (one element per thread: the Philox + Box-Muller cost is paid here, fully parallel,
+        // not in the narrow epilogue of the last layer)
+        if (P.mode == 0 && sidx > 1) {
             for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
                 const int c = u % C0, col = u / C0;
-                const int nq = col / 17, w = col % 17;  // nq = n*T + q
-                const int n = nq / T, q = nq % T;
+                const int n = col / TV17, t = (col / 17) % T, v = col % 17;
                 float z = 0.f;
-                for (int v = 0; v < 17; ++v) {
-                    float y = 0.f;
-#pragma unroll
-                    for (int t = 0; t < T; ++t) y = fmaf(XT[((n * T + t) * 17 + v) * 4 + c], Tq[(q * 17 + v) * T + t], y);
-                    z = fmaf(y, Am[(q * 17 + v) * 17 + w], z);
+                if (t >= tf) {
+                    int chain = chain0 + n;
+                    if (chain >= P.n_chains) chain = P.n_chains - 1;
+                    const int b = chain / P.S, s = chain % P.S;
+                    const int e = (c * Tx + (t - tf)) * 17 + v;
+                    const int k = P.ns - sidx;
+                    if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
+                    else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
                 }
-                XT[col * 4 + 2 + c] = z;
+                ZN[u] = z;
             }
+        }
+        for (int u = tid; u < COLS17 * 4; u += NTHREADS) {
+            const int col = u >> 2, c4 = (u & 3) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 == 0) { v.x = XT[col * 4 + 0]; v.y = XT[col * 4 + 1]; }
+            *reinterpret_cast<float4*>(RG + PL::L0_in + col * 20 + c4) = v;
         }
         __syncthreads();
         STAGE(0);
-        for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
-            const int n = u / EMB_TOTAL, o = u % EMB_TOTAL;
-            const float* wr = wb + tab_i(wb, TAB_WE) + o * EDIM;
-            const float* se = SE + n * EDIM;
-            float a = as_global(wb)[tab_i(wb, TAB_BE) + o];
-#pragma unroll
-            for (int k4 = 0; k4 < EDIM / 4; ++k4) {
-                const float4 w4 = load_global4(wr + k4 * 4);
-                a = fmaf(w4.x, se[k4 * 4 + 0], a);
-                a = fmaf(w4.y, se[k4 * 4 + 1], a);
-                a = fmaf(w4.z, se[k4 * 4 + 2], a);
-                a = fmaf(w4.w, se[k4 * 4 + 3], a);
-            }
-            EMB[n * EMB_STRIDE + o] = a;
-        }
-        __syncthreads();
-        STAGE(1);
-        // ---- layer 0 (2 -> 16, V=17) on the VALU: thread = column
+        // ---- embeddings of this step for all 11 layers on the matrix cores: EMB[n][o] = b_e[o] + sum_k W_e[o][k] SE[n][k]
+        //      (M = 532 outputs in 34 m-tiles, K = 16, N = chains padded to 16; same stage as the layer-0 mix)
         {
-            const LayerW lw = layer_w(wb, 0);
-            cfloat* w0 = as_const(wb + lw.wp);   // [16][4] = (Wt0, Wt1, Wr0, Wr1)
-            cfloat* b0 = as_const(wb + lw.bias);
-            for (int col = tid; col < COLS17; col += NTHREADS) {
-                const float4 xz = *reinterpret_cast<const float4*>(XT + col * 4);
-                const int n = col / TV17;
-                float* o = RG + PL::L0_out + col * cs_of(16);
+            gfloat* wef = as_global(wb + tab_i(wb, TAB_WEF));
+            gfloat* beg = as_global(wb + tab_i(wb, TAB_BE));
+            const int j = lane & 15, g = lane >> 4;
+            float bk[4];
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    float r[4];
+            for (int ks = 0; ks < 4; ++ks) bk[ks] = j < NB ? SE[j * EDIM + 4 * ks + g] : 0.f;
+            constexpr int EMT = (EMB_TOTAL + 15) / 16;
+#pragma unroll 1
+            for (int mt = wave; mt < EMT; mt += NWAVES) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int co = c4 * 4 + k;
-                        float a = b0[co];
-                        a = fmaf(w0[co * 4 + 0], xz.z, a);
-                        a = fmaf(w0[co * 4 + 1], xz.w, a);
-                        a = fmaf(w0[co * 4 + 2], xz.x, a);
-                        a = fmaf(w0[co * 4 + 3], xz.y, a);
-                        r[k] = prelu(a, lw.slope) + EMB[n * EMB_STRIDE + co];
-                    }
-                    *reinterpret_cast<float4*>(o + c4 * 4) = make_float4(r[0], r[1], r[2], r[3]);
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wef[(mt * 4 + ks) * 64 + lane], bk[ks], acc, 0, 0, 0);
+                const int o = mt * 16 + 4 * g;
+                if (j < NB && o < EMB_TOTAL) {
+                    const float4 be4 = load_global4(wb + tab_i(wb, TAB_BE) + o);
+                    *reinterpret_cast<float4*>(EMB + j * EMB_STRIDE + o) =
+                        make_float4(acc[0] + be4.x, acc[1] + be4.y, acc[2] + be4.z, acc[3] + be4.w);
                 }
             }
+            (void)beg;
         }
-        __syncthreads();
+        STAGE(1);
+        layer_std<0, T, NB>(wb, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof);   // sp1a (2 -> 16)
         STAGE(2);
         // ---- down path
         layer_std<1, T, NB>(wb, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof);  // sd1.0
@@ -704,8 +693,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             });
             __syncthreads();
             STAGE(10);
-            mix_stage<64, 10, T, NB, true>(Pb, 132, Pb + 64, 132, wb + lw.tq, wb + lw.am, wb + lw.bias, lw.slope,
-                                           EMB + emb_off(6), wave, lane);
+            gfloat* bias6 = as_global(wb + lw.bias);
+            const float slope6 = lw.slope;
+            mix_stage<64, 10, T, NB>(Pb, 132, wb + lw.tq, wb + lw.am, wave, lane,
+                                     [&](int n, int q, int w, int c) { return Pb[((n * T + q) * 10 + w) * 132 + 64 + c]; },
+                                     [&](int n, int q, int w, int c, float v) {
+                                         Pb[((n * T + q) * 10 + w) * 132 + 64 + c] =
+                                             prelu(v + bias6[c], slope6) + EMB[n * EMB_STRIDE + emb_off(6) + c];
+                                     });
             __syncthreads();
             STAGE(11);
         }
@@ -730,42 +725,39 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             layer_std<9, T, NB>(wb, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof);  // su3.0
             STAGE(16);
         }
-        // ---- su3.1 (32 -> 2) + U-Net residual (+X) + DDPM update
+        // ---- su3.1 (32 -> 2) W-first: P = [W_t; W_r] M32 (4 useful rows), then the 2-channel mix with the PReLU,
+        //      embedding, U-Net residual (+X) and the DDPM update fused into its store
         {
             constexpr int NT = PL::P17 / 16;
             const LayerW lw = layer_w(wb, 10);
-            float4 afr[4];
-            load_afrags<1, 4>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
-            mix_stage<32, 17, T, NB, false>(RG + PL::L10_in, 36, RG + PL::L10_z, 36, wb + lw.tq, wb + lw.am, nullptr, 0.f,
-                                            nullptr, wave, lane);
+            float* Pb = RG + PL::L10_p;
+            float4 afr[2];
+            load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+            gemm_tiles<1, NT, 2, 0, false>(afr, RG + PL::L10_in, 36, RG + PL::L10_in, 36, wave, lane,
+                                           [&](auto, int col, int c0, f32x4 acc) {
+                if (col < COLS17) *reinterpret_cast<float4*>(Pb + col * 20 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            });
             __syncthreads();
             const float ca = srow[0], cb = srow[1], csg = srow[2];
             gfloat* bias = as_global(wb + lw.bias);
             const float slope10 = lw.slope;
-            gemm_tiles<1, NT, 2, 2, false>(afr, RG + PL::L10_z, 36, RG + PL::L10_in, 36,
-                                           wave, lane, [&](auto, int col, int c0, f32x4 acc) {
-                if (col < COLS17 && c0 == 0) {
-                    const int n = col / TV17, t = (col / 17) % T, v = col % 17;
+            mix_stage<16, 17, T, NB>(Pb, 20, wb + lw.tq, wb + lw.am, wave, lane,
+                                     [](int, int, int, int) { return 0.f; },
+                                     [&](int n, int t, int v, int c, float val) {
+                if (c < C0) {
+                    const int col = (n * T + t) * 17 + v;
                     int chain = chain0 + n;
                     const bool valid = chain < P.n_chains;
                     if (!valid) chain = P.n_chains - 1;
-                    const int b = chain / P.S, s = chain % P.S;
-#pragma unroll
-                    for (int c = 0; c < C0; ++c) {
-                        const float x = XT[col * 4 + c];
-                        const float eps = prelu(acc[c] + bias[c], slope10) + EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
-                        if (P.mode == 1) {
-                            if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
-                        } else if (t >= tf) {
-                            float z = 0.f;
-                            if (sidx > 1) {
-                                const int e = (c * Tx + (t - tf)) * 17 + v;
-                                const int k = P.ns - sidx;
-                                if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
-                                else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
-                            }
-                            XT[col * 4 + c] = ca * (x - cb * eps) + csg * z;
-                        }
+                    const int b = chain / P.S;
+                    const float x = XT[col * 4 + c];
+                    const float eps = prelu(val + Pb[col * 20 + C0 + c] + bias[c], slope10) +
+                                      EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
+                    if (P.mode == 1) {
+                        if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
+                    } else if (t >= tf) {
+                        const float z = sidx > 1 ? ZN[col * C0 + c] : 0.f;
+                        XT[col * 4 + c] = ca * (x - cb * eps) + csg * z;
                     }
                 }
             });
@@ -1137,18 +1129,15 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
                                          "st_gcnnsd3.0", "st_gcnnsd3.1", "st_gcnnsu4.0", "st_gcnnsu4.1", "st_gcnnsu3.0",
                                          "st_gcnnsu3.1"};
     U.we = B.alloc((size_t)EMB_TOTAL * EDIM);
-    U.be = B.alloc(EMB_TOTAL);
+    U.be = B.alloc(EMB_TOTAL + 12);
     for (int l = 0; l < NLAYERS; ++l) {
         const LDesc D = layer_desc(l);
         const std::string p = std::string("model.") + names[l];
-        if (l == 0) {
-            if (!pack_mix(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
-        } else {
-            if (!pack_mix_mfma(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
-        }
+        if (!pack_mix_mfma(tm, p, T, D.V, B, U.L[l].tq, U.L[l].am)) return fail(MCD_EMISSING, tm.missing);
+        const int cin = l == 0 ? C0 : D.cin;   // real input channels (layer 0 is zero-padded to one 16-channel block)
         Folded ft, fr;
-        if (!fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", D.cout, D.cin, ft)) return fail(MCD_EMISSING, tm.missing);
-        if (D.res && !fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", D.cout, D.cin, fr)) return fail(MCD_EMISSING, tm.missing);
+        if (!fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", D.cout, cin, ft)) return fail(MCD_EMISSING, tm.missing);
+        if (D.res && !fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", D.cout, cin, fr)) return fail(MCD_EMISSING, tm.missing);
         const float* sl = tm.get(p + ".prelu.weight", 1);
         const float* we = tm.get(p + ".emb_layer.1.weight", (int64_t)D.cout * EDIM);
         const float* be = tm.get(p + ".emb_layer.1.bias", D.cout);
@@ -1159,26 +1148,18 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         const int mpad = ceil16(D.cout);
         U.L[l].bias = B.alloc(mpad);
         for (int o = 0; o < D.cout; ++o) B.buf[U.L[l].bias + o] = (float)(ft.b[o] + (D.res ? fr.b[o] : 0.0));
-        if (l == 0) {  // VALU layer: [16][4] = Wt(2), Wr(2)
-            U.L[l].wp = B.alloc(16 * 4);
-            for (int o = 0; o < 16; ++o) {
-                B.buf[U.L[l].wp + o * 4 + 0] = (float)ft.w[o * 2 + 0];
-                B.buf[U.L[l].wp + o * 4 + 1] = (float)ft.w[o * 2 + 1];
-                B.buf[U.L[l].wp + o * 4 + 2] = (float)fr.w[o * 2 + 0];
-                B.buf[U.L[l].wp + o * 4 + 3] = (float)fr.w[o * 2 + 1];
-            }
-            continue;
-        }
-        // MFMA fragment order.  Logical matrix Wcat[M][K]:
-        //   mix-first layers: M = cout, K = cin (W_t') + cin (W_r', when the layer has a residual conv)
-        //   layer 6 (W-first): M = 128 = [W_t' ; W_r'], K = cin
-        const bool wfirst = (l == 6);
-        const int M = wfirst ? 2 * D.cout : mpad;
-        const int Kc = wfirst ? D.cin : D.cin * (D.res ? 2 : 1);
+        // MFMA fragment order.  Logical matrix Wcat[M][K] (cinp = input channels padded to 16):
+        //   mix-first layers: M = cout, K = cinp (W_t') + cinp (W_r', when the layer has a residual conv)
+        //   W-first layers 6 and 10: M = [W_t' ; W_r'] stacked (layer 10: rows 0,1 / 2,3 of one 16-row tile), K = cinp
+        const bool wfirst = (l == 6 || l == 10);
+        const int cinp = D.cin;
+        const int M = l == 6 ? 2 * D.cout : mpad;
+        const int Kc = wfirst ? cinp : cinp * (D.res ? 2 : 1);
+        auto wt = [&](int r, int k) -> double { return (r < D.cout && k < cin) ? ft.w[(size_t)r * cin + k] : 0.0; };
+        auto wr = [&](int r, int k) -> double { return (r < D.cout && k < cin) ? fr.w[(size_t)r * cin + k] : 0.0; };
         auto wcat = [&](int r, int k) -> double {
-            if (wfirst) return r < D.cout ? ft.w[(size_t)r * D.cin + k] : fr.w[(size_t)(r - D.cout) * D.cin + k];
-            if (r >= D.cout) return 0.0;
-            return k < D.cin ? ft.w[(size_t)r * D.cin + k] : fr.w[(size_t)r * D.cin + (k - D.cin)];
+            if (wfirst) return r < D.cout ? wt(r, k) : (r < 2 * D.cout ? wr(r - D.cout, k) : 0.0);
+            return k < cinp ? wt(r, k) : wr(r, k - cinp);
         };
         const int MTn = M / 16, KQ = Kc / 16;
         U.L[l].wp = B.alloc((size_t)MTn * KQ * 64 * 4);
@@ -1188,6 +1169,13 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
                 const int k = kq * 16 + 8 * h + 2 * g + r;
                 B.buf[U.L[l].wp + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)wcat(row, k);
             }
+    }
+    // embedding Linear of all layers as MFMA A fragments: lane (i, g) of (mt, ks) = We_all[16mt + i][4ks + g]
+    const int EMT = (EMB_TOTAL + 15) / 16;
+    const int wef = B.alloc((size_t)EMT * 4 * 64);
+    for (int mt = 0; mt < EMT; ++mt) for (int ks = 0; ks < 4; ++ks) for (int lane = 0; lane < 64; ++lane) {
+        const int o = mt * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
+        B.buf[wef + (mt * 4 + ks) * 64 + lane] = o < EMB_TOTAL ? B.buf[U.we + (size_t)o * EDIM + k] : 0.f;
     }
     static const char* rs_names[4] = {"down1", "down2", "up3", "up2"};
     static const int rs_in[4] = {17, 12, 10, 12}, rs_out[4] = {12, 10, 12, 17};
@@ -1253,7 +1241,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             tab[l * F_STRIDE + F_TQT] = U.L[l].tqt; tab[l * F_STRIDE + F_AMT] = U.L[l].amt;
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
         }
-        tab[TAB_WE] = U.we; tab[TAB_BE] = U.be;
+        tab[TAB_WE] = U.we; tab[TAB_BE] = U.be; tab[TAB_WEF] = wef;
         for (int r = 0; r < 4; ++r) { tab[TAB_RSW + r] = U.rs_w[r]; tab[TAB_RSB + r] = U.rs_b[r]; }
     }
     HIP_TRY(hipSetDevice(device));
