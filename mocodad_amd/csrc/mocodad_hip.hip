@@ -79,7 +79,7 @@ __host__ __device__ constexpr int emb_off(int l) {
 // Offset table stored in the first TAB_FLOATS words of the packed weight buffer (offsets in floats from the
 // buffer start).  The kernel scalar-loads an entry right where it is used; keeping the table out of the
 // kernarg segment stops the compiler from hoisting ~100 pointers into SGPRs for the whole trajectory loop.
-constexpr int TAB_FLOATS = 128;
+constexpr int TAB_FLOATS = 256;   // [0,128): U-Net table, [128,256): fast condition-encoder table
 enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_TQT = 5, F_AMT = 6, F_STRIDE = 8 };
 //   tab[l*8 + F_TQ]    layer 0: Tq[q][v][t] (= gcn.T[v][t][q]);  layers 1..10: time-mix coefficients packed 16 per
 //                      VGPR for DPP row broadcast, TQD[q][r][64]: lane 16g+i = T[v=4s+g][t][q] with s*T+t = 16r+i
@@ -156,7 +156,9 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     }
     const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    // Box-Muller on the hardware transcendental units (v_log_f32, v_cos_f32, v_sqrt_f32): this is a noise source,
+    // ~1e-6 relative accuracy is irrelevant to its distribution
+    return __fsqrt_rn(-1.38629436111989f * __log2f(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
 __device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
@@ -443,33 +445,33 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
 }
 
 // one mix-first ST-GCN layer: LDS `in` -> `out`, with `z` as scratch; the three regions are disjoint.
-template <int L, int T, int NB>
-__device__ __forceinline__ void layer_std(const float* wb, const float* in, float* z, float* out, const float* emb,
-                                          int wave, int lane, Prof& prof) {
-    constexpr LDesc D = layer_desc(L);
-    constexpr int MT = ceil16(D.cout) / 16;
-    constexpr int COLS = NB * T * D.V;
+// generic mix-first ST-GCN layer (CIN -> COUT at V joints), used by the U-Net and by the condition encoder.
+// HASEMB = false: no embedding term (condition-encoder layers get t = None, components.py:56-63).
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB>
+__device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const float* in, float* z, float* out,
+                                              const float* embl, int wave, int lane, Prof& prof, int prof_id) {
+    constexpr int MT = ceil16(COUT) / 16;
+    constexpr int COLS = NB * T * V;
     constexpr int NT = ceil16(COLS) / 16;
-    constexpr int TV = T * D.V;
-    constexpr int CSI = cs_of(D.cin), CSO = cs_of(D.cout);
-    constexpr int KQ1 = D.cin / 16, KQ2 = D.res ? D.cin / 16 : 0;
-    const LayerW lw = layer_w(wb, L);
+    constexpr int TV = T * V;
+    constexpr int CSI = cs_of(CIN), CSO = cs_of(COUT);
+    constexpr int KQ1 = CIN / 16, KQ2 = RES ? CIN / 16 : 0;
     float4 afr[KQ1 + KQ2];
     load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
-    mix_stage<D.cin, D.V, T, NB>(in, CSI, wb + lw.tq, wb + lw.am, wave, lane,
-                                 [](int, int, int, int) { return 0.f; },
-                                 [&](int n, int q, int w, int c, float v) { z[((n * T + q) * D.V + w) * CSI + c] = v; });
+    mix_stage<CIN, V, T, NB>(in, CSI, wb + lw.tq, wb + lw.am, wave, lane,
+                             [](int, int, int, int) { return 0.f; },
+                             [&](int n, int q, int w, int c, float v) { z[((n * T + q) * V + w) * CSI + c] = v; });
     __syncthreads();
-    prof.mark(32 + 3 * L);
+    prof.mark(prof_id);
     const float* bias = wb + lw.bias;
     const float slope = lw.slope;
-    const float* embl = emb + emb_off(L);
-    gemm_tiles<MT, NT, KQ1, KQ2, !D.res>(
+    gemm_tiles<MT, NT, KQ1, KQ2, !RES>(
         afr, z, CSI, in, CSI, wave, lane,
         [&](auto, int col, int c0, f32x4 acc) {
-            if (col < COLS && c0 < D.cout) {
+            if (col < COLS && c0 < COUT) {
                 const float4 b = load_global4(bias + c0);
-                const float4 e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
+                float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (HASEMB) e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
                 float4 v;
                 v.x = prelu(acc[0] + b.x, slope) + e.x;
                 v.y = prelu(acc[1] + b.y, slope) + e.y;
@@ -479,7 +481,16 @@ __device__ __forceinline__ void layer_std(const float* wb, const float* in, floa
             }
         });
     __syncthreads();
-    prof.mark(33 + 3 * L);
+    prof.mark(prof_id + 1);
+}
+
+// U-Net layer L of the fixed channel plan
+template <int L, int T, int NB>
+__device__ __forceinline__ void layer_std(const float* wb, const float* in, float* z, float* out, const float* emb,
+                                          int wave, int lane, Prof& prof) {
+    constexpr LDesc D = layer_desc(L);
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB>(wb, layer_w(wb, L), in, z, out, emb + emb_off(L), wave, lane,
+                                                               prof, 32 + 3 * L);
 }
 
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
@@ -640,18 +651,26 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) bk[ks] = j < NB ? SE[j * EDIM + 4 * ks + g] : 0.f;
             constexpr int EMT = (EMB_TOTAL + 15) / 16;
-#pragma unroll 1
-            for (int mt = wave; mt < EMT; mt += NWAVES) {
+            constexpr int ER = (EMT + NWAVES - 1) / NWAVES;
+            float wf[ER][4];
+            float4 be4[ER];
+#pragma unroll
+            for (int i = 0; i < ER; ++i) {          // all fragment loads first: one L2 round trip for the whole stage
+                const int mt = wave + i * NWAVES < EMT ? wave + i * NWAVES : EMT - 1;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wf[i][ks] = wef[(mt * 4 + ks) * 64 + lane];
+                be4[i] = load_global4(wb + tab_i(wb, TAB_BE) + mt * 16 + 4 * g);
+            }
+#pragma unroll
+            for (int i = 0; i < ER; ++i) {
+                const int mt = wave + i * NWAVES;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wef[(mt * 4 + ks) * 64 + lane], bk[ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][ks], bk[ks], acc, 0, 0, 0);
                 const int o = mt * 16 + 4 * g;
-                if (j < NB && o < EMB_TOTAL) {
-                    const float4 be4 = load_global4(wb + tab_i(wb, TAB_BE) + o);
+                if (mt < EMT && j < NB && o < EMB_TOTAL)
                     *reinterpret_cast<float4*>(EMB + j * EMB_STRIDE + o) =
-                        make_float4(acc[0] + be4.x, acc[1] + be4.y, acc[2] + be4.z, acc[3] + be4.w);
-                }
+                        make_float4(acc[0] + be4[i].x, acc[1] + be4[i].y, acc[2] + be4[i].z, acc[3] + be4[i].w);
             }
             (void)beg;
         }
@@ -795,6 +814,71 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
         const int chain = chain0 + wave;
         if (lane == 0 && chain < P.n_chains) P.loss_out[chain] = sum / (float)per;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// condition encoder, fast path for the shipped architecture (channels [32,16,32] + h_dim 32, latent 16):
+// the same MFMA mix / GEMM stages as the U-Net, NB windows per 512-thread workgroup, followed by the
+// bottleneck Linear over the (c,t,v) flattening (stsae.py:73-89).  Reads the condition frames straight from the
+// window tensor (no gather pass).  Other channel lists use cond_encode_kernel below.
+// ------------------------------------------------------------------------------------------------
+constexpr int TABC = 128;                  // cond table: second 128 words of the weight buffer
+constexpr int TABC_LW = 40, TABC_LB = 41;  // bottleneck Linear weight [16][32*T*17] / bias
+struct FrameIdx { int idx[MCD_MAX_FRAMES]; };
+
+template <int T, int NB>
+__global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbuf, const float* __restrict__ data,
+                                                                const FrameIdx fi, int seg_len, float* __restrict__ emb_out,
+                                                                int B) {
+    constexpr int P17 = ceil16(NB * T * 17);
+    constexpr int s16 = P17 * 20, s32 = P17 * 36;
+    constexpr int TV = T * 17, COLS = NB * TV;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const X0 = smem;                   // [P17][20]  in of layers 0, 2 ; out of layer 1
+    float* const Z0 = smem + s16;             // [P17][20]
+    float* const Y0 = smem + 2 * s16;         // [P17][36]  out of layers 0, 2 ; in of layers 1, 3
+    float* const Z1 = smem + 2 * s16 + s32;   // [P17][36]
+    float* const H = smem;                    // [P17][36]  out of layer 3 (over X0/Z0: 36 <= 40)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * NB;
+    Prof prof;
+#ifdef MCD_PROFILE
+    prof.on = false; prof.p = nullptr; prof.tlast = 0;
+#endif
+    for (int u = tid; u < 2 * s16 + 2 * s32; u += NTHREADS) smem[u] = 0.f;
+    __syncthreads();
+    for (int u = tid; u < COLS * C0; u += NTHREADS) {
+        const int c = u % C0, col = u / C0;
+        const int n = col / TV, t = (col / 17) % T, v = col % 17;
+        const int b = b0 + n < B ? b0 + n : B - 1;
+        X0[col * 20 + c] = data[(((size_t)b * C0 + c) * seg_len + fi.idx[t]) * 17 + v];
+    }
+    __syncthreads();
+    const float* wb = wbuf;
+    auto lw = [&](int l) {
+        LayerW w;
+        w.tq = tab_i(wb, TABC + l * F_STRIDE + F_TQ); w.am = tab_i(wb, TABC + l * F_STRIDE + F_AM);
+        w.wp = tab_i(wb, TABC + l * F_STRIDE + F_WP); w.bias = tab_i(wb, TABC + l * F_STRIDE + F_BIAS);
+        w.tqt = 0; w.amt = 0; w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
+        return w;
+    };
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(0), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 2(16) -> 32
+    layer_generic<32, 16, 17, true, false, T, NB>(wb, lw(1), Y0, Z1, X0, nullptr, wave, lane, prof, 0);   // 32 -> 16
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(2), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 16 -> 32
+    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(3), Y0, Z1, H, nullptr, wave, lane, prof, 0);   // 32 -> 32
+    // bottleneck Linear: emb[n][j] = b[j] + sum_k W[j][k] H[n][k], k = c*TV + tv.  thread = (n, j, part of 16)
+    constexpr int F = 32 * TV;
+    gfloat* W = as_global(wb + tab_i(wb, TABC + TABC_LW));
+    gfloat* bb = as_global(wb + tab_i(wb, TABC + TABC_LB));
+    for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
+        const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
+        float a = 0.f;
+        for (int k = part; k < F; k += 16) a = fmaf(W[jo * F + k], H[(n * TV + k % TV) * 36 + k / TV], a);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+        if (part == 0 && b0 + n < B) emb_out[(size_t)(b0 + n) * EDIM + jo] = a + bb[jo];
     }
 }
 
@@ -1055,6 +1139,21 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
     return true;
 }
 
+// MFMA A-operand fragment order of a logical [M][K] matrix (M, K multiples of 16) with the K permutation that lets
+// one ds_read_b64 of the B operand feed two k-steps (see gemm_tiles): element e of lane (i, g) in group kq is
+// W[16 mt + i][16 kq + 8 (e >> 1) + 2 g + (e & 1)].
+template <class F>
+int pack_gemm_frags(Builder& B, int M, int K, F&& w) {
+    const int MTn = M / 16, KQ = K / 16;
+    const int off = B.alloc((size_t)MTn * KQ * 64 * 4);
+    for (int mt = 0; mt < MTn; ++mt) for (int kq = 0; kq < KQ; ++kq) for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 4; ++e) {
+            const int row = mt * 16 + (lane & 15), g = lane >> 4, h = e >> 1, r = e & 1;
+            B.buf[off + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)w(row, kq * 16 + 8 * h + 2 * g + r);
+        }
+    return off;
+}
+
 }  // namespace
 
 struct mcd_weights {
@@ -1064,6 +1163,7 @@ struct mcd_weights {
     size_t n_floats;
     CondW cond;
     bool has_cond;
+    bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
 };
 
 namespace {
@@ -1100,6 +1200,33 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+template <int T, int NB>
+int launch_cond_fast_t(const mcd_weights* w, const float* data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+    constexpr int P17 = ceil16(NB * T * 17);
+    constexpr size_t bytes = (size_t)P17 * (2 * 20 + 2 * 36) * 4;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_fast_kernel<T, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((cond_fast_kernel<T, NB>), dim3((B + NB - 1) / NB), dim3(NTHREADS), bytes, st, w->dbuf, data, fi, seg_len, emb, B);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+int launch_cond_fast(const mcd_weights* w, const float* data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+    switch (w->cond.Tc) {
+        case 3: return launch_cond_fast_t<3, 4>(w, data, fi, seg_len, emb, B, st);
+        case 6: return launch_cond_fast_t<6, 2>(w, data, fi, seg_len, emb, B, st);
+        case 12: return launch_cond_fast_t<12, 1>(w, data, fi, seg_len, emb, B, st);
+        default: return fail(MCD_EUNSUPPORTED, "cond_fast: frame count not instantiated");
+    }
+}
+}  // namespace
+
 static unsigned long long* g_prof = nullptr;  // MCD_PROFILE builds: device buffer of 32 accumulators
 
 extern "C" {
@@ -1129,7 +1256,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
                                          "st_gcnnsd3.0", "st_gcnnsd3.1", "st_gcnnsu4.0", "st_gcnnsu4.1", "st_gcnnsu3.0",
                                          "st_gcnnsu3.1"};
     U.we = B.alloc((size_t)EMB_TOTAL * EDIM);
-    U.be = B.alloc(EMB_TOTAL + 12);
+    U.be = B.alloc(EMB_TOTAL + 28);
     for (int l = 0; l < NLAYERS; ++l) {
         const LDesc D = layer_desc(l);
         const std::string p = std::string("model.") + names[l];
@@ -1161,14 +1288,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             if (wfirst) return r < D.cout ? wt(r, k) : (r < 2 * D.cout ? wr(r - D.cout, k) : 0.0);
             return k < cinp ? wt(r, k) : wr(r, k - cinp);
         };
-        const int MTn = M / 16, KQ = Kc / 16;
-        U.L[l].wp = B.alloc((size_t)MTn * KQ * 64 * 4);
-        for (int mt = 0; mt < MTn; ++mt) for (int kq = 0; kq < KQ; ++kq) for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 4; ++e) {
-                const int row = mt * 16 + (lane & 15), g = lane >> 4, h = e >> 1, r = e & 1;
-                const int k = kq * 16 + 8 * h + 2 * g + r;
-                B.buf[U.L[l].wp + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)wcat(row, k);
-            }
+        U.L[l].wp = pack_gemm_frags(B, M, Kc, wcat);
     }
     // embedding Linear of all layers as MFMA A fragments: lane (i, g) of (mt, ks) = We_all[16mt + i][4ks + g]
     const int EMT = (EMB_TOTAL + 15) / 16;
@@ -1197,6 +1317,8 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     // condition encoder
     CondW Cw;
     memset(&Cw, 0, sizeof(Cw));
+    bool cond_fast = false;
+    int ctab[4][F_STRIDE] = {{0}};
     const bool has_cond = cfg->strategy == MCD_STRATEGY_INJECT;
     if (has_cond) {
         if (cfg->cond_layers < 1 || cfg->cond_layers > MCD_MAX_COND_LAYERS) return fail(MCD_EINVAL, "bad cond_layers");
@@ -1230,6 +1352,33 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         if (!lw || !lb) return fail(MCD_EMISSING, tm.missing);
         Cw.lw = B.alloc(F * EDIM); memcpy(&B.buf[Cw.lw], lw, sizeof(float) * F * EDIM);
         Cw.lb = B.alloc(EDIM); memcpy(&B.buf[Cw.lb], lb, sizeof(float) * EDIM);
+        // fast path (cond_fast_kernel): the shipped architecture at a frame count the MFMA stages are instantiated for
+        cond_fast = Cw.n_layers == 4 && Cw.cout[0] == 32 && Cw.cout[1] == 16 && Cw.cout[2] == 32 && Cw.cout[3] == 32 &&
+                    (Cw.Tc == 3 || Cw.Tc == 6 || Cw.Tc == 12);
+        if (cond_fast) {
+            int cinr = C0;
+            for (int l = 0; l < 4; ++l) {
+                const int cout = Cw.cout[l], cinp = l == 0 ? 16 : cinr;
+                const std::string p = "condition_encoder.encoder.model_layers." + std::to_string(l);
+                Folded ft, fr;
+                const bool res = cinr != cout;
+                fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", cout, cinr, ft);
+                if (res) fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", cout, cinr, fr);
+                int tq = 0, am = 0;
+                pack_mix_mfma(tm, p, Cw.Tc, 17, B, tq, am);
+                const int wp = pack_gemm_frags(B, ceil16(cout), cinp * (res ? 2 : 1), [&](int r, int k) -> double {
+                    const bool second = k >= cinp;
+                    const int kk = second ? k - cinp : k;
+                    if (r >= cout || kk >= cinr) return 0.0;
+                    return second ? fr.w[(size_t)r * cinr + kk] : ft.w[(size_t)r * cinr + kk];
+                });
+                const int bias = B.alloc(ceil16(cout));
+                for (int o = 0; o < cout; ++o) B.buf[bias + o] = (float)(ft.b[o] + (res ? fr.b[o] : 0.0));
+                ctab[l][F_TQ] = tq; ctab[l][F_AM] = am; ctab[l][F_WP] = wp; ctab[l][F_BIAS] = bias;
+                memcpy(&ctab[l][F_SLOPE], &Cw.slope[l], sizeof(float));
+                cinr = cout;
+            }
+        }
         const size_t lds = ((size_t)3 * Cw.cmax * Cw.Tc * 17 + 256) * 4;
         if (lds > 160 * 1024) return fail(MCD_EUNSUPPORTED, "condition encoder activations exceed LDS");
     }
@@ -1242,11 +1391,15 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
         }
         tab[TAB_WE] = U.we; tab[TAB_BE] = U.be; tab[TAB_WEF] = wef;
+        if (cond_fast) {
+            for (int l = 0; l < 4; ++l) for (int f = 0; f < F_STRIDE; ++f) tab[TABC + l * F_STRIDE + f] = ctab[l][f];
+            tab[TABC + TABC_LW] = Cw.lw; tab[TABC + TABC_LB] = Cw.lb;
+        }
         for (int r = 0; r < 4; ++r) { tab[TAB_RSW + r] = U.rs_w[r]; tab[TAB_RSB + r] = U.rs_b[r]; }
     }
     HIP_TRY(hipSetDevice(device));
     mcd_weights* w = new mcd_weights();
-    w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond;
+    w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(w->dbuf, B.buf.data(), B.buf.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1268,6 +1421,11 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
     if (!w->has_cond) return fail(MCD_EINVAL, "model has no condition encoder");
     if (n_windows <= 0) return MCD_OK;
     if (!cond_data || !emb_out) return fail(MCD_EINVAL, "null argument");
+    if (w->cond_fast && !getenv("MCD_COND_GENERIC")) {
+        FrameIdx fi;
+        for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = k;
+        return launch_cond_fast(w, cond_data, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
+    }
     const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
     static bool attr_set[16] = {false};
     int dev = 0;
@@ -1300,7 +1458,6 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
     return (int64_t)cfg->n_windows * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
 }
 
-struct FrameIdx { int idx[MCD_MAX_FRAMES]; };
 __global__ void gather_frames_kernel(const float* __restrict__ data, float* __restrict__ out, int B, int C, int T, int V,
                                      int n, const FrameIdx fi) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1338,6 +1495,14 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
         float* emb = reinterpret_cast<float*>(workspace);
         float* cbuf = emb + (size_t)B * EDIM + 16;
         const int Tc = cfg->n_cond;
+        if (w->cond_fast && !getenv("MCD_COND_GENERIC")) {
+            FrameIdx fi;
+            for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
+            int rc = launch_cond_fast(w, data, fi, cfg->seg_len, emb, B, st);
+            if (rc != MCD_OK) return rc;
+            P.cond_emb = emb;
+            return launch_score(Tu, P, st);
+        }
         const int total = B * C0 * Tc * 17;
         FrameIdx fi;
         for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
