@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmocodad_hip.so")
+LIB_PATH = os.environ.get("MCD_LIB", os.path.join(_HERE, "libmocodad_hip.so"))   # MCD_LIB: tuning builds only
 
 MCD_MAX_FRAMES = 32
 MCD_MAX_COND_LAYERS = 8

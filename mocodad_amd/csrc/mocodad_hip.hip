@@ -52,8 +52,11 @@ __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byt
 }
 __device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)p; }
 
-constexpr int NTHREADS = 512;
-constexpr int NWAVES = 8;
+#ifndef MCD_NWAVES
+#define MCD_NWAVES 8
+#endif
+constexpr int NWAVES = MCD_NWAVES;          // waves per workgroup (8; 16 is a tuning experiment)
+constexpr int NTHREADS = NWAVES * 64;
 constexpr int C0 = 2;        // num_coords
 constexpr int EDIM = 16;     // embedding_dim
 constexpr int NLAYERS = 11;  // ST-GCN layers of the U-Net
@@ -220,7 +223,7 @@ __host__ __device__ constexpr int mix_vmap(int V, int ks, int g) {
 // result (plain Z store, in-place PReLU epilogue of layer 6, or the fused DDPM update of layer 10).
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int V, int T, int NB, class Init, class Store>
-__device__ __forceinline__ void mix_stage(const float* in, int cs_in, const float* __restrict__ tqd,
+__device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const float* __restrict__ tqd,
                                           const float* __restrict__ af, int wave, int lane, Init&& init, Store&& store) {
     constexpr int KS = (V + 3) / 4;
     constexpr int KP = 2 * (KS / 2);                     // paired k-steps (see mix_vmap)
@@ -317,7 +320,7 @@ __host__ __device__ constexpr int rs_vmap(bool capture, int vin, int ks, int g) 
 }
 
 template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, int NSK>
-__device__ __forceinline__ void resample_stage(const float* in, int cs_in, float* out, int cs_out,
+__device__ __forceinline__ void resample_stage(const float* __restrict__ in, int cs_in, float* __restrict__ out, int cs_out,
                                                const float* __restrict__ wf, const float* __restrict__ bdp,
                                                float (&skip)[NSK], int wave, int lane) {
     using RC = RsCfg<C, VIN, VOUT, T, NB, CAPTURE>;
@@ -400,8 +403,8 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
 }
 
 template <int MT, int NT, int KQ1, int KQ2, bool IDRES, class Epi>
-__device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* b1, int cs1, const float* b2,
-                                           int cs2, int wave, int lane, Epi&& epi) {
+__device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
+                                           const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi) {
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
     const int mt = wave % MT, ng = wave / MT;
@@ -448,8 +451,9 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
 // generic mix-first ST-GCN layer (CIN -> COUT at V joints), used by the U-Net and by the condition encoder.
 // HASEMB = false: no embedding term (condition-encoder layers get t = None, components.py:56-63).
 template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB>
-__device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const float* in, float* z, float* out,
-                                              const float* embl, int wave, int lane, Prof& prof, int prof_id) {
+__device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const float* __restrict__ in,
+                                              float* __restrict__ z, float* __restrict__ out,
+                                              const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id) {
     constexpr int MT = ceil16(COUT) / 16;
     constexpr int COLS = NB * T * V;
     constexpr int NT = ceil16(COLS) / 16;
@@ -1189,10 +1193,12 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
     static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
     switch (T) {
         case 3:
-            if (variant == 1) return launch_score_t<3, 4, 2>(P, st);   // 4 chains / WG, 1 WG per CU
+            if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st);   // 4 chains / WG, 1 WG per CU
             if (variant == 2) return launch_score_t<3, 2, 2>(P, st);
             return launch_score_t<3, 2, 4>(P, st);                     // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
-        case 6: return launch_score_t<6, 2, 2>(P, st);
+        case 6:
+            if (variant == 1) return launch_score_t<6, 2, 2>(P, st);
+            return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
         case 12: return launch_score_t<12, 1, 2>(P, st);
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
     }
