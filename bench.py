@@ -172,7 +172,7 @@ def main():
                                    f"noise_steps={ns}, {S} generated samples, inject conditioning, 'best' aggregation",
                        "windows_per_step_per_gpu": B, "denoiser_passes_per_window": P, "weights": "seeded random init (tests/golden/weights_inject.npz)",
                        "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), all-gather of scores"},
-            "roofline": {"bound": "mfma", "kernel": "score_kernel<3,2,4> (+cond_encode_kernel)", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": "score_kernel<3,2,4> (+cond_fast_kernel<3,4>)", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
                          "hbm_algorithmic_bytes_per_window": 820, "traffic": None},

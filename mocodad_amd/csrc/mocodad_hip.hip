@@ -362,7 +362,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             if (ADD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
-                if (SK == 5) acc[MT - 1][0] += skip[i * SK + 4];     // joint 16 lives in lane group g = 0, row 0 of m-tile 1
+                if constexpr (SK == 5) acc[MT - 1][0] += skip[i * SK + 4];     // joint 16 lives in lane group g = 0, row 0 of m-tile 1
             }
             float* zo = out + (nt * VOUT + 4 * g) * cs_out + cb * 16 + j;
 #pragma unroll
