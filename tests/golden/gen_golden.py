@@ -140,6 +140,49 @@ def state_to_np(model):
     return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
 
 
+def extra(MoCoDAD):
+    """Second batch of vectors (added later; `python tests/golden/gen_golden.py --extra` regenerates only these):
+    no_condition strategy, 'E' condition encoder with a non-default channel list, l1 / mse losses."""
+    cases = {
+        # name: (overrides, ns, S, B)
+        "nocond": (dict(conditioning_strategy="no_condition"), 4, 2, 4),
+        "encE": (dict(conditioning_architecture="E", channels=[24, 40], h_dim=8), 4, 2, 4),
+        "l1": (dict(loss_fn="l1"), 4, 2, 4),
+        "mse": (dict(loss_fn="mse"), 4, 2, 4),
+    }
+    for name, (over, ns, S, B) in cases.items():
+        gen = torch.Generator().manual_seed(4321 + len(name))
+        args, cfg = make_args(noise_steps=ns, n_gen=S, aggr="all", ret="all")
+        for k, v in over.items():
+            setattr(args, k, v)
+            cfg[k] = v
+        cfg.update(noise_steps=ns, n_generated_samples=S)
+        torch.manual_seed(7 + len(name))
+        m = MoCoDAD(args).eval()
+        perturb_(m, gen)
+        tame_(m, 0.25)
+        save(f"weights_{name}.npz", __cfg__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **state_to_np(m))
+        data = synth_windows(B, 6, gen)
+        Tx = m.n_frames_corrupt
+        noise = fp16_round(torch.randn(S, ns - 1, B, 2, Tx, 17, generator=gen))
+        batch = [data, torch.zeros(B, dtype=torch.long), torch.zeros(B, 4, dtype=torch.long), torch.zeros(B, 6, dtype=torch.int32)]
+        out = {}
+        orig = torch.randn_like
+        for aggr in ("all", "best", "mean"):
+            torch.randn_like = NoiseFeeder(noise)
+            try:
+                o = m.forward(batch, aggr_strategy=aggr, return_="all")
+            finally:
+                torch.randn_like = orig
+            out[f"loss_{aggr}"] = o[0]
+            if o[1] is not None:
+                out[f"pose_{aggr}"] = o[1]
+        if m.condition_encoder is not None:
+            cd, _, _ = m._select_frames(data)
+            out["cond_emb"] = m.condition_encoder(cd, t=None)[0]
+        save(f"traj_{name}_ns{ns}_S{S}.npz", data=data, noise=noise.half(), **out)
+
+
 def main():
     _install_lightning_stub()
     sys.path.insert(0, REF)
@@ -148,6 +191,9 @@ def main():
     from models.mocodad import MoCoDAD  # noqa: E402
     from utils.diffusion_utils import Diffusion  # noqa: E402
     from utils.model_utils import processing_data  # noqa: E402
+    if "--extra" in sys.argv:
+        extra(MoCoDAD)
+        return
 
     # ---------------------------------------------------------------- 5. schedules
     sched = {}

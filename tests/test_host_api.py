@@ -17,7 +17,7 @@ from mocodad_amd.utils.model_utils import processing_data
 from oracle import mocodad_oracle as O
 
 
-@pytest.mark.parametrize("variant", ["inject", "concat", "T12", "injtail"])
+@pytest.mark.parametrize("variant", ["inject", "concat", "T12", "injtail", "nocond", "encE"])
 def test_state_dict_layout_matches_reference_checkpoint(variant):
     sd, cfg = golden_weights(variant)
     m = MoCoDAD(make_args(cfg))

@@ -120,3 +120,21 @@ def test_full_size_properties():
     worst = sc.aggregate(data, loss, None, "worst", noise_steps=10)[1]
     assert torch.equal(best, loss.min(1)[0]) and torch.equal(worst, loss.max(1)[0])
     assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
+
+
+@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse"])
+def test_extra_variants_vs_reference(name):
+    """no_condition strategy (U-Net on all 6 frames), 'E' encoder with channels [24,40]+8 (generic condition-encoder
+    kernel), l1 / mse losses — against vectors generated by the reference."""
+    g = load_golden(f"traj_{name}_ns4_S2.npz")
+    m, _, cfg = _model(name)
+    batch = [torch.from_numpy(g["data"]), torch.zeros(4), torch.zeros(4, 4), torch.zeros(4, 6)]
+    noise = torch.from_numpy(g["noise"].astype(np.float32))
+    for aggr in ("all", "best", "mean"):
+        out = m.forward(batch, aggr_strategy=aggr, return_="all", noise=noise)
+        np.testing.assert_allclose(out[0].cpu().numpy(), g[f"loss_{aggr}"], atol=ATOL, rtol=0, err_msg=aggr)
+        if f"pose_{aggr}" in g:
+            np.testing.assert_allclose(out[1].cpu().numpy(), g[f"pose_{aggr}"], atol=ATOL, rtol=1e-5, err_msg=aggr)
+    if "cond_emb" in g:
+        emb = m.scorer().cond_encode(batch[0][:, :, m._frame_split()[0], :]).cpu().numpy()
+        np.testing.assert_allclose(emb, g["cond_emb"], atol=2e-5, rtol=1e-5)
