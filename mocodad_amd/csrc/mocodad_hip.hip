@@ -377,15 +377,17 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
 // ------------------------------------------------------------------------------------------------
 // channel GEMM on v_mfma_f32_16x16x4_f32.  D[c', col] = sum_k Wp[c', k] * B[k, col]
 //   A operand (weights): lane l holds W[m0 + (l&15)][k], pre-packed as float4 per 16-channel group
-//   B operand (activations in LDS [col][ch]): lane (j = l&15, g = l>>4) reads channels 16kq+8h+2g+{0,1}
-//   of column n0+j with one ds_read_b64 -> two k-steps.  The packer applies the same K permutation.
+//   B operand (activations in LDS [col][ch]): lane (j = l&15, g = l>>4) reads channels 16kq+4g+{0..3}
+//   of column n0+j with one ds_read_b128 -> four k-steps (a merged ds_read2_b64 of two 8-byte pieces is 2-4x
+//   slower: 8 LDS cycles and 2-way conflicted at these strides).  The packer applies the same K permutation.
 // Wave w owns m-tile w % MT and n-tiles (w / MT) + i * (8 / MT).
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <int MT, int NT>
 struct Tiling {
-    static constexpr int NG = NWAVES / MT;
+    static constexpr int MW = MT > NWAVES ? MT / NWAVES : 1;      // m-tiles per wave (sequential)
+    static constexpr int NG = MT > NWAVES ? 1 : NWAVES / MT;      // waves sharing one m-tile
     static constexpr int MAXN = (NT + NG - 1) / NG;
 };
 
@@ -396,18 +398,18 @@ struct Tiling {
 // weight fragments of this wave's m-tile: issued early (before the barrier that precedes the GEMM) so that their L2
 // latency overlaps the mix stage
 template <int MT, int KQ>
-__device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int wave, int lane, float4 (&a)[KQ]) {
-    const float* wpl = reinterpret_cast<const float*>(wp + ((wave % MT) * KQ) * 64 + lane);
+__device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int wave, int lane, float4 (&a)[KQ], int mi = 0) {
+    const float* wpl = reinterpret_cast<const float*>(wp + (((wave + mi * NWAVES) % MT) * KQ) * 64 + lane);
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) a[kq] = load_global4(wpl + kq * 256);
 }
 
 template <int MT, int NT, int KQ1, int KQ2, bool IDRES, class Epi>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
-                                           const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi) {
+                                           const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0) {
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
-    const int mt = wave % MT, ng = wave / MT;
+    const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
     const int j = lane & 15, g = lane >> 4;
     const int c0 = mt * 16 + 4 * g;
     static_for<MAXN>([&](auto ii) {
@@ -420,26 +422,24 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
                 const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + c0);
                 c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
             }
-            const float* p1 = b1 + col * cs1 + 2 * g;
+            const float* p1 = b1 + col * cs1 + 4 * g;
 #pragma unroll
             for (int kq = 0; kq < KQ1; ++kq) {
-                const float2 u = *reinterpret_cast<const float2*>(p1 + kq * 16);
-                const float2 w = *reinterpret_cast<const float2*>(p1 + kq * 16 + 8);
+                const float4 u = *reinterpret_cast<const float4*>(p1 + kq * 16);   // one ds_read_b128 = 4 k-steps
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, w.x, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, w.y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u.z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u.w, c, 0, 0, 0);
             }
             if (KQ2 > 0) {
-                const float* p2 = b2 + col * cs2 + 2 * g;
+                const float* p2 = b2 + col * cs2 + 4 * g;
 #pragma unroll
                 for (int kq = 0; kq < KQ2; ++kq) {
-                    const float2 u = *reinterpret_cast<const float2*>(p2 + kq * 16);
-                    const float2 w = *reinterpret_cast<const float2*>(p2 + kq * 16 + 8);
+                    const float4 u = *reinterpret_cast<const float4*>(p2 + kq * 16);
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].x, u.x, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].y, u.y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].z, w.x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].w, w.y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].z, u.z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].w, u.w, c, 0, 0, 0);
                 }
             }
             epi(ii, col, c0, c);
@@ -469,21 +469,25 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     prof.mark(prof_id);
     const float* bias = wb + lw.bias;
     const float slope = lw.slope;
-    gemm_tiles<MT, NT, KQ1, KQ2, !RES>(
-        afr, z, CSI, in, CSI, wave, lane,
-        [&](auto, int col, int c0, f32x4 acc) {
-            if (col < COLS && c0 < COUT) {
-                const float4 b = load_global4(bias + c0);
-                float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (HASEMB) e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
-                float4 v;
-                v.x = prelu(acc[0] + b.x, slope) + e.x;
-                v.y = prelu(acc[1] + b.y, slope) + e.y;
-                v.z = prelu(acc[2] + b.z, slope) + e.z;
-                v.w = prelu(acc[3] + b.w, slope) + e.w;
-                *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
-            }
-        });
+    auto epi = [&](auto, int col, int c0, f32x4 acc) {
+        if (col < COLS && c0 < COUT) {
+            const float4 b = load_global4(bias + c0);
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HASEMB) e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
+            float4 v;
+            v.x = prelu(acc[0] + b.x, slope) + e.x;
+            v.y = prelu(acc[1] + b.y, slope) + e.y;
+            v.z = prelu(acc[2] + b.z, slope) + e.z;
+            v.w = prelu(acc[3] + b.w, slope) + e.w;
+            *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
+        }
+    };
+    gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi);
+#pragma unroll
+    for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
+        load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
+        gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi, mi);
+    }
     __syncthreads();
     prof.mark(prof_id + 1);
 }
@@ -709,11 +713,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const LayerW lw = layer_w(wb, 6);
             float* Pb = RG + PL::L6_p;
             float4 afr[8];
-            load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
-            gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132,
-                                           wave, lane, [&](auto, int col, int c0, f32x4 acc) {
+            auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            });
+            };
+#pragma unroll
+            for (int mi = 0; mi < Tiling<8, NT>::MW; ++mi) {
+                load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
+                gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+            }
             __syncthreads();
             STAGE(10);
             gfloat* bias6 = as_global(wb + lw.bias);
@@ -1144,16 +1151,16 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
 }
 
 // MFMA A-operand fragment order of a logical [M][K] matrix (M, K multiples of 16) with the K permutation that lets
-// one ds_read_b64 of the B operand feed two k-steps (see gemm_tiles): element e of lane (i, g) in group kq is
-// W[16 mt + i][16 kq + 8 (e >> 1) + 2 g + (e & 1)].
+// one ds_read_b128 of the B operand feed four k-steps (see gemm_tiles): element e of lane (i, g) in group kq is
+// W[16 mt + i][16 kq + 4 g + e]  (k-step e of the group covers channels {16 kq + 4 g + e : g = 0..3}).
 template <class F>
 int pack_gemm_frags(Builder& B, int M, int K, F&& w) {
     const int MTn = M / 16, KQ = K / 16;
     const int off = B.alloc((size_t)MTn * KQ * 64 * 4);
     for (int mt = 0; mt < MTn; ++mt) for (int kq = 0; kq < KQ; ++kq) for (int lane = 0; lane < 64; ++lane)
         for (int e = 0; e < 4; ++e) {
-            const int row = mt * 16 + (lane & 15), g = lane >> 4, h = e >> 1, r = e & 1;
-            B.buf[off + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)w(row, kq * 16 + 8 * h + 2 * g + r);
+            const int row = mt * 16 + (lane & 15), g = lane >> 4;
+            B.buf[off + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)w(row, kq * 16 + 4 * g + e);
         }
     return off;
 }
@@ -1195,6 +1202,7 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
         case 3:
             if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st);   // 4 chains / WG, 1 WG per CU
             if (variant == 2) return launch_score_t<3, 2, 2>(P, st);
+            if (variant == 3) return launch_score_t<3, 1, 4>(P, st);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
             return launch_score_t<3, 2, 4>(P, st);                     // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
         case 6:
             if (variant == 1) return launch_score_t<6, 2, 2>(P, st);
