@@ -5,20 +5,23 @@
 //   STSAE_Unet.forward                  models/stsae/stsae_unet.py:406-438   launch for all S*(ns-1) passes)
 //   ST_GCNN_layer / ConvTemporalGraphical / CNN_layer  models/gcae/stsgcn.py:94-199
 //   DDPM ancestral update + SmoothL1    models/mocodad.py:172-178,484
-//   STSE.encode (condition encoder)     models/stsae/stsae.py:59-92    -> cond_encode_kernel
+//   STSE.encode (condition encoder)     models/stsae/stsae.py:59-92    -> cond_fast_kernel / cond_encode_kernel
 //   _aggregation_strategy               models/mocodad.py:454-520      -> aggregate_kernel
 //
 // Design: one 512-thread workgroup owns NB reverse-diffusion chains (a chain = one
 // (window, sample) pair) for their whole trajectory.  Activations live in LDS as [column][channel]
-// (column = (chain, frame, joint), channel fastest, row stride = C+4 floats = 4*odd so that the b64
-// MFMA-operand reads and the b128 epilogue stores are bank-conflict free).  Per ST-GCN layer:
-//   mix     VALU: lane = (chain, channel), the learned time-mix T[v,t,q] and joint-mix A[q,v,w]
-//           coefficients are wave-uniform (scalar loads), data is lane-private
-//   GEMM    the 1x1 channel convolutions (tcn + residual, BatchNorm folded) as one K-concatenated
-//           [W_t | W_r] x [Z ; X] product on v_mfma_f32_16x16x4_f32 (exact fp32), weights pre-packed in
-//           fragment order and streamed from L2 straight into registers
-//   epilog  +bias, (+identity residual), PReLU, + SiLU-Linear embedding, b128 store back to LDS
-// U-Net skip tensors d1/d2 stay in the accumulator registers of the waves that produced them.
+// (column = (chain, frame, joint), channel fastest, row stride = C+4 floats = 4*odd: conflict-free
+// MFMA-operand reads and b128 epilogue stores).  Every dense contraction runs on v_mfma_f32_16x16x4_f32
+// (exact fp32 = fmaf chain), with weights pre-packed in fragment order and streamed from L2 into registers:
+//   mix       joint mix A_q^T x Y_q per (chain, 16-channel block); Y_q (the time mix) is built in registers with
+//             DPP-broadcast coefficients as the B operand
+//   GEMM      the 1x1 channel convolutions (tcn + residual, BatchNorm folded) as one K-concatenated
+//             [W_t | W_r] x [Z ; X] product; the epilogue (+bias, PReLU, +SiLU-Linear embedding, b128 store)
+//             runs right behind each 16x16 tile
+//   resample  joint down/up-sampling per (frame, 16-channel block); the down-samplers' B operands double as the
+//             register-resident U-Net skip tensors d1/d2 that the up-samplers add back
+//   W-first   layers 6 and 10: GEMM first, then the mix on the (fewer) output channels with the layer epilogue
+//             (layer 10: + U-Net residual + DDPM update) in the mix's store functor
 // Everything is fp32 (the reverse chain amplifies error by up to 1e3).
 
 #include <hip/hip_runtime.h>
@@ -50,7 +53,6 @@ __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byt
     const f32x4 v = *(gf32x4*)p;
     return make_float4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)p; }
 
 #ifndef MCD_NWAVES
 #define MCD_NWAVES 8
@@ -83,12 +85,11 @@ __host__ __device__ constexpr int emb_off(int l) {
 // buffer start).  The kernel scalar-loads an entry right where it is used; keeping the table out of the
 // kernarg segment stops the compiler from hoisting ~100 pointers into SGPRs for the whole trajectory loop.
 constexpr int TAB_FLOATS = 256;   // [0,128): U-Net table, [128,256): fast condition-encoder table
-enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_TQT = 5, F_AMT = 6, F_STRIDE = 8 };
-//   tab[l*8 + F_TQ]    layer 0: Tq[q][v][t] (= gcn.T[v][t][q]);  layers 1..10: time-mix coefficients packed 16 per
-//                      VGPR for DPP row broadcast, TQD[q][r][64]: lane 16g+i = T[v=4s+g][t][q] with s*T+t = 16r+i
-//   tab[l*8 + F_AM]    layer 0: A[q][v][w];  layers 1..10: MFMA A-operand fragments of A_q^T,
-//                      AF[q][mt][s][64]: lane (i=j, g) = A[q][v=4s+g][w=16mt+j]  (0 outside V x V)
-//   tab[l*8 + F_WP]    MFMA-packed [W_t' | W_r'] (layer 0: plain [16][4] = Wt(2) Wr(2))
+enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_STRIDE = 8 };
+//   tab[l*8 + F_TQ]    time-mix coefficients packed 16 per VGPR for DPP row broadcast, TQD[q][r][64]:
+//                      lane 16g+i = gcn.T[v = mix_vmap(s,g)][t][q] with s*T+t = 16r+i
+//   tab[l*8 + F_AM]    MFMA A-operand fragments of A_q^T, AF[q][mt][s][64]: lane (i, g) = gcn.A[q][v=mix_vmap(s,g)][w=16mt+i]
+//   tab[l*8 + F_WP]    MFMA-packed [W_t' | W_r'] (layers 6, 10: [W_t' ; W_r'] stacked, W-first)
 //   tab[l*8 + F_BIAS]  folded bias, padded to 16
 //   tab[l*8 + F_SLOPE] PReLU slope (float bits)
 constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
@@ -98,12 +99,11 @@ constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: MFMA A frag
 typedef const int __attribute__((address_space(4))) cint;
 __device__ __forceinline__ int tab_i(const float* base, int idx) { return ((cint*)base)[idx]; }
 __device__ __forceinline__ float tab_f(const float* base, int idx) { return ((cfloat*)base)[idx]; }
-struct LayerW { int tq, am, wp, bias, tqt, amt; float slope; };
+struct LayerW { int tq, am, wp, bias; float slope; };
 __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
     LayerW w;
     w.tq = tab_i(base, l * F_STRIDE + F_TQ); w.am = tab_i(base, l * F_STRIDE + F_AM);
     w.wp = tab_i(base, l * F_STRIDE + F_WP); w.bias = tab_i(base, l * F_STRIDE + F_BIAS);
-    w.tqt = tab_i(base, l * F_STRIDE + F_TQT); w.amt = tab_i(base, l * F_STRIDE + F_AMT);
     w.slope = tab_f(base, l * F_STRIDE + F_SLOPE);
     return w;
 }
@@ -189,12 +189,6 @@ __device__ __forceinline__ float mul_bc(float coef, float y) {
         asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "=v"(r) : "v"(coef), "v"(y), "n"(L));
     else
         asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(coef), "v"(y), "n"(L));
-    return r;
-}
-template <int L>
-__device__ __forceinline__ float mov_bc(float coef) {
-    float r;
-    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(coef), "n"(L));
     return r;
 }
 template <int... Is, class F>
@@ -872,7 +866,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
         LayerW w;
         w.tq = tab_i(wb, TABC + l * F_STRIDE + F_TQ); w.am = tab_i(wb, TABC + l * F_STRIDE + F_AM);
         w.wp = tab_i(wb, TABC + l * F_STRIDE + F_WP); w.bias = tab_i(wb, TABC + l * F_STRIDE + F_BIAS);
-        w.tqt = 0; w.amt = 0; w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
+        w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
         return w;
     };
     layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(0), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 2(16) -> 32
@@ -1262,7 +1256,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
 
     Builder B;
-    struct HostLayer { int tq, am, wp, bias, tqt, amt; float slope; };
+    struct HostLayer { int tq, am, wp, bias; float slope; };
     struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4]; } U;
     memset(&U, 0, sizeof(U));
     B.alloc(TAB_FLOATS);  // offset table lives at the start of the buffer
@@ -1401,7 +1395,6 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         for (int l = 0; l < NLAYERS; ++l) {
             tab[l * F_STRIDE + F_TQ] = U.L[l].tq; tab[l * F_STRIDE + F_AM] = U.L[l].am;
             tab[l * F_STRIDE + F_WP] = U.L[l].wp; tab[l * F_STRIDE + F_BIAS] = U.L[l].bias;
-            tab[l * F_STRIDE + F_TQT] = U.L[l].tqt; tab[l * F_STRIDE + F_AMT] = U.L[l].amt;
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
         }
         tab[TAB_WE] = U.we; tab[TAB_BE] = U.be; tab[TAB_WEF] = wef;
