@@ -175,7 +175,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "score_kernel<3,2,4> (+cond_fast_kernel<3,4>)", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
-                         "hbm_algorithmic_bytes_per_window": 820, "traffic": None},
+                         "hbm_algorithmic_bytes_per_window": 820,
+                         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+                         # profiles/r01f_pmc_hbm.txt); measured for the default workload only
+                         "traffic": 7.59e6 if (B, ns, S) == (1024, 10, 5) else None,
+                         "traffic_source": "profiles/r01f_pmc_hbm.txt"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ns, S, args.cpu_budget)
