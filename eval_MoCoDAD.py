@@ -30,6 +30,9 @@ def main():
     ap.add_argument("-c", "--config", type=str, required=True)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic clips instead of dataset files")
     ap.add_argument("--frames-per-clip", type=int, default=200)
+    ap.add_argument("--device-windows", action="store_true",
+                    help="upload per-person trajectories once and let the kernels window + transform them on load "
+                         "(instead of materialising seg_len x num_transform copies on the host)")
     cli = ap.parse_args()
     args = load_config(cli.config)
     if hasattr(args, "diffusion_on_latent"):
@@ -44,7 +47,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    if cli.synthetic:
+    tw = None
+    if cli.synthetic and cli.device_windows:
+        from mocodad_amd.data.windows import TrajectoryWindows
+        trajs, gts = synthetic.make_trajectories(n_clips=cli.synthetic, frames_per_clip=cli.frames_per_clip, seed=args.seed)
+        tw = TrajectoryWindows(trajs, args.seg_len, args.num_transform).to(dev)
+        data, trans, meta, frames = tw, tw.trans.long(), tw.meta, tw.frames
+        gt_dir = tempfile.mkdtemp(prefix="mocodad_gt_")
+        synthetic.write_gt(gt_dir, gts)
+        args.gt_path = gt_dir
+    elif cli.synthetic:
         data, trans, meta, frames, gts = synthetic.make_dataset(n_clips=cli.synthetic, frames_per_clip=cli.frames_per_clip,
                                                                 seg_len=args.seg_len, num_transform=args.num_transform,
                                                                 seed=args.seed)
@@ -64,7 +76,7 @@ def main():
     elif rank == 0:
         print(f"[warn] checkpoint {ckpt} not found: scoring with random-init weights")
 
-    n = data.shape[0]
+    n = len(tw) if tw is not None else data.shape[0]
     shard = WindowShard(n, rank, world)
     if world > 1:
         shard.host_meta = (trans.numpy(), meta.numpy(), frames.numpy())
@@ -73,7 +85,9 @@ def main():
     t0 = time.perf_counter()
     model.on_test_epoch_start()
     with torch.no_grad():
-        for i, batch in enumerate(synthetic.batches((data, trans, meta, frames), args.batch_size, shard.lo, shard.hi)):
+        batches = tw.batches(args.batch_size, shard.lo, shard.hi) if tw is not None else \
+            synthetic.batches((data, trans, meta, frames), args.batch_size, shard.lo, shard.hi)
+        for i, batch in enumerate(batches):
             model._calls = shard.lo + i * args.batch_size     # global window id keys the noise stream
             model.test_step(batch, i)
     auc = model.on_test_epoch_end()

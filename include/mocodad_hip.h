@@ -114,6 +114,25 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
               uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
               float* loss_out, float* pose_out, void* stream);
 
+/* Window view: lets the kernels read windows straight out of per-person trajectory buffers
+ * and apply the dataset's test-time affine transform while loading, instead of the host materialising
+ * seg_len x num_transform copies (reference: sliding windows utils/preprocessing.py:14-86, transforms
+ * utils/dataset_utils.py:255-310 applied per item in utils/dataset.py:67-76).
+ * Element (b, c, t, v) of window b is data[base[b] + c*stride_c + t*stride_t + v], then, when trans != NULL,
+ * [x', y'] = A[trans[b]] @ [x, y, 1] with A = affine + 6*trans[b] = rows [a00 a01 a02 a10 a11 a12]. */
+typedef struct {
+    const int64_t* base;      /* device (B,) element offsets; NULL = dense (B,C,T,V) tensor */
+    int64_t stride_c;         /* elements between the two coordinates of one joint */
+    int64_t stride_t;         /* elements between consecutive frames */
+    const int32_t* trans;     /* device (B,) transform index per window, or NULL */
+    const float* affine;      /* device (n_transform, 6), required when trans != NULL */
+} mcd_window_view_t;
+
+/* mcd_score with a window view (view == NULL is exactly mcd_score). */
+int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
+                   const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+                   float* loss_out, float* pose_out, void* stream);
+
 /* Replaces: MoCoDAD._aggregation_strategy (mocodad.py:454-520) on the (B,S) losses / (B,S,C,Tx,V) poses.
  * data/cfg give the ground-truth corrupt frames for the *_pose strategies.  loss_agg (B,), pose_agg
  * NULL or (B,C,Tx,V).  MCD_AGGR_ALL is the identity and is not handled here. */

@@ -30,6 +30,11 @@ class ScoreCfg(C.Structure):
                 ("corrupt_idx", C.c_int32 * MCD_MAX_FRAMES), ("loss_fn", C.c_int32)]
 
 
+class WindowView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("stride_c", C.c_int64), ("stride_t", C.c_int64), ("trans", C.c_void_p),
+                ("affine", C.c_void_p)]
+
+
 _SIGS = {
     "mcd_pack_weights": (C.c_int, [C.POINTER(Tensor), C.c_int32, C.POINTER(ModelCfg), C.c_int32, C.POINTER(C.c_void_p)]),
     "mcd_free_weights": (None, [C.c_void_p]),
@@ -38,6 +43,8 @@ _SIGS = {
     "mcd_score_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(ScoreCfg)]),
     "mcd_score": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcd_score_view": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.POINTER(WindowView), C.c_void_p, C.c_uint64,
+                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_aggregate": (C.c_int, [C.POINTER(ScoreCfg), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_scatter_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

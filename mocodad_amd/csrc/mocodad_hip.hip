@@ -124,10 +124,29 @@ struct Prof {
 };
 #define STAGE(id) prof.mark(id)
 
+// where the windows live: a dense (B,C,T,V) tensor, or a view into trajectory buffers with an optional affine
+// test-time transform applied on load (mcd_window_view_t)
+struct DataView {
+    const float* data;
+    const long long* base;
+    long long sc, st;
+    const int* trans;
+    const float* aff;
+};
+__device__ __forceinline__ float load_coord(const DataView& dv, int b, int c, int t, int v, int seg_len) {
+    const long long sc = dv.base ? dv.sc : (long long)seg_len * 17;
+    const long long st = dv.base ? dv.st : 17;
+    const float* p = dv.data + (dv.base ? dv.base[b] : (long long)b * C0 * seg_len * 17) + t * st + v;
+    if (!dv.trans) return p[c * sc];
+    const float x = p[0], y = p[sc];
+    const float* a = dv.aff + dv.trans[b] * 6 + c * 3;
+    return (a[0] * x + a[1] * y) + a[2];
+}
+
 struct ScoreParams {
     unsigned long long* prof; // stage timing accumulators (MCD_PROFILE builds) or null
     const float* wbuf;        // packed weights; first TAB_FLOATS words = offset table
-    const float* data;        // (B,C,T,V)
+    DataView dv;              // windows: (B,C,T,V) tensor or a trajectory view
     const float* noise;       // (S,K,B,C,Tx,V) or null
     const float* cond_emb;    // (B,16) or null
     const float* step_table;  // (ns, 4+16)
@@ -572,7 +591,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (P.mode == 1) {
                 xv[c] = P.x_in[((b * C0 + c) * T + t) * 17 + v];
             } else if (t < tf) {
-                xv[c] = P.data[((b * C0 + c) * P.seg_len + P.src_frame[t]) * 17 + v];
+                xv[c] = load_coord(P.dv, b, c, P.src_frame[t], v, P.seg_len);
             } else {
                 const int e = (c * Tx + (t - tf)) * 17 + v;
                 if (P.noise) xv[c] = P.noise[((size_t)(s * K + 0) * P.B + b) * CTV + e];
@@ -802,7 +821,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         if (!valid) chain = P.n_chains - 1;
         const int b = chain / P.S, s = chain % P.S;
         const float x0 = XT[((n * T + tf + tx) * 17 + v) * 4 + c];
-        const float gt = P.data[((b * C0 + c) * P.seg_len + P.src_frame[tf + tx]) * 17 + v];
+        const float gt = load_coord(P.dv, b, c, P.src_frame[tf + tx], v, P.seg_len);
         const float d = fabsf(x0 - gt);
         float l;
         if (P.loss_fn == MCD_LOSS_SMOOTH_L1) l = d < 1.f ? 0.5f * d * d : d - 0.5f;
@@ -833,9 +852,8 @@ constexpr int TABC_LW = 40, TABC_LB = 41;  // bottleneck Linear weight [16][32*T
 struct FrameIdx { int idx[MCD_MAX_FRAMES]; };
 
 template <int T, int NB>
-__global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbuf, const float* __restrict__ data,
-                                                                const FrameIdx fi, int seg_len, float* __restrict__ emb_out,
-                                                                int B) {
+__global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbuf, const DataView dv, const FrameIdx fi,
+                                                                int seg_len, float* __restrict__ emb_out, int B) {
     constexpr int P17 = ceil16(NB * T * 17);
     constexpr int s16 = P17 * 20, s32 = P17 * 36;
     constexpr int TV = T * 17, COLS = NB * TV;
@@ -858,7 +876,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
         const int c = u % C0, col = u / C0;
         const int n = col / TV, t = (col / 17) % T, v = col % 17;
         const int b = b0 + n < B ? b0 + n : B - 1;
-        X0[col * 20 + c] = data[(((size_t)b * C0 + c) * seg_len + fi.idx[t]) * 17 + v];
+        X0[col * 20 + c] = load_coord(dv, b, c, fi.idx[t], v, seg_len);
     }
     __syncthreads();
     const float* wb = wbuf;
@@ -1210,7 +1228,7 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
 
 namespace {
 template <int T, int NB>
-int launch_cond_fast_t(const mcd_weights* w, const float* data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+int launch_cond_fast_t(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     constexpr int P17 = ceil16(NB * T * 17);
     constexpr size_t bytes = (size_t)P17 * (2 * 20 + 2 * 36) * 4;
     static bool attr_set[16] = {false};
@@ -1225,7 +1243,7 @@ int launch_cond_fast_t(const mcd_weights* w, const float* data, const FrameIdx& 
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
-int launch_cond_fast(const mcd_weights* w, const float* data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+int launch_cond_fast(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     switch (w->cond.Tc) {
         case 3: return launch_cond_fast_t<3, 4>(w, data, fi, seg_len, emb, B, st);
         case 6: return launch_cond_fast_t<6, 2>(w, data, fi, seg_len, emb, B, st);
@@ -1431,7 +1449,10 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
     if (w->cond_fast && !getenv("MCD_COND_GENERIC")) {
         FrameIdx fi;
         for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = k;
-        return launch_cond_fast(w, cond_data, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
+        DataView dv;
+        memset(&dv, 0, sizeof(dv));
+        dv.data = cond_data;
+        return launch_cond_fast(w, dv, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
     }
     const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
     static bool attr_set[16] = {false};
@@ -1465,17 +1486,23 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
     return (int64_t)cfg->n_windows * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
 }
 
-__global__ void gather_frames_kernel(const float* __restrict__ data, float* __restrict__ out, int B, int C, int T, int V,
-                                     int n, const FrameIdx fi) {
+__global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out, int B, int C, int T, int V, int n,
+                                     const FrameIdx fi) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= B * C * n * V) return;
     const int v = u % V, k = (u / V) % n, c = (u / (V * n)) % C, b = u / (V * n * C);
-    out[u] = data[(((size_t)b * C + c) * T + fi.idx[k]) * V + v];
+    out[u] = load_coord(dv, b, c, fi.idx[k], v, T);
 }
 
 int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise, uint64_t seed,
               int64_t first_window_id, const float* step_table, void* workspace, float* loss_out, float* pose_out,
               void* stream) {
+    return mcd_score_view(w, cfg, data, nullptr, noise, seed, first_window_id, step_table, workspace, loss_out, pose_out, stream);
+}
+
+int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
+                   const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+                   float* loss_out, float* pose_out, void* stream) {
     if (!w || !cfg) return fail(MCD_EINVAL, "null argument");
     const int B = cfg->n_windows, S = cfg->n_samples;
     if (B <= 0) return MCD_OK;
@@ -1491,7 +1518,13 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
     hipStream_t st = (hipStream_t)stream;
     ScoreParams P;
     memset(&P, 0, sizeof(P));
-    P.wbuf = w->dbuf; P.prof = g_prof; P.data = data; P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
+    P.wbuf = w->dbuf; P.prof = g_prof; P.dv.data = data;
+    if (view) {
+        if (view->trans && !view->affine) return fail(MCD_EINVAL, "window view: trans given without an affine table");
+        P.dv.base = reinterpret_cast<const long long*>(view->base); P.dv.sc = view->stride_c; P.dv.st = view->stride_t;
+        P.dv.trans = view->trans; P.dv.aff = view->affine;
+        if (!view->base) { P.dv.sc = (long long)cfg->seg_len * 17; P.dv.st = 17; }
+    } P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
     P.seed = seed; P.first_window = first_window_id;
     P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt; P.t_fixed = tf;
     P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
@@ -1505,7 +1538,7 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
         if (w->cond_fast && !getenv("MCD_COND_GENERIC")) {
             FrameIdx fi;
             for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
-            int rc = launch_cond_fast(w, data, fi, cfg->seg_len, emb, B, st);
+            int rc = launch_cond_fast(w, P.dv, fi, cfg->seg_len, emb, B, st);
             if (rc != MCD_OK) return rc;
             P.cond_emb = emb;
             return launch_score(Tu, P, st);
@@ -1513,7 +1546,7 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
         const int total = B * C0 * Tc * 17;
         FrameIdx fi;
         for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
-        hipLaunchKernelGGL(gather_frames_kernel, dim3((total + 255) / 256), dim3(256), 0, st, data, cbuf, B, C0, cfg->seg_len,
+        hipLaunchKernelGGL(gather_frames_kernel, dim3((total + 255) / 256), dim3(256), 0, st, P.dv, cbuf, B, C0, cfg->seg_len,
                            17, Tc, fi);
         HIP_TRY(hipGetLastError());
         int rc = mcd_cond_encode(w, cbuf, B, emb, stream);

@@ -46,6 +46,29 @@ def make_dataset(n_clips: int = 4, frames_per_clip: int = 120, persons_per_clip:
             torch.tensor(meta, dtype=torch.int64), torch.from_numpy(np.stack(frames).astype(np.int32)), gts)
 
 
+def make_trajectories(n_clips: int = 4, frames_per_clip: int = 120, persons_per_clip: int = 3, seed: int = 999,
+                      anomaly_gain: float = 3.0):
+    """{(scene, clip, person): (first_frame, traj (F,2,17) f32)} + gt masks, same generative model as make_dataset."""
+    rng = np.random.default_rng(seed)
+    trajs, gts = {}, {}
+    for clip in range(1, n_clips + 1):
+        scene = 1
+        gt = np.zeros(frames_per_clip, dtype=np.int64)
+        a = int(rng.integers(frames_per_clip // 4, frames_per_clip // 2))
+        gt[a:a + frames_per_clip // 5] = 1
+        gts[(scene, clip)] = gt
+        for person in range(1, persons_per_clip + 1):
+            f0 = int(rng.integers(1, 10))
+            f1 = frames_per_clip - int(rng.integers(0, 10))
+            n = f1 - f0 + 1
+            step = rng.standard_normal((n, 2, 17)) * 0.08
+            step[gt[f0 - 1:f1] == 1] *= anomaly_gain
+            traj = np.cumsum(step, 0) + rng.standard_normal((1, 2, 17))
+            traj = np.clip((traj - np.median(traj)) / (np.percentile(traj, 90) - np.percentile(traj, 10) + 1e-6), -5, 5)
+            trajs[(scene, clip, person)] = (f0, traj.astype(np.float32))
+    return trajs, gts
+
+
 def write_gt(gt_dir: str, gts: Dict[Tuple[int, int], np.ndarray]) -> None:
     os.makedirs(gt_dir, exist_ok=True)
     for (scene, clip), g in gts.items():

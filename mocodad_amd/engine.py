@@ -115,12 +115,27 @@ class HipScorer:
             _lib.check(self.L.mcd_unet_forward(self._h, _ptr(x), _ptr(cond), _ptr(tab), int(t), x.shape[0], _ptr(out), _stream()))
         return out
 
-    def score(self, data: torch.Tensor, *, n_samples: int, noise_steps: int, noise: Optional[torch.Tensor] = None,
+    def score(self, data, *, n_samples: int, noise_steps: int, noise: Optional[torch.Tensor] = None,
               seed: int = 0, first_window_id: int = 0, loss_fn: str = "smooth_l1", want_poses: bool = False
               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """data (B,C,T,V) -> (loss (B,S), poses (B,S,C,Tx,V) | None).  Asynchronous on the current stream."""
-        data = _f32c(data, self.device)
-        B = data.shape[0]
+        """data (B,C,T,V) tensor, or a mocodad_amd.data.windows.WindowBatch (windows read in place from trajectory
+        buffers, test-time transform applied on load) -> (loss (B,S), poses (B,S,C,Tx,V) | None).
+        Asynchronous on the current stream."""
+        view = None
+        keep = None
+        if hasattr(data, "as_view"):
+            wb = data.to(self.device)
+            keep = wb
+            view = _lib.WindowView(base=wb.base.data_ptr(), stride_c=wb.stride_c, stride_t=wb.stride_t,
+                                   trans=wb.trans.data_ptr() if wb.trans is not None else None,
+                                   affine=wb.affine.data_ptr() if wb.affine is not None else None)
+            B = int(wb.base.shape[0])
+            data = wb.buffer
+            if wb.seg_len != self.seg_len:
+                raise ValueError(f"window view has seg_len {wb.seg_len}, model expects {self.seg_len}")
+        else:
+            data = _f32c(data, self.device)
+            B = data.shape[0]
         S = int(n_samples)
         Tx = len(self.corrupt_idx)
         cfg = self._score_cfg(B, S, int(noise_steps), loss_fn)
@@ -135,9 +150,10 @@ class HipScorer:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
         with torch.cuda.device(self.device):
-            _lib.check(self.L.mcd_score(self._h, C.byref(cfg), _ptr(data), _ptr(noise), C.c_uint64(seed & (2**64 - 1)),
-                                        C.c_int64(first_window_id), _ptr(self.table(noise_steps)), _ptr(self._ws),
-                                        _ptr(loss), _ptr(poses), _stream()))
+            _lib.check(self.L.mcd_score_view(self._h, C.byref(cfg), _ptr(data), C.byref(view) if view is not None else None,
+                                             _ptr(noise), C.c_uint64(seed & (2**64 - 1)), C.c_int64(first_window_id),
+                                             _ptr(self.table(noise_steps)), _ptr(self._ws), _ptr(loss), _ptr(poses), _stream()))
+        del keep
         return loss, poses
 
     def aggregate(self, data: torch.Tensor, loss_all: torch.Tensor, poses_all: Optional[torch.Tensor], strategy: str,
@@ -153,7 +169,13 @@ class HipScorer:
         if name not in _lib.AGGR or name == "all":
             raise ValueError(f"Unknown aggregation strategy {strategy}")
         cfg = self._score_cfg(B, S, int(noise_steps), loss_fn)
-        data = _f32c(data, self.device)
+        needs_data = name in ("mean_pose", "median_pose")
+        if torch.is_tensor(data):
+            data = _f32c(data, self.device)
+        elif needs_data:
+            raise ValueError("the *_pose aggregation strategies need the materialised (B,C,T,V) windows")
+        else:
+            data = None
         out = torch.empty(B, device=self.device, dtype=torch.float32)
         gives_pose = name in ("best", "worst", "mean_pose", "median_pose")
         pose = None

@@ -287,6 +287,8 @@ class MoCoDAD(_Base):
         if window_offset is None:
             window_offset = self._calls
         self._calls += tensor_data.shape[0]
+        if hasattr(tensor_data, "as_view") and pose_aggr and aggr in ("mean_pose", "median_pose"):
+            tensor_data = tensor_data.materialize()      # the *_pose strategies compare against the windows themselves
         loss_all, poses_all = sc.score(tensor_data, n_samples=S, noise_steps=ns, noise=noise, seed=self.seed,
                                        first_window_id=window_offset, loss_fn=self.loss_name, want_poses=want_pose)
         selected_x, loss = self._aggregate(sc, tensor_data, loss_all, poses_all, aggr, want_pose)
@@ -320,6 +322,7 @@ class MoCoDAD(_Base):
         return out + additional_out
 
     def _unpack_data(self, x):
+        # x[0] is the (B,C,T,V) tensor of the reference, or a WindowBatch view into trajectories (data/windows.py)
         return x[0].to(self.device), [x[1], x[2], x[3]]
 
     # -------------------------------------------------------------- test / validation loops

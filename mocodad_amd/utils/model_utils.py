@@ -16,7 +16,10 @@ def processing_data(data: Sequence[Sequence]) -> Tuple[np.ndarray, np.ndarray, n
     concatenated on the device first and cross PCIe once."""
     cols = list(zip(*[d[:5] for d in data]))
     out = []
-    for col in cols:
+    for ci, col in enumerate(cols):
+        if ci == 1 and any(hasattr(t, "as_view") or t is None for t in col):
+            out.append(None)     # windows were views into trajectories: nothing to collate (gt_data is unused downstream)
+            continue
         if all(torch.is_tensor(t) and t.is_cuda for t in col):
             out.append(torch.cat(list(col), dim=0).cpu().numpy())
         else:

@@ -183,6 +183,20 @@ def extra(MoCoDAD):
         save(f"traj_{name}_ns{ns}_S{S}.npz", data=data, noise=noise.half(), **out)
 
 
+def extra2():
+    """Test-time affine transforms of the reference's dataset (utils/dataset_utils.py:255-310; applied in
+    utils/dataset.py:67-76): `python tests/golden/gen_golden.py --extra2`."""
+    from utils.dataset_utils import ae_trans_list
+    gen = torch.Generator().manual_seed(99)
+    base = synth_windows(6, 6, gen).numpy()                       # (N,2,T,V) float32
+    pose3 = np.concatenate([base, np.ones_like(base[:, :1])], 1)   # reference windows carry a confidence channel = 1
+    out = {"base": base}
+    for i, tr in enumerate(ae_trans_list):
+        out[f"mat_{i}"] = tr.trans_mat.numpy()
+        out[f"out_{i}"] = np.stack([tr(p)[:2] for p in pose3]).astype(np.float32)
+    save("transforms.npz", **out)
+
+
 def main():
     _install_lightning_stub()
     sys.path.insert(0, REF)
@@ -193,6 +207,9 @@ def main():
     from utils.model_utils import processing_data  # noqa: E402
     if "--extra" in sys.argv:
         extra(MoCoDAD)
+        return
+    if "--extra2" in sys.argv:
+        extra2()
         return
 
     # ---------------------------------------------------------------- 5. schedules

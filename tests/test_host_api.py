@@ -155,3 +155,24 @@ def test_pack_weights_reports_missing_tensor_without_a_gpu():
     assert rc == -2 and b"missing tensor" in L.mcd_last_error()
     cfg.t_unet = 5
     assert L.mcd_pack_weights(arr, 1, ctypes.byref(cfg), 0, ctypes.byref(h)) == -4
+
+
+def test_window_views_materialize_like_the_reference_dataset():
+    """TrajectoryWindows / WindowBatch (views into trajectories + affine on load) reproduce what the reference's
+    dataset materialises: the golden transformed windows, in transform-major order."""
+    from mocodad_amd.data.windows import TrajectoryWindows
+    g = load_golden("transforms.npz")
+    base = g["base"]                                    # (N,2,T,V): treat each window as a 6-frame trajectory
+    trajs = {(1, 1, i + 1): (1, np.ascontiguousarray(base[i].transpose(1, 0, 2))) for i in range(base.shape[0])}
+    tw = TrajectoryWindows(trajs, seg_len=6, num_transform=5)
+    assert len(tw) == 5 * base.shape[0] and tw.n_samples == base.shape[0]
+    mat = tw.materialize().numpy()
+    for tr in range(5):
+        np.testing.assert_allclose(mat[tr * base.shape[0]:(tr + 1) * base.shape[0]], g[f"out_{tr}"], atol=1e-6, rtol=0)
+    assert tw.trans.tolist() == sorted(tw.trans.tolist()) and tw.meta.shape == (len(tw), 4)
+    # sliding windows over a longer trajectory: window s starts at frame first_frame + s
+    long = {(1, 2, 1): (5, np.arange(10 * 2 * 17, dtype=np.float32).reshape(10, 2, 17))}
+    tw2 = TrajectoryWindows(long, seg_len=6, num_transform=1)
+    m2 = tw2.materialize()
+    assert len(tw2) == 5 and tw2.frames[2].tolist() == [7, 8, 9, 10, 11, 12] and tw2.meta[2].tolist() == [1, 2, 1, 7]
+    assert torch.equal(m2[2, 1, 0], torch.from_numpy(long[(1, 2, 1)][1][2, 1]))

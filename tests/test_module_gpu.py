@@ -138,3 +138,30 @@ def test_extra_variants_vs_reference(name):
     if "cond_emb" in g:
         emb = m.scorer().cond_encode(batch[0][:, :, m._frame_split()[0], :]).cpu().numpy()
         np.testing.assert_allclose(emb, g["cond_emb"], atol=2e-5, rtol=1e-5)
+
+
+def test_window_views_score_like_materialised_windows(tmp_path):
+    """Windows read in place from trajectory buffers with the test-time transform applied on load (mcd_score_view)
+    give the scores of the host-materialised (B,C,T,V) windows, and the test loop gives the same AUC."""
+    from mocodad_amd.data import synthetic
+    from mocodad_amd.data.windows import TrajectoryWindows
+    trajs, gts = synthetic.make_trajectories(n_clips=2, frames_per_clip=40, persons_per_clip=2)
+    synthetic.write_gt(str(tmp_path), gts)
+    tw = TrajectoryWindows(trajs, seg_len=6, num_transform=5)
+    dense = tw.materialize()
+    m, _, _ = _model("inject", noise_steps=4, n_generated_samples=2, gt_path=str(tmp_path), num_transform=5,
+                     dataset_choice="HR-STC", pad_size=-1, filter_kernel_size=3, frames_shift=2, save_tensors=False)
+    sc = m.scorer()
+    tw.to("cuda:0")
+    a, pa = sc.score(tw.batch(0, len(tw))[0], n_samples=2, noise_steps=4, seed=3, want_poses=True)
+    b, pb = sc.score(dense, n_samples=2, noise_steps=4, seed=3, want_poses=True)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=0)
+    np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    aucs = []
+    for batches in (tw.batches(128), synthetic.batches((dense, tw.trans.long(), tw.meta, tw.frames), 128)):
+        m.on_test_epoch_start()
+        for i, batch in enumerate(batches):
+            m._calls = i * 128
+            m.test_step(batch, i)
+        aucs.append(m.on_test_epoch_end())
+    assert abs(aucs[0] - aucs[1]) < 1e-6, aucs
