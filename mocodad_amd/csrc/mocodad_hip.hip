@@ -149,6 +149,8 @@ struct ScoreParams {
     DataView dv;              // windows: (B,C,T,V) tensor or a trajectory view
     const float* noise;       // (S,K,B,C,Tx,V) or null
     const float* cond_emb;    // (B,16) or null
+    const float* emb_tab;     // precomputed per-step layer embeddings [(window,) step-1][EMB_STRIDE] or null (computed in-kernel)
+    long long emb_wstride;    // floats between two windows' tables (0: one table shared by all windows)
     const float* step_table;  // (ns, 4+16)
     const float* x_in;        // single-pass mode: (B,C,Tu,V)
     float* loss_out;          // (B,S)
@@ -235,39 +237,57 @@ __host__ __device__ constexpr int mix_vmap(int V, int ks, int g) {
 // init(n,q,w,c) seeds the accumulator (0, or the residual term of a W-first layer); store(n,q,w,c,val) consumes the
 // result (plain Z store, in-place PReLU epilogue of layer 6, or the fused DDPM update of layer 10).
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int V, int T, int NB, class Init, class Store>
-__device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const float* __restrict__ tqd,
-                                          const float* __restrict__ af, int wave, int lane, Init&& init, Store&& store) {
-    constexpr int KS = (V + 3) / 4;
-    constexpr int KP = 2 * (KS / 2);                     // paired k-steps (see mix_vmap)
-    constexpr int MT = (V + 15) / 16;
-    constexpr int CB = CIN / 16;
+template <int CIN, int V, int T, int NB>
+struct MixCfg {
+    static constexpr int KS = (V + 3) / 4;
+    static constexpr int KP = 2 * (KS / 2);                     // paired k-steps (see mix_vmap)
+    static constexpr int MT = (V + 15) / 16;
+    static constexpr int CB = CIN / 16;
     // output frames computed together by one unit: all of them (shared X reads) when that still gives every wave
     // work, otherwise one frame per unit
-    constexpr int QALL = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;
-    constexpr int QC = (NB * CB * (T / QALL) >= NWAVES) ? QALL : 1;
-    constexpr int NQ = T / QC;
-    constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
-    constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
-    gfloat* tqd_g = as_global(tqd);
-    gfloat* af_g = as_global(af);
+    static constexpr int QALL = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;
+    static constexpr int QC = (NB * CB * (T / QALL) >= NWAVES) ? QALL : 1;
+    static constexpr int NQ = T / QC;
+    static constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
+    static constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;   // rounds
+    static constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
+};
+// time-mix rows + joint-mix A fragments of one unit.  Loaded one stage ahead of their use (behind the barrier of the
+// previous stage their ~L2 latency would sit on the critical path of every mix).
+template <int CIN, int V, int T, int NB>
+struct MixCoef {
+    using M = MixCfg<CIN, V, T, NB>;
+    float tq[M::QC][M::NR], aop[M::QC][M::MT][M::KS];
+    __device__ __forceinline__ void load(const float* tqd, const float* af, int u, int lane) {
+        gfloat* tqd_g = as_global(tqd);
+        gfloat* af_g = as_global(af);
+        const int uc = u < M::UNITS ? u : M::UNITS - 1;
+        const int q0 = (uc % M::NQ) * M::QC;
+#pragma unroll
+        for (int qi = 0; qi < M::QC; ++qi) {
+#pragma unroll
+            for (int r = 0; r < M::NR; ++r) tq[qi][r] = tqd_g[((q0 + qi) * M::NR + r) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < M::MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < M::KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * M::MT + mt) * M::KS + ks) * 64 + lane];
+        }
+    }
+};
+
+template <int CIN, int V, int T, int NB, class Init, class Store>
+__device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const MixCoef<CIN, V, T, NB>& pre,
+                                          const float* __restrict__ tqd, const float* __restrict__ af, int wave, int lane,
+                                          Init&& init, Store&& store) {
+    using M = MixCfg<CIN, V, T, NB>;
+    constexpr int KS = M::KS, KP = M::KP, MT = M::MT, CB = M::CB, QC = M::QC, NQ = M::NQ, UNITS = M::UNITS, PER = M::PER;
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
-    for (int u = wave; u < UNITS; u += NWAVES) {
+    auto unit = [&](const MixCoef<CIN, V, T, NB>& cur, int u) {
         const int q0 = (u % NQ) * QC, rest = u / NQ;
         const int cb = rest % CB, n = rest / CB;
         const float* xin_p = in + (n * T * V + voff_pair) * cs_in + cb * 16 + j;
         const float* xin_l = in + (n * T * V + g) * cs_in + cb * 16 + j;
-        float tq[QC][NR], aop[QC][MT][KS];
-#pragma unroll
-        for (int qi = 0; qi < QC; ++qi) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) tq[qi][r] = tqd_g[((q0 + qi) * NR + r) * 64 + lane];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
-        }
         f32x4 acc[QC][MT];
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi)
@@ -288,14 +308,14 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             static_for<QC>([&](auto qq) {
                 constexpr int qi = decltype(qq)::value;
                 // y = sum_t X[t, v] * T[v, t, q]   (coefficient (ks,t) = lane ks*T+t of this DPP row)
-                float y = mul_bc<(ks * T) % 16, T == 1>(tq[qi][(ks * T) / 16], x[0]);
+                float y = mul_bc<(ks * T) % 16, T == 1>(cur.tq[qi][(ks * T) / 16], x[0]);
                 static_for<T - 1>([&](auto ti) {
                     constexpr int t = decltype(ti)::value + 1;
-                    fmac_bc<(ks * T + t) % 16, t == T - 1>(y, tq[qi][(ks * T + t) / 16], x[t]);
+                    fmac_bc<(ks * T + t) % 16, t == T - 1>(y, cur.tq[qi][(ks * T + t) / 16], x[t]);
                 });
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
+                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
             });
         });
 #pragma unroll
@@ -305,7 +325,34 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (mt * 16 + 4 * g + r < V) store(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j, acc[qi][mt][r]);
+    };
+    // later rounds: coefficients fetched one round ahead where the register budget allows (T = 3), else in place
+    if constexpr (T == 3) {
+        MixCoef<CIN, V, T, NB> cur = pre;
+        static_for<PER>([&](auto ri) {
+            constexpr int rnd = decltype(ri)::value;
+            const int u = wave + rnd * NWAVES;
+            MixCoef<CIN, V, T, NB> nxt;
+            if constexpr (rnd + 1 < PER) nxt.load(tqd, af, u + NWAVES, lane);
+            if (u < UNITS) unit(cur, u);
+            if constexpr (rnd + 1 < PER) cur = nxt;
+        });
+    } else {
+        MixCoef<CIN, V, T, NB> cur = pre;     // one copy of the unit body: these shapes are I-cache bound
+#pragma unroll 1
+        for (int u = wave; u < UNITS; u += NWAVES) {
+            if (u != wave) cur.load(tqd, af, u, lane);
+            unit(cur, u);
+        }
     }
+}
+// coefficients loaded at the top of the stage itself (condition encoder)
+template <int CIN, int V, int T, int NB, class Init, class Store>
+__device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const float* __restrict__ tqd,
+                                          const float* __restrict__ af, int wave, int lane, Init&& init, Store&& store) {
+    MixCoef<CIN, V, T, NB> mc;
+    mc.load(tqd, af, wave, lane);
+    mix_stage<CIN, V, T, NB>(in, cs_in, mc, tqd, af, wave, lane, init, store);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,27 +379,38 @@ __host__ __device__ constexpr int rs_vmap(bool capture, int vin, int ks, int g) 
     return capture ? (ks < 4 ? 4 * g + ks : 16 + g) : mix_vmap(vin, ks, g);
 }
 
+// resampler weights (A fragments) + bias of one wave, loaded one stage ahead
+template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE>
+struct RsCoef {
+    using RC = RsCfg<C, VIN, VOUT, T, NB, CAPTURE>;
+    float aop[RC::MT][RC::KS];
+    float bias[RC::MT][4];
+    __device__ __forceinline__ void load(const float* wf, const float* bdp, int lane) {
+        gfloat* wf_g = as_global(wf);
+        gfloat* bdp_g = as_global(bdp);
+        const int g = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < RC::MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < RC::KS; ++ks) aop[mt][ks] = wf_g[(mt * RC::KS + ks) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < RC::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[mt][r] = bdp_g[mt * 16 + 4 * g + r];
+    }
+};
+
 template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, int NSK>
 __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int cs_in, float* __restrict__ out, int cs_out,
-                                               const float* __restrict__ wf, const float* __restrict__ bdp,
+                                               const RsCoef<C, VIN, VOUT, T, NB, CAPTURE>& rc,
                                                float (&skip)[NSK], int wave, int lane) {
     using RC = RsCfg<C, VIN, VOUT, T, NB, CAPTURE>;
     constexpr int KS = RC::KS, MT = RC::MT, CB = RC::CB, UNITS = RC::UNITS, PER = RC::PER, SK = RC::SK;
     static_assert(!(CAPTURE || ADD) || NSK == PER * SK, "skip register count");
     constexpr int KP = 2 * (((VIN + 3) / 4) / 2);
-    gfloat* wf_g = as_global(wf);
-    gfloat* bdp_g = as_global(bdp);
     const int j = lane & 15, g = lane >> 4;
-    float aop[MT][KS];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) aop[mt][ks] = wf_g[(mt * KS + ks) * 64 + lane];
-    float bias[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[mt][r] = bdp_g[mt * 16 + 4 * g + r];
+    const auto& aop = rc.aop;
+    const auto& bias = rc.bias;
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
@@ -463,10 +521,15 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
 // one mix-first ST-GCN layer: LDS `in` -> `out`, with `z` as scratch; the three regions are disjoint.
 // generic mix-first ST-GCN layer (CIN -> COUT at V joints), used by the U-Net and by the condition encoder.
 // HASEMB = false: no embedding term (condition-encoder layers get t = None, components.py:56-63).
-template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB>
-__device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const float* __restrict__ in,
-                                              float* __restrict__ z, float* __restrict__ out,
-                                              const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id) {
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `mc`: this layer's mix coefficients (already loaded); `pre_gemm` runs between the mix barrier and the GEMM, `pre_barrier`
+// between the GEMM and the closing barrier -- the callers use them to issue the NEXT stage's coefficient loads.
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, class H1, class H2>
+__device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
+                                              const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
+                                              const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
+                                              H1&& pre_gemm, H2&& pre_barrier) {
     constexpr int MT = ceil16(COUT) / 16;
     constexpr int COLS = NB * T * V;
     constexpr int NT = ceil16(COLS) / 16;
@@ -475,23 +538,24 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     constexpr int KQ1 = CIN / 16, KQ2 = RES ? CIN / 16 : 0;
     float4 afr[KQ1 + KQ2];
     load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
-    mix_stage<CIN, V, T, NB>(in, CSI, wb + lw.tq, wb + lw.am, wave, lane,
+    const float* bias = wb + lw.bias;
+    mix_stage<CIN, V, T, NB>(in, CSI, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              [](int, int, int, int) { return 0.f; },
                              [&](int n, int q, int w, int c, float v) { z[((n * T + q) * V + w) * CSI + c] = v; });
     __syncthreads();
     prof.mark(prof_id);
-    const float* bias = wb + lw.bias;
+    float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
+    pre_gemm();
     const float slope = lw.slope;
     auto epi = [&](auto, int col, int c0, f32x4 acc) {
         if (col < COLS && c0 < COUT) {
-            const float4 b = load_global4(bias + c0);
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
             if (HASEMB) e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
             float4 v;
-            v.x = prelu(acc[0] + b.x, slope) + e.x;
-            v.y = prelu(acc[1] + b.y, slope) + e.y;
-            v.z = prelu(acc[2] + b.z, slope) + e.z;
-            v.w = prelu(acc[3] + b.w, slope) + e.w;
+            v.x = prelu(acc[0] + bcur.x, slope) + e.x;
+            v.y = prelu(acc[1] + bcur.y, slope) + e.y;
+            v.z = prelu(acc[2] + bcur.z, slope) + e.z;
+            v.w = prelu(acc[3] + bcur.w, slope) + e.w;
             *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
         }
     };
@@ -499,19 +563,32 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
         load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
+        bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
         gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi, mi);
     }
+    pre_barrier();
     __syncthreads();
     prof.mark(prof_id + 1);
+}
+// self-contained form (condition encoder): coefficients loaded at the top of the layer
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB>
+__device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const float* __restrict__ in,
+                                              float* __restrict__ z, float* __restrict__ out,
+                                              const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id) {
+    MixCoef<CIN, V, T, NB> mc;
+    mc.load(wb + lw.tq, wb + lw.am, wave, lane);
+    layer_generic<CIN, COUT, V, RES, HASEMB, T, NB>(wb, lw, mc, in, z, out, embl, wave, lane, prof, prof_id, NoHook{}, NoHook{});
 }
 
 // U-Net layer L of the fixed channel plan
 template <int L, int T, int NB>
-__device__ __forceinline__ void layer_std(const float* wb, const float* in, float* z, float* out, const float* emb,
-                                          int wave, int lane, Prof& prof) {
+using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
+template <int L, int T, int NB, class H1, class H2>
+__device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
+                                          const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
     constexpr LDesc D = layer_desc(L);
-    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB>(wb, layer_w(wb, L), in, z, out, emb + emb_off(L), wave, lane,
-                                                               prof, 32 + 3 * L);
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
+                                                               prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
@@ -602,6 +679,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         XT[u * 4 + 1] = xv[1];
     }
     __syncthreads();
+    // U-Net input as a 16-channel block X20 (x in channels 0,1; 2..15 zero).  Written here for the first pass; the
+    // fused DDPM store of layer 10 rewrites it for every following pass.
+    for (int u = tid; u < COLS17 * 4; u += NTHREADS) {
+        const int col = u >> 2, c4 = (u & 3) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 == 0) { v.x = XT[col * 4 + 0]; v.y = XT[col * 4 + 1]; }
+        *reinterpret_cast<float4*>(RG + PL::L0_in + col * 20 + c4) = v;
+    }
+    __syncthreads();
 
     Prof prof;
 #ifdef MCD_PROFILE
@@ -615,6 +701,18 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
+    // embedding rows EMB[n][532] of the first pass (one float4 per thread); the rows of pass i-1 are fetched during
+    // the last layer of pass i.  The embeddings depend on the step and the window only, so mcd_score precomputes them
+    // for the whole trajectory (emb_table_kernel); without a table (single-pass mode) they are computed per pass.
+    constexpr int EROW4 = EMB_STRIDE / 4;
+    const bool has_tab = P.emb_tab != nullptr;
+    auto erow_ptr = [&](int t_id, int row) {
+        const int n = t_id / EROW4, q4 = t_id % EROW4;
+        int chain = chain0 + n;
+        if (chain >= P.n_chains) chain = P.n_chains - 1;
+        return P.emb_tab + (size_t)(chain / P.S) * P.emb_wstride + (size_t)row * EMB_STRIDE + q4 * 4;
+    };
+    if (has_tab && tid < NB * EROW4) *reinterpret_cast<float4*>(EMB + tid * 4) = load_global4(erow_ptr(tid, i_first - 1));
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
         const float* wb = P.wbuf;
@@ -625,8 +723,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // ---- step prologue: SE = SiLU(pe(i) + cond) and the U-Net input as a 16-channel block X20 (x in ch 0,1)
-        if (tid < NB * EDIM) {
+        // ---- step prologue: layer-0 mix coefficients, this step's noise z (and, without a table, the embeddings)
+        LMix<0, T, NB> mc0;
+        mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);
+        if (!has_tab && tid < NB * EDIM) {
             const int n = tid / EDIM, k = tid % EDIM;
             int chain = chain0 + n;
             if (chain >= P.n_chains) chain = P.n_chains - 1;
@@ -637,8 +737,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         // this step's noise z (one element per thread: the Philox + Box-Muller cost is paid here, fully parallel,
         // not in the narrow epilogue of the last layer)
-        if (P.mode == 0 && sidx > 1) {
-            for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
+        // -- by the last two waves when they have no unit in the layer-0 mix that follows, else by everybody
+        constexpr bool NZ_TAIL = MixCfg<16, 17, T, NB>::UNITS <= NWAVES - 2;
+        constexpr int NZ_T0 = NZ_TAIL ? NTHREADS - 128 : 0, NZ_N = NZ_TAIL ? 128 : NTHREADS;
+        if (P.mode == 0 && sidx > 1 && tid >= NZ_T0) {
+            for (int u = tid - NZ_T0; u < COLS17 * C0; u += NZ_N) {
                 const int c = u % C0, col = u / C0;
                 const int n = col / TV17, t = (col / 17) % T, v = col % 17;
                 float z = 0.f;
@@ -654,83 +757,102 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 ZN[u] = z;
             }
         }
-        for (int u = tid; u < COLS17 * 4; u += NTHREADS) {
-            const int col = u >> 2, c4 = (u & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c4 == 0) { v.x = XT[col * 4 + 0]; v.y = XT[col * 4 + 1]; }
-            *reinterpret_cast<float4*>(RG + PL::L0_in + col * 20 + c4) = v;
-        }
-        __syncthreads();
         STAGE(0);
-        // ---- embeddings of this step for all 11 layers on the matrix cores: EMB[n][o] = b_e[o] + sum_k W_e[o][k] SE[n][k]
-        //      (M = 532 outputs in 34 m-tiles, K = 16, N = chains padded to 16; same stage as the layer-0 mix)
-        {
+        if (!has_tab) {
+            __syncthreads();
+            // embeddings of this step for all 11 layers on the matrix cores: EMB[n][o] = b_e[o] + sum_k W_e[o][k] SE[n][k]
+            //      (M = 532 outputs in 34 m-tiles, K = 16, N = chains padded to 16; same stage as the layer-0 mix)
             gfloat* wef = as_global(wb + tab_i(wb, TAB_WEF));
-            gfloat* beg = as_global(wb + tab_i(wb, TAB_BE));
             const int j = lane & 15, g = lane >> 4;
             float bk[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) bk[ks] = j < NB ? SE[j * EDIM + 4 * ks + g] : 0.f;
             constexpr int EMT = (EMB_TOTAL + 15) / 16;
             constexpr int ER = (EMT + NWAVES - 1) / NWAVES;
-            float wf[ER][4];
-            float4 be4[ER];
-#pragma unroll
-            for (int i = 0; i < ER; ++i) {          // all fragment loads first: one L2 round trip for the whole stage
-                const int mt = wave + i * NWAVES < EMT ? wave + i * NWAVES : EMT - 1;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wf[i][ks] = wef[(mt * 4 + ks) * 64 + lane];
-                be4[i] = load_global4(wb + tab_i(wb, TAB_BE) + mt * 16 + 4 * g);
-            }
-#pragma unroll
+#pragma unroll 1
             for (int i = 0; i < ER; ++i) {
                 const int mt = wave + i * NWAVES;
+                const int mtc = mt < EMT ? mt : EMT - 1;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][ks], bk[ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wef[(mtc * 4 + ks) * 64 + lane], bk[ks], acc, 0, 0, 0);
+                const float4 be4 = load_global4(wb + tab_i(wb, TAB_BE) + mtc * 16 + 4 * g);
                 const int o = mt * 16 + 4 * g;
                 if (mt < EMT && j < NB && o < EMB_TOTAL)
                     *reinterpret_cast<float4*>(EMB + j * EMB_STRIDE + o) =
-                        make_float4(acc[0] + be4[i].x, acc[1] + be4[i].y, acc[2] + be4[i].z, acc[3] + be4[i].w);
+                        make_float4(acc[0] + be4.x, acc[1] + be4.y, acc[2] + be4.z, acc[3] + be4.w);
             }
-            (void)beg;
         }
         STAGE(1);
-        layer_std<0, T, NB>(wb, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof);   // sp1a (2 -> 16)
+        // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
+        // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.
+        //      (PF: only where the register budget allows it -- the T = 3 shapes; otherwise loaded at the top of the stage.)
+        constexpr bool PF = T == 3;
+        auto mixload = [&](auto& mc, int l) { mc.load(wb + tab_i(wb, l * F_STRIDE + F_TQ), wb + tab_i(wb, l * F_STRIDE + F_AM), wave, lane); };
+        auto rsload = [&](auto& rc, int r) { rc.load(wb + tab_i(wb, TAB_RSW + r), wb + tab_i(wb, TAB_RSB + r), lane); };
+        auto mix_early = [&](auto& mc, int l) { if constexpr (PF) mixload(mc, l); };
+        auto mix_late = [&](auto& mc, int l) { if constexpr (!PF) mixload(mc, l); };
+        auto rs_early = [&](auto& rc, int r) { if constexpr (PF) rsload(rc, r); };
+        auto rs_late = [&](auto& rc, int r) { if constexpr (!PF) rsload(rc, r); };
+        NoHook nohook;
+        LMix<1, T, NB> mc1;
+        layer_std<0, T, NB>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
+                            [&] { mix_early(mc1, 1); }, nohook);                                           // sp1a (2 -> 16)
         STAGE(2);
         // ---- down path
-        layer_std<1, T, NB>(wb, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof);  // sd1.0
+        LMix<2, T, NB> mc2;
+        mix_late(mc1, 1);
+        layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
+                            [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
-        layer_std<2, T, NB>(wb, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof);   // sd1.1 -> d1
+        RsCoef<32, 17, 12, T, NB, true> rc1;
+        mix_late(mc2, 2);
+        layer_std<2, T, NB>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
+                            [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
         STAGE(4);
-        resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, wb + tab_i(wb, TAB_RSW + 0),
-                                                       wb + tab_i(wb, TAB_RSB + 0), skip1, wave, lane);  // down1 (captures d1)
+        LMix<3, T, NB> mc3;
+        mix_early(mc3, 3);
+        rs_late(rc1, 0);
+        resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         __syncthreads();
         STAGE(5);
-        layer_std<3, T, NB>(wb, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof);  // sd2.0
+        LMix<4, T, NB> mc4;
+        mix_late(mc3, 3);
+        layer_std<3, T, NB>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
+                            [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
         STAGE(6);
-        layer_std<4, T, NB>(wb, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof);   // sd2.1 -> d2
+        RsCoef<64, 12, 10, T, NB, true> rc2;
+        mix_late(mc4, 4);
+        layer_std<4, T, NB>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
+                            [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
         STAGE(7);
-        resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, wb + tab_i(wb, TAB_RSW + 1),
-                                                       wb + tab_i(wb, TAB_RSB + 1), skip2, wave, lane);  // down2 (captures d2)
+        LMix<5, T, NB> mc5;
+        mix_early(mc5, 5);
+        rs_late(rc2, 1);
+        resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         __syncthreads();
         STAGE(8);
-        {
-            layer_std<5, T, NB>(wb, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof);  // sd3.0
-            STAGE(9);
-        }
-        // ---- sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G, then out = PReLU(mix(P_t) + P_r + b) + e in place of P_r
+        // ---- sd3.0, then sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G, then out = PReLU(mix(P_t) + P_r + b) + e in place of P_r
         {
             constexpr int NT = PL::P10 / 16;
             constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
-            float* Pb = RG + PL::L6_p;
             float4 afr[8];
+            mix_late(mc5, 5);
+            layer_std<5, T, NB>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
+                                [&] { if constexpr (PF) load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0); });  // sd3.0
+            STAGE(9);
+            if constexpr (!PF) load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
+            float* Pb = RG + PL::L6_p;
+            MixCoef<64, 10, T, NB> mc6;
+            if constexpr (PF) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
+            gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
 #pragma unroll
-            for (int mi = 0; mi < Tiling<8, NT>::MW; ++mi) {
+            for (int mi = 1; mi < Tiling<8, NT>::MW; ++mi) {
                 load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
                 gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
             }
@@ -738,53 +860,76 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(10);
             gfloat* bias6 = as_global(wb + lw.bias);
             const float slope6 = lw.slope;
-            mix_stage<64, 10, T, NB>(Pb, 132, wb + lw.tq, wb + lw.am, wave, lane,
+            if constexpr (!PF) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
+            mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w, int c) { return Pb[((n * T + q) * 10 + w) * 132 + 64 + c]; },
                                      [&](int n, int q, int w, int c, float v) {
                                          Pb[((n * T + q) * 10 + w) * 132 + 64 + c] =
                                              prelu(v + bias6[c], slope6) + EMB[n * EMB_STRIDE + emb_off(6) + c];
                                      });
-            __syncthreads();
-            STAGE(11);
         }
+        RsCoef<64, 10, 12, T, NB, false> rc3;
+        rs_early(rc3, 2);
+        __syncthreads();
+        STAGE(11);
         // ---- up path
-        resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, wb + tab_i(wb, TAB_RSW + 2),
-                                                       wb + tab_i(wb, TAB_RSB + 2), skip2, wave, lane);  // up3 (+ d2)
+        LMix<7, T, NB> mc7;
+        mix_early(mc7, 7);
+        rs_late(rc3, 2);
+        resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         __syncthreads();
         STAGE(12);
-        {
-            layer_std<7, T, NB>(wb, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof);  // su4.0
-            STAGE(13);
-        }
-        {
-            layer_std<8, T, NB>(wb, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof);  // su4.1
-            STAGE(14);
-        }
-        resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, wb + tab_i(wb, TAB_RSW + 3),
-                                                       wb + tab_i(wb, TAB_RSB + 3), skip1, wave, lane);  // up2 (+ d1)
+        LMix<8, T, NB> mc8;
+        mix_late(mc7, 7);
+        layer_std<7, T, NB>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
+                            [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
+        STAGE(13);
+        RsCoef<32, 12, 17, T, NB, false> rc4;
+        mix_late(mc8, 8);
+        layer_std<8, T, NB>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
+                            [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
+        STAGE(14);
+        LMix<9, T, NB> mc9;
+        mix_early(mc9, 9);
+        rs_late(rc4, 3);
+        resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         __syncthreads();
         STAGE(15);
-        {
-            layer_std<9, T, NB>(wb, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof);  // su3.0
-            STAGE(16);
-        }
-        // ---- su3.1 (32 -> 2) W-first: P = [W_t; W_r] M32 (4 useful rows), then the 2-channel mix with the PReLU,
+        // ---- su3.0, then su3.1 (32 -> 2) W-first: P = [W_t; W_r] M32 (4 useful rows), then the 2-channel mix with the PReLU,
         //      embedding, U-Net residual (+X) and the DDPM update fused into its store
         {
             constexpr int NT = PL::P17 / 16;
             const LayerW lw = layer_w(wb, 10);
-            float* Pb = RG + PL::L10_p;
             float4 afr[2];
-            load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+            MixCoef<16, 17, T, NB> mc10;
+            mix_late(mc9, 9);
+            layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
+                                [&] {
+                                    if constexpr (PF) {
+                                        load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+                                        mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
+                                    }
+                                }, nohook);                                                              // su3.0
+            STAGE(16);
+            if constexpr (!PF) load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+            float* Pb = RG + PL::L10_p;
+            // next pass: its embedding rows (consumed at the top of the loop) and its layer-0 mix coefficients
+            float4 erow = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool fetch = has_tab && sidx > i_last && tid < NB * EROW4;
+            if (fetch) erow = load_global4(erow_ptr(tid, sidx - 2));
             gemm_tiles<1, NT, 2, 0, false>(afr, RG + PL::L10_in, 36, RG + PL::L10_in, 36, wave, lane,
                                            [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS17) *reinterpret_cast<float4*>(Pb + col * 20 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             });
+            // next pass's U-Net input block: pad channels zeroed here, x written by the fused store below
+            for (int u = tid; u < COLS17 * 4; u += NTHREADS)
+                *reinterpret_cast<float4*>(RG + PL::L0_in + (u >> 2) * 20 + (u & 3) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
             const float ca = srow[0], cb = srow[1], csg = srow[2];
             gfloat* bias = as_global(wb + lw.bias);
             const float slope10 = lw.slope;
-            mix_stage<16, 17, T, NB>(Pb, 20, wb + lw.tq, wb + lw.am, wave, lane,
+            if constexpr (!PF) mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
+            mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      [](int, int, int, int) { return 0.f; },
                                      [&](int n, int t, int v, int c, float val) {
                 if (c < C0) {
@@ -798,13 +943,19 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                       EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
                     if (P.mode == 1) {
                         if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
-                    } else if (t >= tf) {
-                        const float z = sidx > 1 ? ZN[col * C0 + c] : 0.f;
-                        XT[col * 4 + c] = ca * (x - cb * eps) + csg * z;
+                    } else {
+                        float xn = x;
+                        if (t >= tf) {
+                            const float z = sidx > 1 ? ZN[col * C0 + c] : 0.f;
+                            xn = ca * (x - cb * eps) + csg * z;
+                            XT[col * 4 + c] = xn;
+                        }
+                        RG[PL::L0_in + col * 20 + c] = xn;
                     }
                 }
             });
             __syncthreads();
+            if (fetch) *reinterpret_cast<float4*>(EMB + tid * 4) = erow;
             STAGE(17);
         }
     }
@@ -838,6 +989,34 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
         const int chain = chain0 + wave;
         if (lane == 0 && chain < P.n_chains) P.loss_out[chain] = sum / (float)per;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-step layer embeddings for a whole trajectory: out[(w,) k][o] = b_e[o] + sum_j W_e[o][j] SiLU(pe(k+1) + cond_w)[j]
+// (the Linear(SiLU(.)) of every ST-GCN layer, stsgcn.py:184-186, stsae_unet.py:173-179).  They do not depend on x_t,
+// so the persistent kernel only copies NB rows per pass.  grid = (windows or 1, steps).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emb_table_kernel(const float* __restrict__ wbuf, const float* __restrict__ step_table,
+                                                        const float* __restrict__ cond_emb, float* __restrict__ out, int K) {
+    __shared__ float se[EDIM];
+    const int b = blockIdx.x, k = blockIdx.y;
+    if (threadIdx.x < EDIM) {
+        float e = step_table[(k + 1) * (4 + EDIM) + 4 + threadIdx.x];
+        if (cond_emb) e += cond_emb[b * EDIM + threadIdx.x];
+        se[threadIdx.x] = e / (1.f + expf(-e));
+    }
+    __syncthreads();
+    const float* we = wbuf + tab_i(wbuf, TAB_WE);
+    const float* be = wbuf + tab_i(wbuf, TAB_BE);
+    for (int o = threadIdx.x; o < EMB_STRIDE; o += blockDim.x) {
+        float acc = 0.f;
+        if (o < EMB_TOTAL) {
+            acc = be[o];
+#pragma unroll
+            for (int j = 0; j < EDIM; ++j) acc = fmaf(we[o * EDIM + j], se[j], acc);
+        }
+        out[((size_t)b * K + k) * EMB_STRIDE + o] = acc;
     }
 }
 
@@ -1210,6 +1389,12 @@ int launch_score_t(const ScoreParams& P, hipStream_t st) {
 
 int launch_score(int T, const ScoreParams& P, hipStream_t st) {
     static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
+#ifdef MCD_FAST_T6      // developer builds: one instantiation
+    return launch_score_t<6, 1, 4>(P, st);
+#elif defined(MCD_FAST_BUILD)   // developer builds: only the two default-shape instantiations
+    if (T == 3) return variant == 2 ? launch_score_t<3, 2, 2>(P, st) : launch_score_t<3, 2, 4>(P, st);
+    return fail(MCD_EUNSUPPORTED, "fast build");
+#else
     switch (T) {
         case 3:
             if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st);   // 4 chains / WG, 1 WG per CU
@@ -1222,6 +1407,7 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
         case 12: return launch_score_t<12, 1, 2>(P, st);
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
     }
+#endif
 }
 
 }  // namespace
@@ -1480,10 +1666,19 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     return launch_score(w->cfg.t_unet, P, (hipStream_t)stream);
 }
 
+static int64_t ws_cond_bytes(const mcd_weights* w, int64_t B) {
+    const int64_t raw = B * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
+    return (raw + 255) / 256 * 256;
+}
+static int64_t ws_tab_floats(const mcd_weights* w, int64_t B, int ns) {
+    const int64_t K = ns > 1 ? ns - 1 : 1;
+    return (w->cfg.strategy == MCD_STRATEGY_INJECT ? B : 1) * K * EMB_STRIDE;
+}
+
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg) {
     if (!w || !cfg) return 0;
-    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V)
-    return (int64_t)cfg->n_windows * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
+    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V) + per-step layer-embedding tables
+    return ws_cond_bytes(w, cfg->n_windows) + ws_tab_floats(w, cfg->n_windows, cfg->noise_steps) * 4;
 }
 
 __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out, int B, int C, int T, int V, int n,
@@ -1492,6 +1687,22 @@ __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out,
     if (u >= B * C * n * V) return;
     const int v = u % V, k = (u / V) % n, c = (u / (V * n)) % C, b = u / (V * n * C);
     out[u] = load_coord(dv, b, c, fi.idx[k], v, T);
+}
+
+// embedding tables for the whole trajectory (workspace tail), then the persistent kernel.  Without a workspace
+// (allowed for the strategies that have no condition encoder) the embeddings are computed in-kernel.
+static int launch_tab_and_score(const mcd_weights* w, const mcd_score_cfg_t* cfg, ScoreParams& P, void* workspace, hipStream_t st) {
+    if (workspace) {
+        const int K = cfg->noise_steps - 1;
+        const bool per_window = w->cfg.strategy == MCD_STRATEGY_INJECT;
+        float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_cond_bytes(w, cfg->n_windows));
+        hipLaunchKernelGGL(emb_table_kernel, dim3(per_window ? cfg->n_windows : 1, K), dim3(256), 0, st, w->dbuf, P.step_table,
+                           per_window ? P.cond_emb : nullptr, tab, K);
+        HIP_TRY(hipGetLastError());
+        P.emb_tab = tab;
+        P.emb_wstride = per_window ? (long long)K * EMB_STRIDE : 0;
+    }
+    return launch_score(w->cfg.t_unet, P, st);
 }
 
 int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise, uint64_t seed,
@@ -1541,7 +1752,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
             int rc = launch_cond_fast(w, P.dv, fi, cfg->seg_len, emb, B, st);
             if (rc != MCD_OK) return rc;
             P.cond_emb = emb;
-            return launch_score(Tu, P, st);
+            return launch_tab_and_score(w, cfg, P, workspace, st);
         }
         const int total = B * C0 * Tc * 17;
         FrameIdx fi;
@@ -1553,7 +1764,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (rc != MCD_OK) return rc;
         P.cond_emb = emb;
     }
-    return launch_score(Tu, P, st);
+    return launch_tab_and_score(w, cfg, P, workspace, st);
 }
 
 int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,
