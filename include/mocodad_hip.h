@@ -34,7 +34,8 @@ enum {
 };
 
 /* conditioning strategy of models/mocodad.py:24-29,100-126 (canonical names) */
-enum { MCD_STRATEGY_INJECT = 0, MCD_STRATEGY_CONCAT = 1, MCD_STRATEGY_NO_CONDITION = 2 };
+enum { MCD_STRATEGY_INJECT = 0, MCD_STRATEGY_CONCAT = 1, MCD_STRATEGY_NO_CONDITION = 2,
+       MCD_STRATEGY_INBETWEEN_IMP = 3 /* condition frames stay at their own positions among the U-Net frames */ };
 /* loss_fn of models/mocodad.py:24,66 (reduction='none', mean over C*Tx*V at :484) */
 enum { MCD_LOSS_SMOOTH_L1 = 0, MCD_LOSS_L1 = 1, MCD_LOSS_MSE = 2 };
 /* aggregation strategy of models/mocodad.py:454-520 */
@@ -58,7 +59,7 @@ typedef struct {
 typedef struct {
     int32_t num_coords;   /* C: 2 */
     int32_t n_joints;     /* V: 17 (the U-Net hard-wires 17/12/10, stsae_unet.py:11) */
-    int32_t t_unet;       /* frames the U-Net runs on: n_frames_corrupt (inject) or seg_len (concat/no_condition) */
+    int32_t t_unet;       /* frames the U-Net runs on: n_frames_corrupt (inject) or seg_len (the other strategies) */
     int32_t t_cond;       /* condition frames seen by the condition encoder (0 when there is none) */
     int32_t emb_dim;      /* embedding_dim == latent_dim: 16 */
     int32_t strategy;     /* MCD_STRATEGY_* */

@@ -158,8 +158,12 @@ struct ScoreParams {
     float* eps_out;           // single-pass mode
     unsigned long long seed;
     long long first_window;
-    int B, S, ns, seg_len, n_corrupt, t_fixed, loss_fn, mode, step_single, n_chains;
-    int src_frame[12];        // data frame feeding U-Net frame t
+    int B, S, ns, seg_len, n_corrupt, loss_fn, mode, step_single, n_chains;
+    int fixed_mask;           // bit t: U-Net frame t is a condition frame copied from the window (concat / imputation)
+    int src_frame[12];        // data frame feeding U-Net frame t (condition frame, or ground truth of a denoised one)
+    int tx_of[12];            // denoised U-Net frame t -> its index among the corrupt frames
+    int pos_of[12];           // corrupt frame k -> its U-Net frame
+    int upd_of[12];           // U-Net frame t -> corrupt frame whose eps-prediction is read at t (-1: none)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chain0 = blockIdx.x * NB;
     const int Tx = P.n_corrupt;
-    const int tf = P.t_fixed;
+    const int fixed = P.fixed_mask;
     const int CTV = C0 * Tx * 17;          // elements of one generated pose
     const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
 
@@ -667,10 +671,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         for (int c = 0; c < C0; ++c) {
             if (P.mode == 1) {
                 xv[c] = P.x_in[((b * C0 + c) * T + t) * 17 + v];
-            } else if (t < tf) {
+            } else if ((fixed >> t) & 1) {
                 xv[c] = load_coord(P.dv, b, c, P.src_frame[t], v, P.seg_len);
             } else {
-                const int e = (c * Tx + (t - tf)) * 17 + v;
+                const int e = (c * Tx + P.tx_of[t]) * 17 + v;
                 if (P.noise) xv[c] = P.noise[((size_t)(s * K + 0) * P.B + b) * CTV + e];
                 else xv[c] = philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
             }
@@ -745,11 +749,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 const int c = u % C0, col = u / C0;
                 const int n = col / TV17, t = (col / 17) % T, v = col % 17;
                 float z = 0.f;
-                if (t >= tf) {
+                if (!((fixed >> t) & 1)) {
                     int chain = chain0 + n;
                     if (chain >= P.n_chains) chain = P.n_chains - 1;
                     const int b = chain / P.S, s = chain % P.S;
-                    const int e = (c * Tx + (t - tf)) * 17 + v;
+                    const int e = (c * Tx + P.tx_of[t]) * 17 + v;
                     const int k = P.ns - sidx;
                     if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
                     else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
@@ -944,13 +948,19 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     if (P.mode == 1) {
                         if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
                     } else {
-                        float xn = x;
-                        if (t >= tf) {
-                            const float z = sidx > 1 ? ZN[col * C0 + c] : 0.f;
-                            xn = ca * (x - cb * eps) + csg * z;
-                            XT[col * 4 + c] = xn;
+                        if ((fixed >> t) & 1) RG[PL::L0_in + col * 20 + c] = x;
+                        // the prediction at frame t drives corrupt frame k = upd_of[t], which lives at frame pos_of[k]
+                        // (the same frame except for 'concat' with the condition at the END of the window, where the
+                        // reference reads the prediction at the corrupt frames' ORIGINAL indices, mocodad.py:829-838)
+                        const int k = P.upd_of[t];
+                        if (k >= 0) {
+                            const int colp = (n * T + P.pos_of[k]) * 17 + v;
+                            const float xo = XT[colp * 4 + c];
+                            const float z = sidx > 1 ? ZN[colp * C0 + c] : 0.f;
+                            const float xn = ca * (xo - cb * eps) + csg * z;
+                            XT[colp * 4 + c] = xn;
+                            RG[PL::L0_in + colp * 20 + c] = xn;
                         }
-                        RG[PL::L0_in + col * 20 + c] = xn;
                     }
                 }
             });
@@ -971,8 +981,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         const bool valid = chain < P.n_chains;
         if (!valid) chain = P.n_chains - 1;
         const int b = chain / P.S, s = chain % P.S;
-        const float x0 = XT[((n * T + tf + tx) * 17 + v) * 4 + c];
-        const float gt = load_coord(P.dv, b, c, P.src_frame[tf + tx], v, P.seg_len);
+        const int tu = P.pos_of[tx];
+        const float x0 = XT[((n * T + tu) * 17 + v) * 4 + c];
+        const float gt = load_coord(P.dv, b, c, P.src_frame[tu], v, P.seg_len);
         const float d = fabsf(x0 - gt);
         float l;
         if (P.loss_fn == MCD_LOSS_SMOOTH_L1) l = d < 1.f ? 0.5f * d * d : d - 0.5f;
@@ -1661,7 +1672,7 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     ScoreParams P;
     memset(&P, 0, sizeof(P));
     P.wbuf = w->dbuf; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
-    P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.t_fixed = 0;
+    P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.fixed_mask = 0;
     P.mode = 1; P.step_single = t; P.n_chains = n_windows;
     return launch_score(w->cfg.t_unet, P, (hipStream_t)stream);
 }
@@ -1723,8 +1734,10 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         return fail(MCD_EINVAL, "cond/corrupt index lists do not partition seg_len");
     const int strat = w->cfg.strategy;
     const int Tu = w->cfg.t_unet;
-    const int tf = strat == MCD_STRATEGY_CONCAT ? cfg->n_cond : 0;
+    const bool keeps_cond = strat == MCD_STRATEGY_CONCAT || strat == MCD_STRATEGY_INBETWEEN_IMP;   // condition frames are U-Net input
+    const int tf = keeps_cond ? cfg->n_cond : 0;
     if (tf + cfg->n_corrupt != Tu) return fail(MCD_EINVAL, "frame split does not match the packed U-Net (t_unet)");
+    if (Tu > 12) return fail(MCD_EUNSUPPORTED, "more than 12 U-Net frames");
     if (strat == MCD_STRATEGY_INJECT && cfg->n_cond != w->cfg.t_cond) return fail(MCD_EINVAL, "n_cond does not match the packed condition encoder");
     hipStream_t st = (hipStream_t)stream;
     ScoreParams P;
@@ -1737,10 +1750,29 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (!view->base) { P.dv.sc = (long long)cfg->seg_len * 17; P.dv.st = 17; }
     } P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
     P.seed = seed; P.first_window = first_window_id;
-    P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt; P.t_fixed = tf;
+    P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt;
     P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
-    for (int t = 0; t < tf; ++t) P.src_frame[t] = cfg->cond_idx[t];
-    for (int t = 0; t < cfg->n_corrupt; ++t) P.src_frame[tf + t] = cfg->corrupt_idx[t];
+    // U-Net frame layout: concat = condition frames first (mocodad.py:668), imputation = natural frame order
+    // (mocodad.py:672-683), inject / no_condition = the corrupt frames only
+    for (int k = 0; k < tf; ++k) {
+        const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->cond_idx[k] : k;
+        if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad cond_idx");
+        P.fixed_mask |= 1 << t;
+        P.src_frame[t] = cfg->cond_idx[k];
+    }
+    for (int k = 0; k < cfg->n_corrupt; ++k) {
+        const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->corrupt_idx[k] : tf + k;
+        if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad corrupt_idx");
+        P.src_frame[t] = cfg->corrupt_idx[k];
+        P.tx_of[t] = k;
+        P.pos_of[k] = t;
+    }
+    for (int t = 0; t < 12; ++t) P.upd_of[t] = -1;
+    for (int k = 0; k < cfg->n_corrupt; ++k) {
+        const int t = keeps_cond ? cfg->corrupt_idx[k] : k;     // mocodad.py:829-838: mask built from corrupt_idxs
+        if (t < 0 || t >= Tu || P.upd_of[t] >= 0) return fail(MCD_EINVAL, "bad corrupt_idx");
+        P.upd_of[t] = k;
+    }
     if (strat == MCD_STRATEGY_INJECT) {
         if (!workspace) return fail(MCD_EINVAL, "workspace required for the inject strategy");
         float* emb = reinterpret_cast<float*>(workspace);

@@ -27,7 +27,7 @@ class HipScorer:
     """One packed model on one GPU.
 
     state_dict: the reference's Lightning-checkpoint keys ('model.*', 'condition_encoder.*') -> tensors.
-    strategy: canonical conditioning strategy ('inject' | 'concat' | 'no_condition').
+    strategy: canonical conditioning strategy ('inject' | 'concat' | 'no_condition' | 'inbetween_imp').
     """
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, strategy: str, seg_len: int, cond_idx: Sequence[int],
@@ -43,7 +43,7 @@ class HipScorer:
         self.corrupt_idx = [int(i) for i in corrupt_idx]
         self.num_coords, self.n_joints, self.emb_dim = num_coords, n_joints, emb_dim
         self.t_cond = len(self.cond_idx) if strategy == "inject" else 0
-        self.t_unet = len(self.corrupt_idx) + (len(self.cond_idx) if strategy == "concat" else 0)
+        self.t_unet = len(self.corrupt_idx) + (len(self.cond_idx) if strategy in ("concat", "inbetween_imp") else 0)
         self._tables: Dict[int, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
 

@@ -8,9 +8,10 @@ reverse-diffusion scoring loop in the hand-written HIP kernels behind the C ABI 
 Reference: /root/reference/models/mocodad.py (forward :129-184, _aggregation_strategy :454-520,
 _set_conditioning_strategy :753-796, _select_frames :708-750, post_processing :337-430).
 
-Scope: inference scoring with the 'inject', 'concat' and 'no_condition' strategies and the
-'AE' / 'E' condition encoders.  Training (training_step / configure_optimizers), the imputation strategies and
-the 'E_unet' condition encoder are outside the accelerated path and raise NotImplementedError.
+Scope: inference scoring with the 'inject', 'concat', 'no_condition' strategies, the
+'AE' / 'E' condition encoders and the 'inbetween_imp' imputation strategy.  Training (training_step /
+configure_optimizers), 'random_imp' and the 'E_unet' condition encoder are outside the accelerated path and raise
+NotImplementedError.
 """
 import argparse
 import os
@@ -180,8 +181,8 @@ class MoCoDAD(_Base):
 
     # -------------------------------------------------------------- construction
     def build_model(self) -> None:
-        if self.conditioning_strategy in ("random_imp", "inbetween_imp"):
-            raise NotImplementedError(f"conditioning strategy '{self.conditioning_strategy}' is not part of the accelerated path")
+        if self.conditioning_strategy == "random_imp":   # per-window random frame permutations drawn from torch's RNG
+            raise NotImplementedError("conditioning strategy 'random_imp' is not part of the accelerated path")
         if self.num_coords != 2 or self.n_joints != 17:
             raise NotImplementedError("the HIP path (like the reference U-Net) supports num_coords=2 and 17 joints")
         enc = None
@@ -223,6 +224,9 @@ class MoCoDAD(_Base):
         if self.conditioning_strategy == "no_condition":
             return [], list(range(T))
         if isinstance(ci, int):
+            if self.conditioning_strategy == "inbetween_imp":
+                cond = list(range(0, T, ci))
+                return cond, [i for i in range(T) if i not in cond]
             n = T // ci
             return list(range(n)), list(range(n, T))
         return list(ci), [i for i in range(T) if i not in ci]

@@ -140,16 +140,26 @@ def state_to_np(model):
     return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
 
 
-def extra(MoCoDAD):
+EXTRA_CASES = {
+    # name: (overrides, ns, S, B)
+    "nocond": (dict(conditioning_strategy="no_condition"), 4, 2, 4),
+    "encE": (dict(conditioning_architecture="E", channels=[24, 40], h_dim=8), 4, 2, 4),
+    "l1": (dict(loss_fn="l1"), 4, 2, 4),
+    "mse": (dict(loss_fn="mse"), 4, 2, 4),
+}
+# `--extra3`: in-between imputation (mocodad.py:672-683,726-731,829-838): every 2nd frame conditions / an explicit list
+EXTRA3_CASES = {
+    "imp2": (dict(conditioning_strategy="inbetween_imp", conditioning_indices=2), 4, 2, 4),
+    "implist": (dict(conditioning_strategy="inbetween_imp", conditioning_indices=[1, 4]), 4, 2, 4),
+    # concat with the condition at the END: the reference reads the prediction at frames [0,1,2] of [cond, x]
+    "cattail": (dict(conditioning_strategy="concat", conditioning_indices=[3, 4, 5]), 4, 2, 4),
+}
+
+
+def extra(MoCoDAD, cases=None):
     """Second batch of vectors (added later; `python tests/golden/gen_golden.py --extra` regenerates only these):
     no_condition strategy, 'E' condition encoder with a non-default channel list, l1 / mse losses."""
-    cases = {
-        # name: (overrides, ns, S, B)
-        "nocond": (dict(conditioning_strategy="no_condition"), 4, 2, 4),
-        "encE": (dict(conditioning_architecture="E", channels=[24, 40], h_dim=8), 4, 2, 4),
-        "l1": (dict(loss_fn="l1"), 4, 2, 4),
-        "mse": (dict(loss_fn="mse"), 4, 2, 4),
-    }
+    cases = EXTRA_CASES if cases is None else cases
     for name, (over, ns, S, B) in cases.items():
         gen = torch.Generator().manual_seed(4321 + len(name))
         args, cfg = make_args(noise_steps=ns, n_gen=S, aggr="all", ret="all")
@@ -210,6 +220,9 @@ def main():
         return
     if "--extra2" in sys.argv:
         extra2()
+        return
+    if "--extra3" in sys.argv:
+        extra(MoCoDAD, EXTRA3_CASES)
         return
 
     # ---------------------------------------------------------------- 5. schedules

@@ -122,10 +122,11 @@ def test_full_size_properties():
     assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
 
 
-@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse"])
+@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse", "imp2", "implist", "cattail"])
 def test_extra_variants_vs_reference(name):
     """no_condition strategy (U-Net on all 6 frames), 'E' encoder with channels [24,40]+8 (generic condition-encoder
-    kernel), l1 / mse losses — against vectors generated by the reference."""
+    kernel), l1 / mse losses, in-between imputation (every 2nd frame / an explicit list conditions), concat with the
+    condition at the end of the window — against vectors generated by the reference."""
     g = load_golden(f"traj_{name}_ns4_S2.npz")
     m, _, cfg = _model(name)
     batch = [torch.from_numpy(g["data"]), torch.zeros(4), torch.zeros(4, 4), torch.zeros(4, 6)]
