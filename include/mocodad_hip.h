@@ -46,6 +46,9 @@ enum {
 
 #define MCD_MAX_FRAMES 32
 #define MCD_MAX_COND_LAYERS 8
+/* cond_layers value selecting the 'E_unet' condition encoder (STSE_Unet: the U-Net's down path + to_time_dim,
+ * models/mocodad.py:110-114, stsae_unet.py:8-251); cond_channels is ignored */
+#define MCD_COND_UNET (-1)
 
 /* One named fp32 tensor of the Lightning checkpoint's state_dict (HOST memory).  Names are the
  * reference's own keys: "model.st_gcnnsd1.0.tcn.0.weight", "condition_encoder.btlnk.bias", ... */
@@ -63,7 +66,7 @@ typedef struct {
     int32_t t_cond;       /* condition frames seen by the condition encoder (0 when there is none) */
     int32_t emb_dim;      /* embedding_dim == latent_dim: 16 */
     int32_t strategy;     /* MCD_STRATEGY_* */
-    int32_t cond_layers;  /* ST-GCN layers of the condition encoder: len(channels)+1 */
+    int32_t cond_layers;  /* ST-GCN layers of the condition encoder: len(channels)+1, or MCD_COND_UNET */
     int32_t cond_channels[MCD_MAX_COND_LAYERS]; /* their output channels: channels + [h_dim] */
 } mcd_model_cfg_t;
 

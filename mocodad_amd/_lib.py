@@ -11,6 +11,7 @@ MCD_MAX_COND_LAYERS = 8
 
 STRATEGY = {"inject": 0, "concat": 1, "no_condition": 2, "inbetween_imp": 3}
 LOSS = {"smooth_l1": 0, "l1": 1, "mse": 2}
+COND_UNET = -1  # MCD_COND_UNET
 AGGR = {"all": 0, "best": 1, "worst": 2, "mean": 3, "median": 4, "mean_pose": 5, "median_pose": 6, "quantile": 7}
 
 

@@ -430,11 +430,11 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
                 if (CAPTURE) row = ks < 4 ? 4 * g + ks : 16 + g;
                 else row = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 4 * KP + g;
                 const float x = xin[row * cs_in];
-                if (CAPTURE) skip[i * SK + ks] = x;
+                if constexpr (CAPTURE) skip[i * SK + ks] = x;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
             });
-            if (ADD) {
+            if constexpr (ADD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
                 if constexpr (SK == 5) acc[MT - 1][0] += skip[i * SK + 4];     // joint 16 lives in lane group g = 0, row 0 of m-tile 1
@@ -1096,6 +1096,89 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
 }
 
 // ------------------------------------------------------------------------------------------------
+// condition encoder 'E_unet' (STSE_Unet with set_out_layer, stsae_unet.py:62-146,182-251): the U-Net's down path
+// 2->16->32->32 | 17->12 | 32->64->64 | 12->10 | 64->128->6 without embeddings (t = None), then
+// Linear(6*T*10 -> latent) over the (c,t,v) flattening.  Same MFMA stages and LDS plan as the scoring kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int TABC_URS = 56;               // down1 / down2 fragments + bias: 4 words
+constexpr int TABC_ULW = 60, TABC_ULB = 61;  // to_time_dim weight [16][6*T*10] / bias
+constexpr int CU_OUT = 6;                  // unet_down_channels[6] of STSE_Unet
+
+template <int T, int NB>
+struct CondUnetLds {     // the scoring kernel's work region, with the [P10][20] output of the last layer behind 2 x s128
+    using PL = Plan<T, NB>;
+    static constexpr int H_OFF = 2 * PL::s128;
+    static constexpr int FLOATS = cmax(PL::R, H_OFF + PL::P10 * 20);
+};
+
+template <int T, int NB>
+__global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbuf, const DataView dv, const FrameIdx fi,
+                                                                int seg_len, float* __restrict__ emb_out, int B) {
+    using PL = Plan<T, NB>;
+    constexpr int TV17 = T * 17, COLS17 = NB * TV17, TV10 = T * 10;
+    constexpr int H_OFF = CondUnetLds<T, NB>::H_OFF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const RG = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * NB;
+    Prof prof;
+#ifdef MCD_PROFILE
+    prof.on = false; prof.p = nullptr; prof.tlast = 0;
+#endif
+    for (int u = tid; u < CondUnetLds<T, NB>::FLOATS; u += NTHREADS) smem[u] = 0.f;
+    __syncthreads();
+    for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
+        const int c = u % C0, col = u / C0;
+        const int n = col / TV17, t = (col / 17) % T, v = col % 17;
+        const int b = b0 + n < B ? b0 + n : B - 1;
+        RG[PL::L0_in + col * 20 + c] = load_coord(dv, b, c, fi.idx[t], v, seg_len);
+    }
+    __syncthreads();
+    const float* wb = wbuf;
+    auto lw = [&](int l) {
+        LayerW w;
+        w.tq = tab_i(wb, TABC + l * F_STRIDE + F_TQ); w.am = tab_i(wb, TABC + l * F_STRIDE + F_AM);
+        w.wp = tab_i(wb, TABC + l * F_STRIDE + F_WP); w.bias = tab_i(wb, TABC + l * F_STRIDE + F_BIAS);
+        w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
+        return w;
+    };
+    float nosk[1] = {0.f};
+    layer_generic<16, 16, 17, true, false, T, NB>(wb, lw(0), RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, nullptr, wave, lane, prof, 0);
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(1), RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, nullptr, wave, lane, prof, 0);
+    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(2), RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, nullptr, wave, lane, prof, 0);
+    {
+        RsCoef<32, 17, 12, T, NB, false> rc;
+        rc.load(wb + tab_i(wb, TABC + TABC_URS + 0), wb + tab_i(wb, TABC + TABC_URS + 1), lane);
+        resample_stage<32, 17, 12, T, NB, false, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc, nosk, wave, lane);
+        __syncthreads();
+    }
+    layer_generic<32, 64, 12, true, false, T, NB>(wb, lw(3), RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, nullptr, wave, lane, prof, 0);
+    layer_generic<64, 64, 12, false, false, T, NB>(wb, lw(4), RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, nullptr, wave, lane, prof, 0);
+    {
+        RsCoef<64, 12, 10, T, NB, false> rc;
+        rc.load(wb + tab_i(wb, TABC + TABC_URS + 2), wb + tab_i(wb, TABC + TABC_URS + 3), lane);
+        resample_stage<64, 12, 10, T, NB, false, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc, nosk, wave, lane);
+        __syncthreads();
+    }
+    layer_generic<64, 128, 10, true, false, T, NB>(wb, lw(5), RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, nullptr, wave, lane, prof, 0);
+    layer_generic<128, 16, 10, true, false, T, NB>(wb, lw(6), RG + PL::L6_in, RG + PL::L6_p, RG + H_OFF, nullptr, wave, lane, prof, 0);
+    // to_time_dim: emb[n][j] = b[j] + sum_k W[j][k] H[n][k], k = c*T*10 + t*10 + v.  thread = (n, j, part of 16)
+    constexpr int F = CU_OUT * TV10;
+    const float* H = RG + H_OFF;
+    gfloat* W = as_global(wb + tab_i(wb, TABC + TABC_ULW));
+    gfloat* bb = as_global(wb + tab_i(wb, TABC + TABC_ULB));
+    for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
+        const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
+        float a = 0.f;
+        for (int k = part; k < F; k += 16) a = fmaf(W[jo * F + k], H[(n * TV10 + k % TV10) * 20 + k / TV10], a);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+        if (part == 0 && b0 + n < B) emb_out[(size_t)(b0 + n) * EDIM + jo] = a + bb[jo];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // condition encoder (runtime channel list; 0.3 % of the work): one workgroup per window, VALU only.
 // ------------------------------------------------------------------------------------------------
 struct CondW {
@@ -1377,6 +1460,7 @@ struct mcd_weights {
     CondW cond;
     bool has_cond;
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
+    bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
 };
 
 namespace {
@@ -1447,6 +1531,33 @@ int launch_cond_fast(const mcd_weights* w, const DataView& data, const FrameIdx&
         case 12: return launch_cond_fast_t<12, 1>(w, data, fi, seg_len, emb, B, st);
         default: return fail(MCD_EUNSUPPORTED, "cond_fast: frame count not instantiated");
     }
+}
+template <int T, int NB>
+int launch_cond_unet_t(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+    constexpr size_t lds = (size_t)CondUnetLds<T, NB>::FLOATS * 4;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_unet_kernel<T, NB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((cond_unet_kernel<T, NB>), dim3((B + NB - 1) / NB), dim3(NTHREADS), lds, st, w->dbuf, data, fi, seg_len, emb, B);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+    switch (w->cond.Tc) {
+        case 3: return launch_cond_unet_t<3, 2>(w, data, fi, seg_len, emb, B, st);
+        case 6: return launch_cond_unet_t<6, 1>(w, data, fi, seg_len, emb, B, st);
+        case 12: return launch_cond_unet_t<12, 1>(w, data, fi, seg_len, emb, B, st);
+        default: return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated (supported: 3, 6, 12)");
+    }
+}
+// the MFMA condition encoders read the condition frames straight from the window view
+int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
+    return w->cond_unet ? launch_cond_unet(w, data, fi, seg_len, emb, B, st) : launch_cond_fast(w, data, fi, seg_len, emb, B, st);
 }
 }  // namespace
 
@@ -1543,7 +1654,58 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     bool cond_fast = false;
     int ctab[4][F_STRIDE] = {{0}};
     const bool has_cond = cfg->strategy == MCD_STRATEGY_INJECT;
-    if (has_cond) {
+    const bool cond_unet = has_cond && cfg->cond_layers == MCD_COND_UNET;
+    int utab[TABC_ULB + 1] = {0};   // cond table of the 'E_unet' encoder: 7 layers, 2 resamplers, Linear
+    if (cond_unet) {
+        const int Tc = cfg->t_cond;
+        if (Tc != 3 && Tc != 6 && Tc != 12) return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated (supported: 3, 6, 12)");
+        Cw.Tc = Tc; Cw.latent = EDIM;
+        static const char* unames[7] = {"st_gcnnsp1a.0", "st_gcnnsd1.0", "st_gcnnsd1.1", "st_gcnnsd2.0", "st_gcnnsd2.1", "st_gcnnsd3.0", "st_gcnnsd3.1"};
+        static const int ucin[7] = {C0, 16, 32, 32, 64, 64, 128}, ucout[7] = {16, 32, 32, 64, 64, 128, CU_OUT}, uv[7] = {17, 17, 17, 12, 12, 10, 10};
+        for (int l = 0; l < 7; ++l) {
+            const int cinr = ucin[l], cout = ucout[l], cinp = cinr < 16 ? 16 : cinr;
+            const std::string p = std::string("condition_encoder.") + unames[l];
+            Folded ft, fr;
+            const bool res = cinr != cout;
+            if (!fold_conv_bn(tm, p + ".tcn.0", p + ".tcn.1", cout, cinr, ft)) return fail(MCD_EMISSING, tm.missing);
+            if (res && !fold_conv_bn(tm, p + ".residual.0", p + ".residual.1", cout, cinr, fr)) return fail(MCD_EMISSING, tm.missing);
+            const float* sl = tm.get(p + ".prelu.weight", 1);
+            if (!sl) return fail(MCD_EMISSING, tm.missing);
+            int tq = 0, am = 0;
+            if (!pack_mix_mfma(tm, p, Tc, uv[l], B, tq, am)) return fail(MCD_EMISSING, tm.missing);
+            const int wp = pack_gemm_frags(B, ceil16(cout), cinp * (res ? 2 : 1), [&](int r, int k) -> double {
+                const bool second = k >= cinp;
+                const int kk = second ? k - cinp : k;
+                if (r >= cout || kk >= cinr) return 0.0;
+                return second ? fr.w[(size_t)r * cinr + kk] : ft.w[(size_t)r * cinr + kk];
+            });
+            const int bias = B.alloc(ceil16(cout));
+            for (int o = 0; o < cout; ++o) B.buf[bias + o] = (float)(ft.b[o] + (res ? fr.b[o] : 0.0));
+            utab[l * F_STRIDE + F_TQ] = tq; utab[l * F_STRIDE + F_AM] = am; utab[l * F_STRIDE + F_WP] = wp; utab[l * F_STRIDE + F_BIAS] = bias;
+            memcpy(&utab[l * F_STRIDE + F_SLOPE], &sl[0], sizeof(float));
+        }
+        static const char* urs[2] = {"down1", "down2"};
+        static const int urin[2] = {17, 12}, urout[2] = {12, 10};
+        for (int r = 0; r < 2; ++r) {
+            Folded f;
+            const std::string p = std::string("condition_encoder.") + urs[r];
+            if (!fold_conv_bn(tm, p + ".block.0", p + ".block.1", urout[r], urin[r], f)) return fail(MCD_EMISSING, tm.missing);
+            const int vin = urin[r], vout = urout[r], KS = (vin + 3) / 4, MTr = (vout + 15) / 16;
+            const int wf = B.alloc((size_t)MTr * KS * 64), bo = B.alloc(32);
+            for (int mt = 0; mt < MTr; ++mt) for (int ks = 0; ks < KS; ++ks) for (int lane = 0; lane < 64; ++lane) {
+                const int vo = mt * 16 + (lane & 15), v = rs_vmap(false, vin, ks, lane >> 4);
+                B.buf[wf + (mt * KS + ks) * 64 + lane] = (vo < vout && v < vin) ? (float)f.w[(size_t)vo * vin + v] : 0.f;
+            }
+            for (int vo = 0; vo < vout; ++vo) B.buf[bo + vo] = (float)f.b[vo];
+            utab[TABC_URS + 2 * r] = wf; utab[TABC_URS + 2 * r + 1] = bo;
+        }
+        const int64_t F = (int64_t)CU_OUT * Tc * 10;
+        const float* lw = tm.get("condition_encoder.to_time_dim.weight", F * EDIM);
+        const float* lb = tm.get("condition_encoder.to_time_dim.bias", EDIM);
+        if (!lw || !lb) return fail(MCD_EMISSING, tm.missing);
+        utab[TABC_ULW] = B.alloc(F * EDIM); memcpy(&B.buf[utab[TABC_ULW]], lw, sizeof(float) * F * EDIM);
+        utab[TABC_ULB] = B.alloc(EDIM); memcpy(&B.buf[utab[TABC_ULB]], lb, sizeof(float) * EDIM);
+    } else if (has_cond) {
         if (cfg->cond_layers < 1 || cfg->cond_layers > MCD_MAX_COND_LAYERS) return fail(MCD_EINVAL, "bad cond_layers");
         if (cfg->t_cond < 1 || cfg->t_cond > 12) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1..12");
         Cw.n_layers = cfg->cond_layers; Cw.Tc = cfg->t_cond; Cw.latent = EDIM; Cw.cmax = C0;
@@ -1613,6 +1775,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
         }
         tab[TAB_WE] = U.we; tab[TAB_BE] = U.be; tab[TAB_WEF] = wef;
+        if (cond_unet) for (int i = 0; i <= TABC_ULB; ++i) tab[TABC + i] = utab[i];
         if (cond_fast) {
             for (int l = 0; l < 4; ++l) for (int f = 0; f < F_STRIDE; ++f) tab[TABC + l * F_STRIDE + f] = ctab[l][f];
             tab[TABC + TABC_LW] = Cw.lw; tab[TABC + TABC_LB] = Cw.lb;
@@ -1621,7 +1784,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     }
     HIP_TRY(hipSetDevice(device));
     mcd_weights* w = new mcd_weights();
-    w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast;
+    w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast; w->cond_unet = cond_unet;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(w->dbuf, B.buf.data(), B.buf.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -1643,13 +1806,13 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
     if (!w->has_cond) return fail(MCD_EINVAL, "model has no condition encoder");
     if (n_windows <= 0) return MCD_OK;
     if (!cond_data || !emb_out) return fail(MCD_EINVAL, "null argument");
-    if (w->cond_fast && !getenv("MCD_COND_GENERIC")) {
+    if (w->cond_unet || (w->cond_fast && !getenv("MCD_COND_GENERIC"))) {
         FrameIdx fi;
         for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = k;
         DataView dv;
         memset(&dv, 0, sizeof(dv));
         dv.data = cond_data;
-        return launch_cond_fast(w, dv, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
+        return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
     }
     const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
     static bool attr_set[16] = {false};
@@ -1778,10 +1941,10 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         float* emb = reinterpret_cast<float*>(workspace);
         float* cbuf = emb + (size_t)B * EDIM + 16;
         const int Tc = cfg->n_cond;
-        if (w->cond_fast && !getenv("MCD_COND_GENERIC")) {
+        if (w->cond_unet || (w->cond_fast && !getenv("MCD_COND_GENERIC"))) {
             FrameIdx fi;
             for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
-            int rc = launch_cond_fast(w, P.dv, fi, cfg->seg_len, emb, B, st);
+            int rc = launch_cond_mfma(w, P.dv, fi, cfg->seg_len, emb, B, st);
             if (rc != MCD_OK) return rc;
             P.cond_emb = emb;
             return launch_tab_and_score(w, cfg, P, workspace, st);

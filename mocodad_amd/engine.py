@@ -28,11 +28,12 @@ class HipScorer:
 
     state_dict: the reference's Lightning-checkpoint keys ('model.*', 'condition_encoder.*') -> tensors.
     strategy: canonical conditioning strategy ('inject' | 'concat' | 'no_condition' | 'inbetween_imp').
+    cond_channels: output channels of the 'AE' / 'E' condition encoder's layers; cond_unet: 'E_unet' encoder instead.
     """
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, strategy: str, seg_len: int, cond_idx: Sequence[int],
-                 corrupt_idx: Sequence[int], cond_channels: Sequence[int] = (), num_coords: int = 2, n_joints: int = 17,
-                 emb_dim: int = 16, device=None):
+                 corrupt_idx: Sequence[int], cond_channels: Sequence[int] = (), cond_unet: bool = False,
+                 num_coords: int = 2, n_joints: int = 17, emb_dim: int = 16, device=None):
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("mocodad_amd needs an MI355X (gfx950) GPU: the scoring path has no CPU fallback")
@@ -50,9 +51,12 @@ class HipScorer:
         cfg = _lib.ModelCfg()
         cfg.num_coords, cfg.n_joints, cfg.t_unet, cfg.t_cond = num_coords, n_joints, self.t_unet, self.t_cond
         cfg.emb_dim, cfg.strategy = emb_dim, _lib.STRATEGY[strategy]
-        cfg.cond_layers = len(cond_channels) if strategy == "inject" else 0
-        for i, c in enumerate(cond_channels):
-            cfg.cond_channels[i] = int(c)
+        if strategy == "inject" and cond_unet:      # 'E_unet' condition encoder (the U-Net's down path)
+            cfg.cond_layers = _lib.COND_UNET
+        else:
+            cfg.cond_layers = len(cond_channels) if strategy == "inject" else 0
+            for i, c in enumerate(cond_channels):
+                cfg.cond_channels[i] = int(c)
         keep = []  # keep host copies alive during the call
         arr = (_lib.Tensor * len(state_dict))()
         n = 0

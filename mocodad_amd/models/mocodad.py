@@ -9,9 +9,8 @@ Reference: /root/reference/models/mocodad.py (forward :129-184, _aggregation_str
 _set_conditioning_strategy :753-796, _select_frames :708-750, post_processing :337-430).
 
 Scope: inference scoring with the 'inject', 'concat', 'no_condition' strategies, the
-'AE' / 'E' condition encoders and the 'inbetween_imp' imputation strategy.  Training (training_step /
-configure_optimizers), 'random_imp' and the 'E_unet' condition encoder are outside the accelerated path and raise
-NotImplementedError.
+'AE' / 'E' / 'E_unet' condition encoders and the 'inbetween_imp' imputation strategy.  Training (training_step /
+configure_optimizers) and 'random_imp' are outside the accelerated path and raise NotImplementedError.
 """
 import argparse
 import os
@@ -113,6 +112,23 @@ class UNetParams(nn.Module):
         self.up3 = JointResampleParams(10, 12, dropout)
 
 
+class CondUNetParams(nn.Module):
+    """Parameter tree of STSE_Unet used as the 'E_unet' condition encoder (stsae_unet.py:8-146; mocodad.py:110-114:
+    embedding_dim=None, set_out_layer=True): the U-Net's down path ending in 6 channels + to_time_dim."""
+    down_channels = [16, 32, 32, 64, 64, 128, 6]
+
+    def __init__(self, c_in: int, latent_dim: int, n_frames: int, dropout: float):
+        super().__init__()
+        d, T = self.down_channels, n_frames
+        self.st_gcnnsp1a = _stack([(c_in, d[0])], T, 17, dropout, None)
+        self.st_gcnnsd1 = _stack([(d[0], d[1]), (d[1], d[2])], T, 17, dropout, None)
+        self.st_gcnnsd2 = _stack([(d[2], d[3]), (d[3], d[4])], T, 12, dropout, None)
+        self.st_gcnnsd3 = _stack([(d[4], d[5]), (d[5], d[6])], T, 10, dropout, None)
+        self.down1 = JointResampleParams(17, 12, dropout)
+        self.down2 = JointResampleParams(12, 10, dropout)
+        self.to_time_dim = nn.Linear(d[6] * T * 10, latent_dim)
+
+
 class _LayerList(nn.Module):
     def __init__(self, chans, T, V, dropout):
         super().__init__()
@@ -188,10 +204,13 @@ class MoCoDAD(_Base):
         enc = None
         if self.conditioning_strategy == "inject":
             arch = self.conditioning_architecture
-            if arch not in ("AE", "E"):
+            if arch not in ("AE", "E", "E_unet"):
                 raise NotImplementedError(f"Conditioning architecture {arch} not implemented.")
-            enc = CondEncoderParams(self.num_coords, self.cond_h_dim, self.cond_latent_dim, self.n_frames_condition,
-                                    self.n_joints, self.cond_channels, self.cond_dropout, with_decoder=(arch == "AE"))
+            if arch == "E_unet":
+                enc = CondUNetParams(self.num_coords, self.cond_latent_dim, self.n_frames_condition, self.cond_dropout)
+            else:
+                enc = CondEncoderParams(self.num_coords, self.cond_h_dim, self.cond_latent_dim, self.n_frames_condition,
+                                        self.n_joints, self.cond_channels, self.cond_dropout, with_decoder=(arch == "AE"))
         self.condition_encoder = enc
         self.model = UNetParams(self.num_coords, self.embedding_dim, self.input_n_frames, self.dropout)
         self.eval()
@@ -264,10 +283,11 @@ class MoCoDAD(_Base):
         if self._scorer is None or self._scorer_key != key:
             from ..engine import HipScorer
             ci, xi = self._frame_split()
-            chans = list(self.condition_encoder.channels) if self.condition_encoder is not None else []
+            unet_enc = isinstance(self.condition_encoder, CondUNetParams)
+            chans = list(self.condition_encoder.channels) if self.condition_encoder is not None and not unet_enc else []
             self._scorer = HipScorer(self.state_dict(), strategy=self.conditioning_strategy, seg_len=self.n_frames,
-                                     cond_idx=ci, corrupt_idx=xi, cond_channels=chans, num_coords=self.num_coords,
-                                     n_joints=self.n_joints, emb_dim=self.embedding_dim, device=dev)
+                                     cond_idx=ci, corrupt_idx=xi, cond_channels=chans, cond_unet=unet_enc,
+                                     num_coords=self.num_coords, n_joints=self.n_joints, emb_dim=self.embedding_dim, device=dev)
             self._scorer_key = key
         return self._scorer
 

@@ -153,6 +153,8 @@ EXTRA3_CASES = {
     "implist": (dict(conditioning_strategy="inbetween_imp", conditioning_indices=[1, 4]), 4, 2, 4),
     # concat with the condition at the END: the reference reads the prediction at frames [0,1,2] of [cond, x]
     "cattail": (dict(conditioning_strategy="concat", conditioning_indices=[3, 4, 5]), 4, 2, 4),
+    # the U-Net's down path as condition encoder (mocodad.py:110-114)
+    "encU": (dict(conditioning_architecture="E_unet"), 4, 2, 4),
 }
 
 
