@@ -35,7 +35,9 @@ enum {
 
 /* conditioning strategy of models/mocodad.py:24-29,100-126 (canonical names) */
 enum { MCD_STRATEGY_INJECT = 0, MCD_STRATEGY_CONCAT = 1, MCD_STRATEGY_NO_CONDITION = 2,
-       MCD_STRATEGY_INBETWEEN_IMP = 3 /* condition frames stay at their own positions among the U-Net frames */ };
+       MCD_STRATEGY_INBETWEEN_IMP = 3, /* condition frames stay at their own positions among the U-Net frames */
+       MCD_STRATEGY_RANDOM_IMP = 4     /* same, with a different random set of n_cond condition frames per window
+                                          (mcd_window_view_t.cond_mask) */ };
 /* loss_fn of models/mocodad.py:24,66 (reduction='none', mean over C*Tx*V at :484) */
 enum { MCD_LOSS_SMOOTH_L1 = 0, MCD_LOSS_L1 = 1, MCD_LOSS_MSE = 2 };
 /* aggregation strategy of models/mocodad.py:454-520 */
@@ -124,13 +126,17 @@ int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* d
  * seg_len x num_transform copies (reference: sliding windows utils/preprocessing.py:14-86, transforms
  * utils/dataset_utils.py:255-310 applied per item in utils/dataset.py:67-76).
  * Element (b, c, t, v) of window b is data[base[b] + c*stride_c + t*stride_t + v], then, when trans != NULL,
- * [x', y'] = A[trans[b]] @ [x, y, 1] with A = affine + 6*trans[b] = rows [a00 a01 a02 a10 a11 a12]. */
+ * [x', y'] = A[trans[b]] @ [x, y, 1] with A = affine + 6*trans[b] = rows [a00 a01 a02 a10 a11 a12].
+ * The view also carries the per-window condition-frame sets of the random_imp strategy. */
 typedef struct {
     const int64_t* base;      /* device (B,) element offsets; NULL = dense (B,C,T,V) tensor */
     int64_t stride_c;         /* elements between the two coordinates of one joint */
     int64_t stride_t;         /* elements between consecutive frames */
     const int32_t* trans;     /* device (B,) transform index per window, or NULL */
     const float* affine;      /* device (n_transform, 6), required when trans != NULL */
+    const int32_t* cond_mask; /* MCD_STRATEGY_RANDOM_IMP only: device (B,), bit t set = frame t of the window is a condition
+                                 frame (exactly n_cond bits; mocodad.py:719-724 keeps both frame subsets in ascending
+                                 order, so the mask is all the kernel needs); NULL otherwise */
 } mcd_window_view_t;
 
 /* mcd_score with a window view (view == NULL is exactly mcd_score). */

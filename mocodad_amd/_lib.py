@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("MCD_LIB", os.path.join(_HERE, "libmocodad_hip.so"))  
 MCD_MAX_FRAMES = 32
 MCD_MAX_COND_LAYERS = 8
 
-STRATEGY = {"inject": 0, "concat": 1, "no_condition": 2, "inbetween_imp": 3}
+STRATEGY = {"inject": 0, "concat": 1, "no_condition": 2, "inbetween_imp": 3, "random_imp": 4}
 LOSS = {"smooth_l1": 0, "l1": 1, "mse": 2}
 COND_UNET = -1  # MCD_COND_UNET
 AGGR = {"all": 0, "best": 1, "worst": 2, "mean": 3, "median": 4, "mean_pose": 5, "median_pose": 6, "quantile": 7}
@@ -33,7 +33,7 @@ class ScoreCfg(C.Structure):
 
 class WindowView(C.Structure):
     _fields_ = [("base", C.c_void_p), ("stride_c", C.c_int64), ("stride_t", C.c_int64), ("trans", C.c_void_p),
-                ("affine", C.c_void_p)]
+                ("affine", C.c_void_p), ("cond_mask", C.c_void_p)]
 
 
 _SIGS = {

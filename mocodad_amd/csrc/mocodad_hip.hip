@@ -164,7 +164,14 @@ struct ScoreParams {
     int tx_of[12];            // denoised U-Net frame t -> its index among the corrupt frames
     int pos_of[12];           // corrupt frame k -> its U-Net frame
     int upd_of[12];           // U-Net frame t -> corrupt frame whose eps-prediction is read at t (-1: none)
+    const int* win_mask;      // random_imp: (B,) per-window bitmask of the condition frames (frames in natural order;
+                              // replaces fixed_mask and the four maps above, which are then derived from the mask)
 };
+// frame layout of one window: `fixed` = its condition-frame bitmask (P.fixed_mask, or the window's own for random_imp)
+__device__ __forceinline__ int fm_tx(const ScoreParams& P, int fixed, int t) {
+    return P.win_mask ? __popc(~fixed & ((1 << t) - 1)) : P.tx_of[t];
+}
+__device__ __forceinline__ int fm_src(const ScoreParams& P, int t) { return P.win_mask ? t : P.src_frame[t]; }
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller (perf mode noise; parity mode reads the caller's noise tensor)
@@ -626,7 +633,8 @@ struct Plan {
     static constexpr int EMB = NB * EMB_STRIDE;
     static constexpr int SE = NB * EDIM;
     static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
-    static constexpr int TOTAL = R + XT + EMB + SE + ZN;
+    static constexpr int WM = 4;                // per-chain condition-frame bitmask (NB <= 4 ints)
+    static constexpr int TOTAL = R + XT + EMB + SE + ZN + WM;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -645,6 +653,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     float* const EMB = XT + PL::XT;
     float* const SE = EMB + PL::EMB;
     float* const ZN = SE + PL::SE;
+    int* const WM = reinterpret_cast<int*>(ZN + PL::ZN);
 
     const int tid0 = threadIdx.x;
     int tid = tid0;
@@ -652,7 +661,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chain0 = blockIdx.x * NB;
     const int Tx = P.n_corrupt;
-    const int fixed = P.fixed_mask;
+    if (threadIdx.x < NB) {
+        int chain = chain0 + threadIdx.x;
+        if (chain >= P.n_chains) chain = P.n_chains - 1;
+        WM[threadIdx.x] = P.win_mask ? P.win_mask[chain / P.S] : P.fixed_mask;
+    }
     const int CTV = C0 * Tx * 17;          // elements of one generated pose
     const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
 
@@ -666,15 +679,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         int chain = chain0 + n;
         if (chain >= P.n_chains) chain = P.n_chains - 1;
         const int b = chain / P.S, s = chain % P.S;
+        const int fixed = WM[n];
         float xv[C0];
 #pragma unroll
         for (int c = 0; c < C0; ++c) {
             if (P.mode == 1) {
                 xv[c] = P.x_in[((b * C0 + c) * T + t) * 17 + v];
             } else if ((fixed >> t) & 1) {
-                xv[c] = load_coord(P.dv, b, c, P.src_frame[t], v, P.seg_len);
+                xv[c] = load_coord(P.dv, b, c, fm_src(P, t), v, P.seg_len);
             } else {
-                const int e = (c * Tx + P.tx_of[t]) * 17 + v;
+                const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
                 if (P.noise) xv[c] = P.noise[((size_t)(s * K + 0) * P.B + b) * CTV + e];
                 else xv[c] = philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
             }
@@ -749,11 +763,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 const int c = u % C0, col = u / C0;
                 const int n = col / TV17, t = (col / 17) % T, v = col % 17;
                 float z = 0.f;
+                const int fixed = WM[n];
                 if (!((fixed >> t) & 1)) {
                     int chain = chain0 + n;
                     if (chain >= P.n_chains) chain = P.n_chains - 1;
                     const int b = chain / P.S, s = chain % P.S;
-                    const int e = (c * Tx + P.tx_of[t]) * 17 + v;
+                    const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
                     const int k = P.ns - sidx;
                     if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
                     else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
@@ -948,13 +963,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     if (P.mode == 1) {
                         if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
                     } else {
+                        const int fixed = WM[n];
                         if ((fixed >> t) & 1) RG[PL::L0_in + col * 20 + c] = x;
                         // the prediction at frame t drives corrupt frame k = upd_of[t], which lives at frame pos_of[k]
                         // (the same frame except for 'concat' with the condition at the END of the window, where the
                         // reference reads the prediction at the corrupt frames' ORIGINAL indices, mocodad.py:829-838)
-                        const int k = P.upd_of[t];
+                        const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
                         if (k >= 0) {
-                            const int colp = (n * T + P.pos_of[k]) * 17 + v;
+                            const int colp = (n * T + (P.win_mask ? t : P.pos_of[k])) * 17 + v;
                             const float xo = XT[colp * 4 + c];
                             const float z = sidx > 1 ? ZN[colp * C0 + c] : 0.f;
                             const float xn = ca * (xo - cb * eps) + csg * z;
@@ -981,9 +997,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         const bool valid = chain < P.n_chains;
         if (!valid) chain = P.n_chains - 1;
         const int b = chain / P.S, s = chain % P.S;
-        const int tu = P.pos_of[tx];
+        int tu = P.pos_of[tx];
+        if (P.win_mask) {                       // frame of the tx-th corrupt frame = tx-th clear bit of the window's mask
+            const int fixed = WM[n];
+            int cnt = 0;
+            for (int t = 0; t < T; ++t)
+                if (!((fixed >> t) & 1)) { if (cnt == tx) tu = t; ++cnt; }
+        }
         const float x0 = XT[((n * T + tu) * 17 + v) * 4 + c];
-        const float gt = load_coord(P.dv, b, c, P.src_frame[tu], v, P.seg_len);
+        const float gt = load_coord(P.dv, b, c, fm_src(P, tu), v, P.seg_len);
         const float d = fabsf(x0 - gt);
         float l;
         if (P.loss_fn == MCD_LOSS_SMOOTH_L1) l = d < 1.f ? 0.5f * d * d : d - 0.5f;
@@ -1897,7 +1919,9 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         return fail(MCD_EINVAL, "cond/corrupt index lists do not partition seg_len");
     const int strat = w->cfg.strategy;
     const int Tu = w->cfg.t_unet;
-    const bool keeps_cond = strat == MCD_STRATEGY_CONCAT || strat == MCD_STRATEGY_INBETWEEN_IMP;   // condition frames are U-Net input
+    const bool rnd = strat == MCD_STRATEGY_RANDOM_IMP;
+    const bool keeps_cond = strat == MCD_STRATEGY_CONCAT || strat == MCD_STRATEGY_INBETWEEN_IMP || rnd;   // condition frames are U-Net input
+    if (rnd && !(view && view->cond_mask)) return fail(MCD_EINVAL, "random_imp needs mcd_window_view_t.cond_mask");
     const int tf = keeps_cond ? cfg->n_cond : 0;
     if (tf + cfg->n_corrupt != Tu) return fail(MCD_EINVAL, "frame split does not match the packed U-Net (t_unet)");
     if (Tu > 12) return fail(MCD_EUNSUPPORTED, "more than 12 U-Net frames");
@@ -1910,6 +1934,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (view->trans && !view->affine) return fail(MCD_EINVAL, "window view: trans given without an affine table");
         P.dv.base = reinterpret_cast<const long long*>(view->base); P.dv.sc = view->stride_c; P.dv.st = view->stride_t;
         P.dv.trans = view->trans; P.dv.aff = view->affine;
+        if (rnd) P.win_mask = view->cond_mask;
         if (!view->base) { P.dv.sc = (long long)cfg->seg_len * 17; P.dv.st = 17; }
     } P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
     P.seed = seed; P.first_window = first_window_id;
@@ -1917,13 +1942,13 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
     P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
     // U-Net frame layout: concat = condition frames first (mocodad.py:668), imputation = natural frame order
     // (mocodad.py:672-683), inject / no_condition = the corrupt frames only
-    for (int k = 0; k < tf; ++k) {
+    for (int k = 0; k < tf && !rnd; ++k) {
         const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->cond_idx[k] : k;
         if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad cond_idx");
         P.fixed_mask |= 1 << t;
         P.src_frame[t] = cfg->cond_idx[k];
     }
-    for (int k = 0; k < cfg->n_corrupt; ++k) {
+    for (int k = 0; k < cfg->n_corrupt && !rnd; ++k) {
         const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->corrupt_idx[k] : tf + k;
         if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad corrupt_idx");
         P.src_frame[t] = cfg->corrupt_idx[k];
@@ -1931,7 +1956,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         P.pos_of[k] = t;
     }
     for (int t = 0; t < 12; ++t) P.upd_of[t] = -1;
-    for (int k = 0; k < cfg->n_corrupt; ++k) {
+    for (int k = 0; k < cfg->n_corrupt && !rnd; ++k) {
         const int t = keeps_cond ? cfg->corrupt_idx[k] : k;     // mocodad.py:829-838: mask built from corrupt_idxs
         if (t < 0 || t >= Tu || P.upd_of[t] >= 0) return fail(MCD_EINVAL, "bad corrupt_idx");
         P.upd_of[t] = k;

@@ -44,7 +44,7 @@ class HipScorer:
         self.corrupt_idx = [int(i) for i in corrupt_idx]
         self.num_coords, self.n_joints, self.emb_dim = num_coords, n_joints, emb_dim
         self.t_cond = len(self.cond_idx) if strategy == "inject" else 0
-        self.t_unet = len(self.corrupt_idx) + (len(self.cond_idx) if strategy in ("concat", "inbetween_imp") else 0)
+        self.t_unet = len(self.corrupt_idx) + (len(self.cond_idx) if strategy in ("concat", "inbetween_imp", "random_imp") else 0)
         self._tables: Dict[int, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
 
@@ -120,19 +120,25 @@ class HipScorer:
         return out
 
     def score(self, data, *, n_samples: int, noise_steps: int, noise: Optional[torch.Tensor] = None,
-              seed: int = 0, first_window_id: int = 0, loss_fn: str = "smooth_l1", want_poses: bool = False
-              ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+              seed: int = 0, first_window_id: int = 0, loss_fn: str = "smooth_l1", want_poses: bool = False,
+              cond_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """data (B,C,T,V) tensor, or a mocodad_amd.data.windows.WindowBatch (windows read in place from trajectory
         buffers, test-time transform applied on load) -> (loss (B,S), poses (B,S,C,Tx,V) | None).
+        cond_mask (random_imp only): (B,) int32, bit t set = frame t of the window conditions.
         Asynchronous on the current stream."""
         view = None
         keep = None
+        if (cond_mask is not None) != (self.strategy == "random_imp"):
+            raise ValueError("cond_mask is required by, and only valid for, the random_imp strategy")
+        if cond_mask is not None:
+            cond_mask = cond_mask.to(self.device, torch.int32).contiguous()
         if hasattr(data, "as_view"):
             wb = data.to(self.device)
             keep = wb
             view = _lib.WindowView(base=wb.base.data_ptr(), stride_c=wb.stride_c, stride_t=wb.stride_t,
                                    trans=wb.trans.data_ptr() if wb.trans is not None else None,
-                                   affine=wb.affine.data_ptr() if wb.affine is not None else None)
+                                   affine=wb.affine.data_ptr() if wb.affine is not None else None,
+                                   cond_mask=cond_mask.data_ptr() if cond_mask is not None else None)
             B = int(wb.base.shape[0])
             data = wb.buffer
             if wb.seg_len != self.seg_len:
@@ -140,6 +146,10 @@ class HipScorer:
         else:
             data = _f32c(data, self.device)
             B = data.shape[0]
+            if cond_mask is not None:     # dense windows + per-window condition sets
+                view = _lib.WindowView(base=None, stride_c=0, stride_t=0, trans=None, affine=None, cond_mask=cond_mask.data_ptr())
+        if cond_mask is not None and cond_mask.numel() != B:
+            raise ValueError(f"cond_mask must have {B} entries")
         S = int(n_samples)
         Tx = len(self.corrupt_idx)
         cfg = self._score_cfg(B, S, int(noise_steps), loss_fn)

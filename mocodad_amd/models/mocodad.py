@@ -9,8 +9,8 @@ Reference: /root/reference/models/mocodad.py (forward :129-184, _aggregation_str
 _set_conditioning_strategy :753-796, _select_frames :708-750, post_processing :337-430).
 
 Scope: inference scoring with the 'inject', 'concat', 'no_condition' strategies, the
-'AE' / 'E' / 'E_unet' condition encoders and the 'inbetween_imp' imputation strategy.  Training (training_step /
-configure_optimizers) and 'random_imp' are outside the accelerated path and raise NotImplementedError.
+'AE' / 'E' / 'E_unet' condition encoders and the 'inbetween_imp' / 'random_imp' imputation strategies.  Training
+(training_step / configure_optimizers) is outside the accelerated path and raises NotImplementedError.
 """
 import argparse
 import os
@@ -197,8 +197,6 @@ class MoCoDAD(_Base):
 
     # -------------------------------------------------------------- construction
     def build_model(self) -> None:
-        if self.conditioning_strategy == "random_imp":   # per-window random frame permutations drawn from torch's RNG
-            raise NotImplementedError("conditioning strategy 'random_imp' is not part of the accelerated path")
         if self.num_coords != 2 or self.n_joints != 17:
             raise NotImplementedError("the HIP path (like the reference U-Net) supports num_coords=2 and 17 joints")
         enc = None
@@ -242,6 +240,8 @@ class MoCoDAD(_Base):
         T, ci = self.n_frames, self.conditioning_indices
         if self.conditioning_strategy == "no_condition":
             return [], list(range(T))
+        if self.conditioning_strategy == "random_imp":   # only the counts matter: the sets are drawn per window in forward
+            return list(range(ci)), list(range(ci, T))
         if isinstance(ci, int):
             if self.conditioning_strategy == "inbetween_imp":
                 cond = list(range(0, T, ci))
@@ -293,12 +293,15 @@ class MoCoDAD(_Base):
 
     # -------------------------------------------------------------- forward
     def forward(self, input_data: List[torch.Tensor], aggr_strategy: str = None, return_: str = None, *,
-                noise: Optional[torch.Tensor] = None, window_offset: Optional[int] = None) -> List[torch.Tensor]:
+                noise: Optional[torch.Tensor] = None, window_offset: Optional[int] = None,
+                cond_mask: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
         """[data (B,C,T,V), transformation_idx, metadata, actual_frames] -> [loss and/or pose] + the inputs.
 
         noise (extension, keyword only): (S, max(ns-1,1), B, C, Tx, V) tensor replacing the in-kernel Philox
         stream, slot 0 = x_T, slot k = z of step ns-k — what torch.randn_like returns in the reference in call
-        order; used for parity tests.  window_offset: global index of the first window (keys the noise stream)."""
+        order; used for parity tests.  window_offset: global index of the first window (keys the noise stream).
+        cond_mask ('random_imp' only): (B,) bitmasks of the condition frames; default = drawn like the reference does
+        (one torch.randperm per window on the default CPU generator, mocodad.py:719-724)."""
         tensor_data, meta_out = self._unpack_data(input_data)
         aggr = self.aggregation_strategy if aggr_strategy is None else aggr_strategy
         ret = return_ if return_ is not None else self.model_return_value
@@ -313,10 +316,23 @@ class MoCoDAD(_Base):
         self._calls += tensor_data.shape[0]
         if hasattr(tensor_data, "as_view") and pose_aggr and aggr in ("mean_pose", "median_pose"):
             tensor_data = tensor_data.materialize()      # the *_pose strategies compare against the windows themselves
+        if self.conditioning_strategy == "random_imp":
+            if aggr in ("mean_pose", "median_pose"):
+                raise NotImplementedError("the *_pose aggregations are not available with 'random_imp'")
+            if cond_mask is None:
+                cond_mask = self.draw_random_imp_mask(tensor_data.shape[0])
         loss_all, poses_all = sc.score(tensor_data, n_samples=S, noise_steps=ns, noise=noise, seed=self.seed,
-                                       first_window_id=window_offset, loss_fn=self.loss_name, want_poses=want_pose)
+                                       first_window_id=window_offset, loss_fn=self.loss_name, want_poses=want_pose,
+                                       cond_mask=cond_mask)
         selected_x, loss = self._aggregate(sc, tensor_data, loss_all, poses_all, aggr, want_pose)
         return self._pack_out_data(selected_x, loss, [tensor_data] + meta_out, return_=ret)
+
+    def draw_random_imp_mask(self, n_windows: int) -> torch.Tensor:
+        """'random_imp' frame sets exactly as _select_frames draws them (mocodad.py:719-724, 535): one randperm per
+        window; frame t conditions iff perm[t] < conditioning_indices.  -> (B,) int32 bitmasks."""
+        T, k = self.n_frames, int(self.conditioning_indices)
+        idx = torch.tensor([torch.randperm(T).tolist() for _ in range(n_windows)])
+        return ((idx < k).int() << torch.arange(T, dtype=torch.int32)).sum(1).to(torch.int32)
 
     def _aggregate(self, sc, data, loss_all, poses_all, aggr: str, want_pose: bool):
         if aggr == "all":

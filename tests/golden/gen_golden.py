@@ -155,7 +155,10 @@ EXTRA3_CASES = {
     "cattail": (dict(conditioning_strategy="concat", conditioning_indices=[3, 4, 5]), 4, 2, 4),
     # the U-Net's down path as condition encoder (mocodad.py:110-114)
     "encU": (dict(conditioning_architecture="E_unet"), 4, 2, 4),
+    # a random set of 2 condition frames per window (mocodad.py:719-724); the drawn sets are recorded as bitmasks
+    "rndimp": (dict(conditioning_strategy="random_imp", conditioning_indices=2), 4, 2, 5),
 }
+RNDIMP_SEED = 1234
 
 
 def extra(MoCoDAD, cases=None):
@@ -180,8 +183,18 @@ def extra(MoCoDAD, cases=None):
         batch = [data, torch.zeros(B, dtype=torch.long), torch.zeros(B, 4, dtype=torch.long), torch.zeros(B, 6, dtype=torch.int32)]
         out = {}
         orig = torch.randn_like
+        drawn = []
+        if m.conditioning_strategy == "random_imp":
+            sel = m._select_frames
+
+            def recording_select(d, sel=sel):
+                r = sel(d)
+                drawn.append(r[2][0].clone())      # (B, k) condition-frame indices, ascending
+                return r
+            m._select_frames = recording_select
         for aggr in ("all", "best", "mean"):
             torch.randn_like = NoiseFeeder(noise)
+            torch.manual_seed(RNDIMP_SEED)         # random_imp: the same randperm draws for every call
             try:
                 o = m.forward(batch, aggr_strategy=aggr, return_="all")
             finally:
@@ -192,6 +205,10 @@ def extra(MoCoDAD, cases=None):
         if m.condition_encoder is not None:
             cd, _, _ = m._select_frames(data)
             out["cond_emb"] = m.condition_encoder(cd, t=None)[0]
+        if drawn:
+            assert all(torch.equal(d, drawn[0]) for d in drawn)
+            out["cond_mask"] = (1 << drawn[0]).sum(1).to(torch.int32)
+            out["rng_seed"] = np.array([RNDIMP_SEED])
         save(f"traj_{name}_ns{ns}_S{S}.npz", data=data, noise=noise.half(), **out)
 
 

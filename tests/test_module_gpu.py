@@ -122,16 +122,22 @@ def test_full_size_properties():
     assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
 
 
-@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse", "imp2", "implist", "cattail", "encU"])
+@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse", "imp2", "implist", "cattail", "encU", "rndimp"])
 def test_extra_variants_vs_reference(name):
     """no_condition strategy (U-Net on all 6 frames), 'E' encoder with channels [24,40]+8 (generic condition-encoder
     kernel), l1 / mse losses, in-between imputation (every 2nd frame / an explicit list conditions), concat with the
-    condition at the end of the window — against vectors generated by the reference."""
+    condition at the end of the window, 'E_unet' condition encoder, random imputation (per-window frame sets drawn
+    from torch's RNG) — against vectors generated by the reference."""
     g = load_golden(f"traj_{name}_ns4_S2.npz")
     m, _, cfg = _model(name)
-    batch = [torch.from_numpy(g["data"]), torch.zeros(4), torch.zeros(4, 4), torch.zeros(4, 6)]
+    B = g["data"].shape[0]
+    batch = [torch.from_numpy(g["data"]), torch.zeros(B), torch.zeros(B, 4), torch.zeros(B, 6)]
     noise = torch.from_numpy(g["noise"].astype(np.float32))
     for aggr in ("all", "best", "mean"):
+        if "rng_seed" in g:       # random_imp: the module draws the per-window frame sets like the reference does
+            torch.manual_seed(int(g["rng_seed"][0]))
+            assert torch.equal(m.draw_random_imp_mask(B), torch.from_numpy(g["cond_mask"]))
+            torch.manual_seed(int(g["rng_seed"][0]))
         out = m.forward(batch, aggr_strategy=aggr, return_="all", noise=noise)
         np.testing.assert_allclose(out[0].cpu().numpy(), g[f"loss_{aggr}"], atol=ATOL, rtol=0, err_msg=aggr)
         if f"pose_{aggr}" in g:
