@@ -122,6 +122,29 @@ def test_full_size_properties():
     assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
 
 
+@pytest.mark.parametrize("variant,B,ns,S,seg_len", [("concat", 1024, 10, 5, 6), ("T12", 4096, 50, 8, 24)])
+def test_full_size_properties_other_configs(variant, B, ns, S, seg_len):
+    """BASELINE configs[3] (concat, 1024 windows) and configs[4] shape (seg_len 24, 12 condition + 12 denoised frames,
+    ns=50, S=8, 4096 windows): finite, deterministic, independent of the batch split, 1-sample-prefix consistent
+    (the chains of sample s do not depend on how many samples are drawn), best <= mean <= worst."""
+    m, _, _ = _model(variant, noise_steps=ns, n_generated_samples=S)
+    sc = m.scorer()
+    gen = torch.Generator().manual_seed(1)
+    data = torch.randn(B, 2, seg_len, 17, generator=gen).clamp_(-5, 5)
+    loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=11)
+    assert torch.isfinite(loss).all()
+    cut = B // 3
+    lo, _ = sc.score(data[:cut], n_samples=S, noise_steps=ns, seed=11, first_window_id=0)
+    hi, _ = sc.score(data[cut:], n_samples=S, noise_steps=ns, seed=11, first_window_id=cut)
+    assert torch.equal(torch.cat([lo, hi]), loss)
+    one, _ = sc.score(data[:64], n_samples=1, noise_steps=ns, seed=11)
+    assert torch.equal(one[:, 0], loss[:64, 0])
+    best = sc.aggregate(data, loss, None, "best", noise_steps=ns)[1]
+    mean = sc.aggregate(data, loss, None, "mean", noise_steps=ns)[1]
+    worst = sc.aggregate(data, loss, None, "worst", noise_steps=ns)[1]
+    assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
+
+
 @pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse", "imp2", "implist", "cattail", "encU", "rndimp"])
 def test_extra_variants_vs_reference(name):
     """no_condition strategy (U-Net on all 6 frames), 'E' encoder with channels [24,40]+8 (generic condition-encoder
