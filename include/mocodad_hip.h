@@ -104,8 +104,8 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
 int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table,
                      int32_t t, int32_t n_windows, float* eps_out, void* stream);
 
-/* Bytes of caller-provided device scratch mcd_score needs (condition embeddings + the per-step layer-embedding
- * tables of the trajectory).  Strategies without a condition encoder also accept workspace == NULL. */
+/* Bytes of caller-provided device scratch mcd_score needs (condition embeddings).  Strategies without a condition
+ * encoder also accept workspace == NULL. */
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.

@@ -93,7 +93,6 @@ enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_STRIDE = 8 };
 //   tab[l*8 + F_BIAS]  folded bias, padded to 16
 //   tab[l*8 + F_SLOPE] PReLU slope (float bits)
 constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
-constexpr int TAB_WEF = 100;             // embedding Linear as MFMA A fragments WEF[34][4][64]
 constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: MFMA A fragments WF[mt][ks][64] (lane (i,g) =
                                           // Wd'[16mt+i][rs_vmap(ks,g)]) and bd' padded to 32
 typedef const int __attribute__((address_space(4))) cint;
@@ -149,8 +148,6 @@ struct ScoreParams {
     DataView dv;              // windows: (B,C,T,V) tensor or a trajectory view
     const float* noise;       // (S,K,B,C,Tx,V) or null
     const float* cond_emb;    // (B,16) or null
-    const float* emb_tab;     // precomputed per-step layer embeddings [(window,) step-1][EMB_STRIDE] or null (computed in-kernel)
-    long long emb_wstride;    // floats between two windows' tables (0: one table shared by all windows)
     const float* step_table;  // (ns, 4+16)
     const float* x_in;        // single-pass mode: (B,C,Tu,V)
     float* loss_out;          // (B,S)
@@ -602,6 +599,55 @@ __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>&
                                                                prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
+// ------------------------------------------------------------------------------------------------
+// layer embeddings of one pass: EMB[n][o] = b_e[o] + sum_k W_e[o][k] SiLU(pe(i) + cond_n)[k] for the 530 (+2 pad)
+// output channels of the 11 layers (the Linear(SiLU(.)) of every ST-GCN layer, stsgcn.py:184-186, fed by the U-Net's
+// time embedding, stsae_unet.py:173-179, 424-431).  They depend on the step and the window only -- not on x_t -- so
+// pass i-1's are computed during the last (light) GEMM stage of pass i from rows fetched one stage earlier.
+// Plain FMAs, one output row per thread: with 2 chains the matrix cores would run this at 1/8 utilisation and the
+// kernel is bound by their time, not by the VALU's.
+// ------------------------------------------------------------------------------------------------
+struct EmbRow {              // W_e row + bias of one output channel
+    float4 w[4];
+    float b;
+    __device__ __forceinline__ void load(const float* wb, int o) {
+        const float* we = wb + tab_i(wb, TAB_WE);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = load_global4(we + o * EDIM + 4 * q);
+        b = as_global(wb + tab_i(wb, TAB_BE))[o];
+    }
+};
+// se: SiLU(pe + cond) [NB][16] in LDS; emb: EMB[n][536] (layers 0..9); e10: layer 10's outputs [n][4]
+template <int NB>
+__device__ __forceinline__ void emb_row(const EmbRow& f, int o, const float* __restrict__ se, float* __restrict__ emb,
+                                        float* __restrict__ e10) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        float acc = f.b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 sv = *reinterpret_cast<const float4*>(se + n * EDIM + 4 * q);   // LDS broadcast
+            acc = fmaf(f.w[q].x, sv.x, acc); acc = fmaf(f.w[q].y, sv.y, acc);
+            acc = fmaf(f.w[q].z, sv.z, acc); acc = fmaf(f.w[q].w, sv.w, acc);
+        }
+        if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = acc;
+        else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc;
+    }
+}
+// thread tid owns output channel tid (row `f`, fetched ahead by the caller); the EMB_TOTAL - NTHREADS channels beyond
+// are done by the last wave, which has no tile in the GEMM stage this runs in
+template <int NB>
+__device__ __forceinline__ void emb_compute(const EmbRow& f, const float* wb, const float* __restrict__ se,
+                                            float* __restrict__ emb, float* __restrict__ e10, int tid, int wave) {
+    emb_row<NB>(f, tid, se, emb, e10);
+    if (wave == NWAVES - 1) {
+        const int o = NTHREADS + (tid & 63);
+        EmbRow g;
+        g.load(wb, o < EMB_TOTAL ? o : EMB_TOTAL - 1);
+        emb_row<NB>(g, o, se, emb, e10);
+    }
+}
+
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
 // tables.  Sizes follow the padded column counts P17/P12/P10 and the row strides C+4.
 template <int T, int NB>
@@ -631,7 +677,8 @@ struct Plan {
                   "LDS plan: regions would overlap");
     static constexpr int XT = P17 * 4;
     static constexpr int EMB = NB * EMB_STRIDE;
-    static constexpr int SE = NB * EDIM;
+    static constexpr int SE = 2 * 4 * 4 + 4 * EDIM;   // layer 10's embedding outputs, double-buffered by step parity: [2][NB<=4][4];
+                                                     // then SiLU(pe + cond) of the NEXT pass [NB<=4][16]
     static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
     static constexpr int WM = 4;                // per-chain condition-frame bitmask (NB <= 4 ints)
     static constexpr int TOTAL = R + XT + EMB + SE + ZN + WM;
@@ -651,8 +698,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     float* const RG = smem;                 // work region (see Plan)
     float* const XT = RG + PL::R;
     float* const EMB = XT + PL::XT;
-    float* const SE = EMB + PL::EMB;
-    float* const ZN = SE + PL::SE;
+    float* const E10 = EMB + PL::EMB;
+    float* const SEN = E10 + 32;
+    float* const ZN = E10 + PL::SE;
     int* const WM = reinterpret_cast<int*>(ZN + PL::ZN);
 
     const int tid0 = threadIdx.x;
@@ -719,18 +767,25 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
-    // embedding rows EMB[n][532] of the first pass (one float4 per thread); the rows of pass i-1 are fetched during
-    // the last layer of pass i.  The embeddings depend on the step and the window only, so mcd_score precomputes them
-    // for the whole trajectory (emb_table_kernel); without a table (single-pass mode) they are computed per pass.
-    constexpr int EROW4 = EMB_STRIDE / 4;
-    const bool has_tab = P.emb_tab != nullptr;
-    auto erow_ptr = [&](int t_id, int row) {
-        const int n = t_id / EROW4, q4 = t_id % EROW4;
-        int chain = chain0 + n;
-        if (chain >= P.n_chains) chain = P.n_chains - 1;
-        return P.emb_tab + (size_t)(chain / P.S) * P.emb_wstride + (size_t)row * EMB_STRIDE + q4 * 4;
+    // embeddings of the first pass; those of pass i-1 are computed during the last layer of pass i
+    auto silu_row = [&](int step, int t_id) {      // SEN[n][k] = SiLU(pe(step)[k] + cond[window of chain n][k])
+        if (t_id < NB * EDIM) {
+            const int n = t_id / EDIM, k = t_id % EDIM;
+            int chain = chain0 + n;
+            if (chain >= P.n_chains) chain = P.n_chains - 1;
+            float e = P.step_table[step * (4 + EDIM) + 4 + k];
+            if (P.cond_emb) e += P.cond_emb[(chain / P.S) * EDIM + k];
+            SEN[t_id] = e / (1.f + expf(-e));
+        }
     };
-    if (has_tab && tid < NB * EROW4) *reinterpret_cast<float4*>(EMB + tid * 4) = load_global4(erow_ptr(tid, i_first - 1));
+    {
+        EmbRow er;
+        er.load(P.wbuf, tid0);
+        silu_row(i_first, tid0);
+        __syncthreads();
+        emb_compute<NB>(er, P.wbuf, SEN, EMB, E10 + (i_first & 1) * 16, tid0, wave);
+        __syncthreads();
+    }
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
         const float* wb = P.wbuf;
@@ -741,18 +796,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // ---- step prologue: layer-0 mix coefficients, this step's noise z (and, without a table, the embeddings)
+        // ---- step prologue: layer-0 mix coefficients and this step's noise z
         LMix<0, T, NB> mc0;
         mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);
-        if (!has_tab && tid < NB * EDIM) {
-            const int n = tid / EDIM, k = tid % EDIM;
-            int chain = chain0 + n;
-            if (chain >= P.n_chains) chain = P.n_chains - 1;
-            const int b = chain / P.S;
-            float e = srow[4 + k];
-            if (P.cond_emb) e += P.cond_emb[b * EDIM + k];
-            SE[tid] = e / (1.f + expf(-e));
-        }
+        silu_row(sidx > 0 ? sidx - 1 : 0, tid);       // for the NEXT pass's embeddings (consumed in this pass's last layer)
         // this step's noise z (one element per thread: the Philox + Box-Muller cost is paid here, fully parallel,
         // not in the narrow epilogue of the last layer)
         // -- by the last two waves when they have no unit in the layer-0 mix that follows, else by everybody
@@ -777,32 +824,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             }
         }
         STAGE(0);
-        if (!has_tab) {
-            __syncthreads();
-            // embeddings of this step for all 11 layers on the matrix cores: EMB[n][o] = b_e[o] + sum_k W_e[o][k] SE[n][k]
-            //      (M = 532 outputs in 34 m-tiles, K = 16, N = chains padded to 16; same stage as the layer-0 mix)
-            gfloat* wef = as_global(wb + tab_i(wb, TAB_WEF));
-            const int j = lane & 15, g = lane >> 4;
-            float bk[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bk[ks] = j < NB ? SE[j * EDIM + 4 * ks + g] : 0.f;
-            constexpr int EMT = (EMB_TOTAL + 15) / 16;
-            constexpr int ER = (EMT + NWAVES - 1) / NWAVES;
-#pragma unroll 1
-            for (int i = 0; i < ER; ++i) {
-                const int mt = wave + i * NWAVES;
-                const int mtc = mt < EMT ? mt : EMT - 1;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wef[(mtc * 4 + ks) * 64 + lane], bk[ks], acc, 0, 0, 0);
-                const float4 be4 = load_global4(wb + tab_i(wb, TAB_BE) + mtc * 16 + 4 * g);
-                const int o = mt * 16 + 4 * g;
-                if (mt < EMT && j < NB && o < EMB_TOTAL)
-                    *reinterpret_cast<float4*>(EMB + j * EMB_STRIDE + o) =
-                        make_float4(acc[0] + be4.x, acc[1] + be4.y, acc[2] + be4.z, acc[3] + be4.w);
-            }
-        }
         STAGE(1);
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
         // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.
@@ -921,21 +942,22 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const LayerW lw = layer_w(wb, 10);
             float4 afr[2];
             MixCoef<16, 17, T, NB> mc10;
+            // next pass's embedding rows.  Unconditional (after the last pass the result is simply unused): a
+            // conditionally loaded register struct costs ~35 VGPRs of phi copies here.
+            EmbRow ef;
+            auto ef_load = [&] { ef.load(wb, tid); };
             mix_late(mc9, 9);
             layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
                                     if constexpr (PF) {
                                         load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
                                         mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
+                                        ef_load();
                                     }
                                 }, nohook);                                                              // su3.0
             STAGE(16);
-            if constexpr (!PF) load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+            if constexpr (!PF) { load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr); ef_load(); }
             float* Pb = RG + PL::L10_p;
-            // next pass: its embedding rows (consumed at the top of the loop) and its layer-0 mix coefficients
-            float4 erow = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool fetch = has_tab && sidx > i_last && tid < NB * EROW4;
-            if (fetch) erow = load_global4(erow_ptr(tid, sidx - 2));
             gemm_tiles<1, NT, 2, 0, false>(afr, RG + PL::L10_in, 36, RG + PL::L10_in, 36, wave, lane,
                                            [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS17) *reinterpret_cast<float4*>(Pb + col * 20 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -943,6 +965,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // next pass's U-Net input block: pad channels zeroed here, x written by the fused store below
             for (int u = tid; u < COLS17 * 4; u += NTHREADS)
                 *reinterpret_cast<float4*>(RG + PL::L0_in + (u >> 2) * 20 + (u & 3) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            // next pass's embeddings: layers 0..9 straight into EMB (dead by now), layer 10's into the other E10 half
+            emb_compute<NB>(ef, wb, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid, wave);
             __syncthreads();
             const float ca = srow[0], cb = srow[1], csg = srow[2];
             gfloat* bias = as_global(wb + lw.bias);
@@ -959,7 +983,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     const int b = chain / P.S;
                     const float x = XT[col * 4 + c];
                     const float eps = prelu(val + Pb[col * 20 + C0 + c] + bias[c], slope10) +
-                                      EMB[n * EMB_STRIDE + emb_off(10) + c] + x;
+                                      E10[(sidx & 1) * 16 + n * 4 + c] + x;
                     if (P.mode == 1) {
                         if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
                     } else {
@@ -981,7 +1005,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 }
             });
             __syncthreads();
-            if (fetch) *reinterpret_cast<float4*>(EMB + tid * 4) = erow;
             STAGE(17);
         }
     }
@@ -1022,34 +1045,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
         const int chain = chain0 + wave;
         if (lane == 0 && chain < P.n_chains) P.loss_out[chain] = sum / (float)per;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-step layer embeddings for a whole trajectory: out[(w,) k][o] = b_e[o] + sum_j W_e[o][j] SiLU(pe(k+1) + cond_w)[j]
-// (the Linear(SiLU(.)) of every ST-GCN layer, stsgcn.py:184-186, stsae_unet.py:173-179).  They do not depend on x_t,
-// so the persistent kernel only copies NB rows per pass.  grid = (windows or 1, steps).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emb_table_kernel(const float* __restrict__ wbuf, const float* __restrict__ step_table,
-                                                        const float* __restrict__ cond_emb, float* __restrict__ out, int K) {
-    __shared__ float se[EDIM];
-    const int b = blockIdx.x, k = blockIdx.y;
-    if (threadIdx.x < EDIM) {
-        float e = step_table[(k + 1) * (4 + EDIM) + 4 + threadIdx.x];
-        if (cond_emb) e += cond_emb[b * EDIM + threadIdx.x];
-        se[threadIdx.x] = e / (1.f + expf(-e));
-    }
-    __syncthreads();
-    const float* we = wbuf + tab_i(wbuf, TAB_WE);
-    const float* be = wbuf + tab_i(wbuf, TAB_BE);
-    for (int o = threadIdx.x; o < EMB_STRIDE; o += blockDim.x) {
-        float acc = 0.f;
-        if (o < EMB_TOTAL) {
-            acc = be[o];
-#pragma unroll
-            for (int j = 0; j < EDIM; ++j) acc = fmaf(we[o * EDIM + j], se[j], acc);
-        }
-        out[((size_t)b * K + k) * EMB_STRIDE + o] = acc;
     }
 }
 
@@ -1646,13 +1641,6 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         };
         U.L[l].wp = pack_gemm_frags(B, M, Kc, wcat);
     }
-    // embedding Linear of all layers as MFMA A fragments: lane (i, g) of (mt, ks) = We_all[16mt + i][4ks + g]
-    const int EMT = (EMB_TOTAL + 15) / 16;
-    const int wef = B.alloc((size_t)EMT * 4 * 64);
-    for (int mt = 0; mt < EMT; ++mt) for (int ks = 0; ks < 4; ++ks) for (int lane = 0; lane < 64; ++lane) {
-        const int o = mt * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
-        B.buf[wef + (mt * 4 + ks) * 64 + lane] = o < EMB_TOTAL ? B.buf[U.we + (size_t)o * EDIM + k] : 0.f;
-    }
     static const char* rs_names[4] = {"down1", "down2", "up3", "up2"};
     static const int rs_in[4] = {17, 12, 10, 12}, rs_out[4] = {12, 10, 12, 17};
     for (int r = 0; r < 4; ++r) {
@@ -1796,7 +1784,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             tab[l * F_STRIDE + F_WP] = U.L[l].wp; tab[l * F_STRIDE + F_BIAS] = U.L[l].bias;
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
         }
-        tab[TAB_WE] = U.we; tab[TAB_BE] = U.be; tab[TAB_WEF] = wef;
+        tab[TAB_WE] = U.we; tab[TAB_BE] = U.be;
         if (cond_unet) for (int i = 0; i <= TABC_ULB; ++i) tab[TABC + i] = utab[i];
         if (cond_fast) {
             for (int l = 0; l < 4; ++l) for (int f = 0; f < F_STRIDE; ++f) tab[TABC + l * F_STRIDE + f] = ctab[l][f];
@@ -1866,15 +1854,10 @@ static int64_t ws_cond_bytes(const mcd_weights* w, int64_t B) {
     const int64_t raw = B * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
     return (raw + 255) / 256 * 256;
 }
-static int64_t ws_tab_floats(const mcd_weights* w, int64_t B, int ns) {
-    const int64_t K = ns > 1 ? ns - 1 : 1;
-    return (w->cfg.strategy == MCD_STRATEGY_INJECT ? B : 1) * K * EMB_STRIDE;
-}
-
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg) {
     if (!w || !cfg) return 0;
-    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V) + per-step layer-embedding tables
-    return ws_cond_bytes(w, cfg->n_windows) + ws_tab_floats(w, cfg->n_windows, cfg->noise_steps) * 4;
+    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V)
+    return ws_cond_bytes(w, cfg->n_windows);
 }
 
 __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out, int B, int C, int T, int V, int n,
@@ -1883,22 +1866,6 @@ __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out,
     if (u >= B * C * n * V) return;
     const int v = u % V, k = (u / V) % n, c = (u / (V * n)) % C, b = u / (V * n * C);
     out[u] = load_coord(dv, b, c, fi.idx[k], v, T);
-}
-
-// embedding tables for the whole trajectory (workspace tail), then the persistent kernel.  Without a workspace
-// (allowed for the strategies that have no condition encoder) the embeddings are computed in-kernel.
-static int launch_tab_and_score(const mcd_weights* w, const mcd_score_cfg_t* cfg, ScoreParams& P, void* workspace, hipStream_t st) {
-    if (workspace) {
-        const int K = cfg->noise_steps - 1;
-        const bool per_window = w->cfg.strategy == MCD_STRATEGY_INJECT;
-        float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_cond_bytes(w, cfg->n_windows));
-        hipLaunchKernelGGL(emb_table_kernel, dim3(per_window ? cfg->n_windows : 1, K), dim3(256), 0, st, w->dbuf, P.step_table,
-                           per_window ? P.cond_emb : nullptr, tab, K);
-        HIP_TRY(hipGetLastError());
-        P.emb_tab = tab;
-        P.emb_wstride = per_window ? (long long)K * EMB_STRIDE : 0;
-    }
-    return launch_score(w->cfg.t_unet, P, st);
 }
 
 int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise, uint64_t seed,
@@ -1972,7 +1939,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
             int rc = launch_cond_mfma(w, P.dv, fi, cfg->seg_len, emb, B, st);
             if (rc != MCD_OK) return rc;
             P.cond_emb = emb;
-            return launch_tab_and_score(w, cfg, P, workspace, st);
+            return launch_score(Tu, P, st);
         }
         const int total = B * C0 * Tc * 17;
         FrameIdx fi;
@@ -1984,7 +1951,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (rc != MCD_OK) return rc;
         P.cond_emb = emb;
     }
-    return launch_tab_and_score(w, cfg, P, workspace, st);
+    return launch_score(Tu, P, st);
 }
 
 int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,
