@@ -296,16 +296,23 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         const int cb = rest % CB, n = rest / CB;
         const float* xin_p = in + (n * T * V + voff_pair) * cs_in + cb * 16 + j;
         const float* xin_l = in + (n * T * V + g) * cs_in + cb * 16 + j;
-        f32x4 acc[QC][MT];
+        // V = 17: output joint 16 would cost a whole second m-tile (15/16 wasted, and the kernel is bound by matrix-pipe
+        // time); it is accumulated with plain FMAs instead -- 5 per frame, partial sums over this lane group's joints
+        constexpr bool J16 = V == 17;
+        constexpr int MTM = J16 ? 1 : MT;            // m-tiles on the matrix cores
+        f32x4 acc[QC][MTM];
+        float part[QC];
 #pragma unroll
-        for (int qi = 0; qi < QC; ++qi)
+        for (int qi = 0; qi < QC; ++qi) {
+            part[qi] = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTM; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[qi][mt][r] = 0.f;
                     if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = init(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j);
                 }
+        }
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
@@ -322,17 +329,28 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                     fmac_bc<(ks * T + t) % 16, t == T - 1>(y, cur.tq[qi][(ks * T + t) / 16], x[t]);
                 });
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MTM; ++mt)
                     acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
+                if constexpr (J16) part[qi] = fmaf(cur.aop[qi][1][ks], y, part[qi]);
             });
         });
 #pragma unroll
-        for (int qi = 0; qi < QC; ++qi)
+        for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTM; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (mt * 16 + 4 * g + r < V) store(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j, acc[qi][mt][r]);
+            if constexpr (J16) {
+                // sum the four lane groups' partials (lanes j, j+16, j+32, j+48): two register-swap steps
+                const unsigned u = __float_as_uint(part[qi]);
+                const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                const float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                if (g == 0) store(n, q0 + qi, 16, cb * 16 + j, z16 + init(n, q0 + qi, 16, cb * 16 + j));
+            }
+        }
     };
     // later rounds: coefficients fetched one round ahead where the register budget allows (T = 3), else in place
     if constexpr (T == 3) {
@@ -1445,7 +1463,9 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
     for (int q = 0; q < T; ++q) for (int s = 0; s < KS; ++s) for (int lane = 0; lane < 64; ++lane) {
         const int j = lane & 15, g = lane >> 4, v = mix_vmap(V, s, g);
         for (int mt = 0; mt < MT; ++mt) {
-            const int w = mt * 16 + j;
+            // m-tile 0: MFMA A fragment (output joint 16mt + j).  V = 17: the one joint beyond it is mixed on the VALU
+            // (mix_stage), its coefficient A_q[v][16] replicated over the 16 lanes of the group
+            const int w = (V == 17 && mt == 1) ? 16 : mt * 16 + j;
             B.buf[af + ((q * MT + mt) * KS + s) * 64 + lane] = (v < V && w < V) ? A[(q * V + v) * V + w] : 0.f;
         }
     }
