@@ -9,9 +9,9 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for path in sys.argv[1:]:
     db = sqlite3.connect(path)
     for name, counter, value in db.execute("select kernel_name, counter_name, value from counters_collection"):
-        if name.startswith("__amd_rocclr") or "at::native" in name:
+        if name.startswith("__amd_rocclr") or "at::native" in name or "at::" in name:
             continue
-        short = name.replace("void (anonymous namespace)::", "").split("(")[0]
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         a = acc[short][counter]
         a[0] += value
         a[1] += 1
