@@ -443,9 +443,14 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
         if (u < UNITS) {
             const int cb = u % CB, nt = u / CB;
             const float* xin = in + (nt * VIN) * cs_in + cb * 16 + j;
-            f32x4 acc[MT];
+            // VOUT = 17: output joint 16 on the VALU (partial sums per lane group, permlane-swap reduction) instead of a
+            // second m-tile with one useful row -- same trade as in mix_stage
+            constexpr bool J16 = VOUT == 17;
+            constexpr int MTM = J16 ? 1 : MT;
+            f32x4 acc[MTM];
+            float part = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+            for (int mt = 0; mt < MTM; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
             static_for<KS>([&](auto si) {
                 constexpr int ks = decltype(si)::value;
                 int row;
@@ -454,19 +459,29 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
                 const float x = xin[row * cs_in];
                 if constexpr (CAPTURE) skip[i * SK + ks] = x;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MTM; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
+                if constexpr (J16) part = fmaf(aop[1][ks], x, part);
             });
             if constexpr (ADD) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
-                if constexpr (SK == 5) acc[MT - 1][0] += skip[i * SK + 4];     // joint 16 lives in lane group g = 0, row 0 of m-tile 1
+                if constexpr (SK == 5 && !J16) acc[MT - 1][0] += skip[i * SK + 4];   // joint 16: lane group g = 0, row 0 of m-tile 1
             }
             float* zo = out + (nt * VOUT + 4 * g) * cs_out + cb * 16 + j;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MTM; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (mt * 16 + 4 * g + r < VOUT) zo[(mt * 16 + r) * cs_out] = acc[mt][r];
+            if constexpr (J16) {
+                const unsigned pu = __float_as_uint(part);
+                const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]) + bias[1][0];
+                if constexpr (ADD && SK == 5) z16 += skip[i * SK + 4];          // captured by lane group g = 0 (k-step 4: joint 16 + g)
+                if (g == 0) out[(nt * VOUT + 16) * cs_out + cb * 16 + j] = z16;
+            }
         }
     });
 }
@@ -1673,7 +1688,8 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         U.rs_w[r] = B.alloc((size_t)MTr * KS * 64);
         U.rs_b[r] = B.alloc(32);
         for (int mt = 0; mt < MTr; ++mt) for (int ks = 0; ks < KS; ++ks) for (int lane = 0; lane < 64; ++lane) {
-            const int vo = mt * 16 + (lane & 15), v = rs_vmap(capture, vin, ks, lane >> 4);
+            // vout = 17: the second fragment holds joint 16's weights replicated over each lane group (VALU path)
+            const int vo = (vout == 17 && mt == 1) ? 16 : mt * 16 + (lane & 15), v = rs_vmap(capture, vin, ks, lane >> 4);
             B.buf[U.rs_w[r] + (mt * KS + ks) * 64 + lane] = (vo < vout && v < vin) ? (float)f.w[(size_t)vo * vin + v] : 0.f;
         }
         for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_b[r] + vo] = (float)f.b[vo];
