@@ -400,6 +400,9 @@ struct RsCfg {
     static constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;   // units per wave
     static constexpr int VS = CAPTURE ? VIN : VOUT;              // joints of the skip tensor
     static constexpr int SK = VS > 16 ? 5 : 4;                   // skip registers per unit
+    // ALIGNED: one wave per (chain, 16-channel block), doing that block's T frames -- the same wave then owns the unit
+    // (chain, block, all frames) of the mix before / after it, so no barrier is needed between the two stages
+    static constexpr bool ALIGNED = NB * CB == NWAVES && PER == T;
 };
 __host__ __device__ constexpr int rs_vmap(bool capture, int vin, int ks, int g) {
     return capture ? (ks < 4 ? 4 * g + ks : 16 + g) : mix_vmap(vin, ks, g);
@@ -441,7 +444,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
         if (u < UNITS) {
-            const int cb = u % CB, nt = u / CB;
+            const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
             const float* xin = in + (nt * VIN) * cs_in + cb * 16 + j;
             // VOUT = 17: output joint 16 on the VALU (partial sums per lane group, permlane-swap reduction) instead of a
             // second m-tile with one useful row -- same trade as in mix_stage
@@ -904,7 +907,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         mix_early(mc5, 5);
         rs_late(rc2, 1);
         resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
-        __syncthreads();
+        // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
+        constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
+        if constexpr (!FUSE64) __syncthreads();
         STAGE(8);
         // ---- sd3.0, then sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G, then out = PReLU(mix(P_t) + P_r + b) + e in place of P_r
         {
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         RsCoef<64, 10, 12, T, NB, false> rc3;
         rs_early(rc3, 2);
-        __syncthreads();
+        if constexpr (!FUSE64) __syncthreads();     // aligned: up3 reads only this wave's own layer-6 output block
         STAGE(11);
         // ---- up path
         LMix<7, T, NB> mc7;
