@@ -29,8 +29,8 @@ F_UNET_T3 = 4_290_352
 F_COND_T3 = 545_904
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 # HBM bytes per launch of the default workload from the rocprofv3 PMC passes (see profiles/)
-HBM_TRAFFIC_DEFAULT = 7.79e6   # (2 x 2747.0 + 80 + 2 x 1046.2 + 64 + 2 x 30 + 4) KB: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-HBM_TRAFFIC_SOURCE = "profiles/r01i_pmc.txt"
+HBM_TRAFFIC_DEFAULT = 7.72e6   # (2 x 2745.0 + 80 + 2 x 1013.1 + 64 + 2 x 30 + 4) KB: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
+HBM_TRAFFIC_SOURCE = "profiles/r01j_pmc.txt"
 PEAK_HBM_GBS = 8000.0
 
 
@@ -175,7 +175,7 @@ def main():
                                    f"noise_steps={ns}, {S} generated samples, inject conditioning, 'best' aggregation",
                        "windows_per_step_per_gpu": B, "denoiser_passes_per_window": P, "weights": "seeded random init (tests/golden/weights_inject.npz)",
                        "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), all-gather of scores"},
-            "roofline": {"bound": "mfma", "kernel": "score_kernel<3,2,4> (+ cond_fast_kernel<3,4>)", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": "score_kernel<3,2,4> (+ cond_fast_kernel<3,2>)", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
                          "hbm_algorithmic_bytes_per_window": 820,

@@ -498,20 +498,6 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
 // Wave w owns m-tile w % MT and n-tiles (w / MT) + i * (8 / MT).
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
-// Lane -> (column, channel block) maps of the GEMM fragments, chosen for the ds_read_b128 lane groups of gfx950
-// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- 8 lanes of one k-group g with 8 of the next): with the natural maps
-// (column = lane & 15, block = g) two lanes of a group always land on one 16-byte bank slot for row strides of 4*odd
-// floats.  gemm_col sends the 8+8 lanes of a group to even / odd columns, gemm_blk = (0,2,1,3) puts the two k-groups of
-// a group two blocks apart: slot = odd*col + blk is then distinct for all 16 lanes (both for the K blocks of the B
-// operand and for the row blocks of the D fragment / identity-residual reads).  Pure relabelling: LDS layout unchanged.
-__host__ __device__ constexpr int gemm_blk(int g) { return ((g & 1) << 1) | (g >> 1); }
-__host__ __device__ constexpr int gemm_col(int j) { return j < 4 ? 2 * j : j < 12 ? 2 * (j - 4) + 1 : 2 * (j - 12) + 8; }
-// lane id + its two GEMM maps, computed once per pass by the kernels (recomputing them in each of the 13 GEMM stages
-// costs more issue slots than the bank conflicts they remove)
-struct Lane {
-    int id, col, blk4;
-    __device__ __forceinline__ explicit Lane(int lane) : id(lane), col(gemm_col(lane & 15)), blk4(4 * gemm_blk(lane >> 4)) {}
-};
 
 template <int MT, int NT>
 struct Tiling {
@@ -535,22 +521,23 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
 
 template <int MT, int NT, int KQ1, int KQ2, bool IDRES, class Epi>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
-                                           const float* __restrict__ b2, int cs2, int wave, const Lane& ln, Epi&& epi, int mi = 0) {
+                                           const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0) {
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
     const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
-    const int c0 = mt * 16 + ln.blk4;
+    const int j = lane & 15, g = lane >> 4;
+    const int c0 = mt * 16 + 4 * g;
     static_for<MAXN>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         const int nt = ng + i * NG;
         if (nt < NT) {
-            const int col = nt * 16 + ln.col;
+            const int col = nt * 16 + j;
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
             if (IDRES) {
                 const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + c0);
                 c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
             }
-            const float* p1 = b1 + col * cs1 + ln.blk4;
+            const float* p1 = b1 + col * cs1 + 4 * g;
 #pragma unroll
             for (int kq = 0; kq < KQ1; ++kq) {
                 const float4 u = *reinterpret_cast<const float4*>(p1 + kq * 16);   // one ds_read_b128 = 4 k-steps
@@ -560,7 +547,7 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u.w, c, 0, 0, 0);
             }
             if (KQ2 > 0) {
-                const float* p2 = b2 + col * cs2 + ln.blk4;
+                const float* p2 = b2 + col * cs2 + 4 * g;
 #pragma unroll
                 for (int kq = 0; kq < KQ2; ++kq) {
                     const float4 u = *reinterpret_cast<const float4*>(p2 + kq * 16);
@@ -585,9 +572,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, class H1, class H2>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
                                               const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
-                                              const float* __restrict__ embl, int wave, const Lane& ln, Prof& prof, int prof_id,
+                                              const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
                                               H1&& pre_gemm, H2&& pre_barrier) {
-    const int lane = ln.id;
     constexpr int MT = ceil16(COUT) / 16;
     constexpr int COLS = NB * T * V;
     constexpr int NT = ceil16(COLS) / 16;
@@ -602,7 +588,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                              [&](int n, int q, int w, int c, float v) { z[((n * T + q) * V + w) * CSI + c] = v; });
     __syncthreads();
     prof.mark(prof_id);
-    float4 bcur = load_global4(bias + (wave % MT) * 16 + ln.blk4);
+    float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
     pre_gemm();
     const float slope = lw.slope;
     auto epi = [&](auto, int col, int c0, f32x4 acc) {
@@ -617,12 +603,12 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
         }
     };
-    gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, ln, epi);
+    gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi);
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
         load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
-        bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + ln.blk4);
-        gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, ln, epi, mi);
+        bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
+        gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi, mi);
     }
     pre_barrier();
     __syncthreads();
@@ -632,10 +618,10 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const float* __restrict__ in,
                                               float* __restrict__ z, float* __restrict__ out,
-                                              const float* __restrict__ embl, int wave, const Lane& ln, Prof& prof, int prof_id) {
+                                              const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id) {
     MixCoef<CIN, V, T, NB> mc;
-    mc.load(wb + lw.tq, wb + lw.am, wave, ln.id);
-    layer_generic<CIN, COUT, V, RES, HASEMB, T, NB>(wb, lw, mc, in, z, out, embl, wave, ln, prof, prof_id, NoHook{}, NoHook{});
+    mc.load(wb + lw.tq, wb + lw.am, wave, lane);
+    layer_generic<CIN, COUT, V, RES, HASEMB, T, NB>(wb, lw, mc, in, z, out, embl, wave, lane, prof, prof_id, NoHook{}, NoHook{});
 }
 
 // U-Net layer L of the fixed channel plan
@@ -643,9 +629,9 @@ template <int L, int T, int NB>
 using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
 template <int L, int T, int NB, class H1, class H2>
 __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
-                                          const float* emb, int wave, const Lane& ln, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
+                                          const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
     constexpr LDesc D = layer_desc(L);
-    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, ln,
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
                                                                prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
@@ -846,7 +832,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const Lane ln(lane);
         // ---- step prologue: layer-0 mix coefficients and this step's noise z
         LMix<0, T, NB> mc0;
         mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);
@@ -888,18 +873,18 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         auto rs_late = [&](auto& rc, int r) { if constexpr (!PF) rsload(rc, r); };
         NoHook nohook;
         LMix<1, T, NB> mc1;
-        layer_std<0, T, NB>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, ln, prof,
+        layer_std<0, T, NB>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc1, 1); }, nohook);                                           // sp1a (2 -> 16)
         STAGE(2);
         // ---- down path
         LMix<2, T, NB> mc2;
         mix_late(mc1, 1);
-        layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, ln, prof,
+        layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
         RsCoef<32, 17, 12, T, NB, true> rc1;
         mix_late(mc2, 2);
-        layer_std<2, T, NB>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, ln, prof,
+        layer_std<2, T, NB>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
         STAGE(4);
         LMix<3, T, NB> mc3;
@@ -910,12 +895,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(5);
         LMix<4, T, NB> mc4;
         mix_late(mc3, 3);
-        layer_std<3, T, NB>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, ln, prof,
+        layer_std<3, T, NB>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
         STAGE(6);
         RsCoef<64, 12, 10, T, NB, true> rc2;
         mix_late(mc4, 4);
-        layer_std<4, T, NB>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, ln, prof,
+        layer_std<4, T, NB>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
         STAGE(7);
         LMix<5, T, NB> mc5;
@@ -933,7 +918,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
             mix_late(mc5, 5);
-            layer_std<5, T, NB>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, ln, prof, nohook,
+            layer_std<5, T, NB>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
                                 [&] { if constexpr (PF) load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0); });  // sd3.0
             STAGE(9);
             if constexpr (!PF) load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
@@ -943,11 +928,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
-            gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, ln, epi6, 0);
+            gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
 #pragma unroll
             for (int mi = 1; mi < Tiling<8, NT>::MW; ++mi) {
                 load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
-                gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, ln, epi6, mi);
+                gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
             }
             __syncthreads();
             STAGE(10);
@@ -974,12 +959,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(12);
         LMix<8, T, NB> mc8;
         mix_late(mc7, 7);
-        layer_std<7, T, NB>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, ln, prof,
+        layer_std<7, T, NB>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
         STAGE(13);
         RsCoef<32, 12, 17, T, NB, false> rc4;
         mix_late(mc8, 8);
-        layer_std<8, T, NB>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, ln, prof,
+        layer_std<8, T, NB>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
         STAGE(14);
         LMix<9, T, NB> mc9;
@@ -1000,7 +985,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             EmbRow ef;
             auto ef_load = [&] { ef.load(wb, tid); };
             mix_late(mc9, 9);
-            layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, ln, prof,
+            layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
                                     if constexpr (PF) {
                                         load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
@@ -1011,7 +996,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(16);
             if constexpr (!PF) { load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr); ef_load(); }
             float* Pb = RG + PL::L10_p;
-            gemm_tiles<1, NT, 2, 0, false>(afr, RG + PL::L10_in, 36, RG + PL::L10_in, 36, wave, ln,
+            gemm_tiles<1, NT, 2, 0, false>(afr, RG + PL::L10_in, 36, RG + PL::L10_in, 36, wave, lane,
                                            [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS17) *reinterpret_cast<float4*>(Pb + col * 20 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             });
@@ -1126,7 +1111,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * NB;
-    const Lane ln(lane);
     Prof prof;
 #ifdef MCD_PROFILE
     prof.on = false; prof.p = nullptr; prof.tlast = 0;
@@ -1148,10 +1132,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
         w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
         return w;
     };
-    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(0), X0, Z0, Y0, nullptr, wave, ln, prof, 0);   // 2(16) -> 32
-    layer_generic<32, 16, 17, true, false, T, NB>(wb, lw(1), Y0, Z1, X0, nullptr, wave, ln, prof, 0);   // 32 -> 16
-    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(2), X0, Z0, Y0, nullptr, wave, ln, prof, 0);   // 16 -> 32
-    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(3), Y0, Z1, H, nullptr, wave, ln, prof, 0);   // 32 -> 32
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(0), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 2(16) -> 32
+    layer_generic<32, 16, 17, true, false, T, NB>(wb, lw(1), Y0, Z1, X0, nullptr, wave, lane, prof, 0);   // 32 -> 16
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(2), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 16 -> 32
+    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(3), Y0, Z1, H, nullptr, wave, lane, prof, 0);   // 32 -> 32
     // bottleneck Linear: emb[n][j] = b[j] + sum_k W[j][k] H[n][k], k = c*TV + tv.  thread = (n, j, part of 16)
     constexpr int F = 32 * TV;
     gfloat* W = as_global(wb + tab_i(wb, TABC + TABC_LW));
@@ -1193,7 +1177,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * NB;
-    const Lane ln(lane);
     Prof prof;
 #ifdef MCD_PROFILE
     prof.on = false; prof.p = nullptr; prof.tlast = 0;
@@ -1216,25 +1199,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
         return w;
     };
     float nosk[1] = {0.f};
-    layer_generic<16, 16, 17, true, false, T, NB>(wb, lw(0), RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, nullptr, wave, ln, prof, 0);
-    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(1), RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, nullptr, wave, ln, prof, 0);
-    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(2), RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, nullptr, wave, ln, prof, 0);
+    layer_generic<16, 16, 17, true, false, T, NB>(wb, lw(0), RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, nullptr, wave, lane, prof, 0);
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(1), RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, nullptr, wave, lane, prof, 0);
+    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(2), RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, nullptr, wave, lane, prof, 0);
     {
         RsCoef<32, 17, 12, T, NB, false> rc;
         rc.load(wb + tab_i(wb, TABC + TABC_URS + 0), wb + tab_i(wb, TABC + TABC_URS + 1), lane);
         resample_stage<32, 17, 12, T, NB, false, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc, nosk, wave, lane);
         __syncthreads();
     }
-    layer_generic<32, 64, 12, true, false, T, NB>(wb, lw(3), RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, nullptr, wave, ln, prof, 0);
-    layer_generic<64, 64, 12, false, false, T, NB>(wb, lw(4), RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, nullptr, wave, ln, prof, 0);
+    layer_generic<32, 64, 12, true, false, T, NB>(wb, lw(3), RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, nullptr, wave, lane, prof, 0);
+    layer_generic<64, 64, 12, false, false, T, NB>(wb, lw(4), RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, nullptr, wave, lane, prof, 0);
     {
         RsCoef<64, 12, 10, T, NB, false> rc;
         rc.load(wb + tab_i(wb, TABC + TABC_URS + 2), wb + tab_i(wb, TABC + TABC_URS + 3), lane);
         resample_stage<64, 12, 10, T, NB, false, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc, nosk, wave, lane);
         __syncthreads();
     }
-    layer_generic<64, 128, 10, true, false, T, NB>(wb, lw(5), RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, nullptr, wave, ln, prof, 0);
-    layer_generic<128, 16, 10, true, false, T, NB>(wb, lw(6), RG + PL::L6_in, RG + PL::L6_p, RG + H_OFF, nullptr, wave, ln, prof, 0);
+    layer_generic<64, 128, 10, true, false, T, NB>(wb, lw(5), RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, nullptr, wave, lane, prof, 0);
+    layer_generic<128, 16, 10, true, false, T, NB>(wb, lw(6), RG + PL::L6_in, RG + PL::L6_p, RG + H_OFF, nullptr, wave, lane, prof, 0);
     // to_time_dim: emb[n][j] = b[j] + sum_k W[j][k] H[n][k], k = c*T*10 + t*10 + v.  thread = (n, j, part of 16)
     constexpr int F = CU_OUT * TV10;
     const float* H = RG + H_OFF;
@@ -1518,10 +1501,8 @@ int pack_gemm_frags(Builder& B, int M, int K, F&& w) {
     const int off = B.alloc((size_t)MTn * KQ * 64 * 4);
     for (int mt = 0; mt < MTn; ++mt) for (int kq = 0; kq < KQ; ++kq) for (int lane = 0; lane < 64; ++lane)
         for (int e = 0; e < 4; ++e) {
-            // lane (i, g): row 16mt + 4*pi(i/4) + i%4, k = 16kq + 4*pi(g) + e  (block permutation pi, see gemm_tiles)
-            const int i = lane & 15, g = lane >> 4;
-            const int row = mt * 16 + 4 * gemm_blk(i >> 2) + (i & 3);
-            B.buf[off + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)w(row, kq * 16 + 4 * gemm_blk(g) + e);
+            const int row = mt * 16 + (lane & 15), g = lane >> 4;
+            B.buf[off + ((size_t)(mt * KQ + kq) * 64 + lane) * 4 + e] = (float)w(row, kq * 16 + 4 * g + e);
         }
     return off;
 }
