@@ -704,13 +704,12 @@ struct Plan {
     static constexpr int UP3_out = 0;
     static constexpr int L7_in = 0, L7_z = s64b, L7_out = 2 * s64b;
     static constexpr int L8_in = 2 * s64b, L8_z = 0, L8_out = s64b;
-    static constexpr int UP2_out = s64b + s32b;
-    static constexpr int L9_in = s64b + s32b, L9_z = 0, L9_out = s32a;
+    static constexpr int UP2_out = cmax(s64b + s32b, 2 * s32a);      // behind layer 8's output and layer 9's (z, out)
+    static constexpr int L9_in = UP2_out, L9_z = 0, L9_out = s32a;
     static constexpr int L10_in = s32a, L10_p = 2 * s32a;
     static constexpr int R = cmax(cmax(cmax(s128 + 2 * s64c, 2 * s128), cmax(3 * s16 + 2 * s32a, 2 * s32b + 2 * s64b)),
-                                  cmax(3 * s64b, 3 * s32a));
-    static_assert(s32a <= 3 * s16 && s64b <= 2 * s32b && 2 * s32a <= s64b + s32b && s32a <= s64b && s64b <= s128,
-                  "LDS plan: regions would overlap");
+                                  cmax(cmax(3 * s64b, 3 * s32a), UP2_out + s32a));
+    static_assert(s32a <= 3 * s16 && s64b <= 2 * s32b && s32a <= s64b && s64b <= s128, "LDS plan: regions would overlap");
     static constexpr int XT = P17 * 4;
     static constexpr int EMB = NB * EMB_STRIDE;
     static constexpr int SE = 2 * 4 * 4 + 4 * EDIM;   // layer 10's embedding outputs, double-buffered by step parity: [2][NB<=4][4];
@@ -1557,7 +1556,9 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
             if (variant == 1) return launch_score_t<6, 2, 2>(P, st);
             return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
         case 12: return launch_score_t<12, 1, 2>(P, st);
-        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
+        case 4: return launch_score_t<4, 1, 4>(P, st);                 // e.g. seg_len 8 split in halves
+        case 8: return launch_score_t<8, 1, 2>(P, st);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
+        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 6, 8, 12)");
     }
 #endif
 }
@@ -1634,7 +1635,8 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (cfg->n_joints != 17) return fail(MCD_EUNSUPPORTED, "n_joints must be 17 (the reference U-Net hard-wires 17/12/10 joints)");
     if (cfg->emb_dim != EDIM) return fail(MCD_EUNSUPPORTED, "embedding_dim must be 16");
     const int T = cfg->t_unet;
-    if (T != 3 && T != 6 && T != 12) return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 6, 12)");
+    if (T != 3 && T != 4 && T != 6 && T != 8 && T != 12)
+        return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 6, 8, 12)");
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
 

@@ -87,6 +87,43 @@ def test_ragged_batch_vs_oracle(B):
     np.testing.assert_allclose(loss.cpu().numpy(), l_ref.t().numpy(), atol=ATOL, rtol=0)
 
 
+@pytest.mark.parametrize("strategy,seg_len,ci", [("inject", 8, 2), ("concat", 8, [0, 1, 2, 3]), ("inject", 12, 3)])
+def test_other_frame_counts_vs_oracle(strategy, seg_len, ci):
+    """U-Net frame counts 4 and 8 (seg_len 8 split in halves / concatenated; seg_len 12 with 4 condition frames), which no
+    reference-generated fixture covers: a randomly initialised model with perturbed BatchNorm statistics, HIP vs. oracle."""
+    from helpers import golden_weights, make_args
+    from mocodad_amd.models.mocodad import MoCoDAD
+    from oracle import mocodad_oracle as O
+    _, cfg = golden_weights("inject")
+    torch.manual_seed(5)
+    m = MoCoDAD(make_args(cfg, conditioning_strategy=strategy, seg_len=seg_len, conditioning_indices=ci, noise_steps=4,
+                          n_generated_samples=2))
+    gen = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=gen) + 0.5)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.1)
+        last = m.model.st_gcnnsu3[-1]              # keep the random eps-prediction O(1) over the chain
+        last.tcn[0].weight.mul_(0.25)
+        last.residual[0].weight.mul_(0.25)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda:0")
+    B, S, ns = 5, 2, 4
+    data = torch.randn(B, 2, seg_len, 17, generator=gen).clamp_(-3, 3)
+    Tx = m.n_frames_corrupt
+    noise = torch.randn(S, ns - 1, B, 2, Tx, 17, generator=gen)
+    batch = [data, torch.zeros(B), torch.zeros(B, 4), torch.zeros(B, seg_len)]
+    out = m.forward(batch, aggr_strategy="all", return_="all", noise=noise)
+    with torch.no_grad():
+        p_ref, corrupt = O.reverse_diffusion(sd, data, noise, noise_steps=ns, strategy=strategy, conditioning_indices=ci)
+        l_ref = O.window_losses(p_ref, corrupt)
+    np.testing.assert_allclose(out[1].cpu().numpy(), p_ref.transpose(0, 1).numpy(), atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(out[0].cpu().numpy(), l_ref.t().numpy(), atol=ATOL, rtol=0)
+
+
 def test_empty_batch():
     sc, _, _ = _scorer("inject")
     loss, poses = sc.score(torch.zeros(0, 2, 6, 17), n_samples=2, noise_steps=4, want_poses=True)
