@@ -113,7 +113,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    # under torch.distributed.run (LOCAL_RANK set) the RCCL path is used even with one rank, so a 1-process launch
+    # exercises exactly what the N-GPU launches do
+    use_dist = world > 1 or "LOCAL_RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -125,36 +128,38 @@ def main():
     # weak scaling: every rank owns its own shard of B windows per step (global window ids keep the
     # Philox streams distinct and independent of the number of GPUs)
     data = synth_windows(B, 6, 1000 + rank).to(dev)
-    gathered = torch.empty(world * B, device=dev, dtype=torch.float32) if world > 1 else None
-
-    def step(i):
-        loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=i, first_window_id=rank * B)
-        _, best = sc.aggregate(data, loss, None, "best", noise_steps=ns, want_pose=False)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, best)   # RCCL: reassemble per-window scores
+    # Window scores stay on their rank while the job runs; ONE all-gather after the last batch reassembles them before
+    # the AUC (SURVEY.md 8e, and what eval_MoCoDAD.py does) -- it is inside the timed region.
+    def run(n_steps, seed0, events=None):
+        # same buffer / collective size in the warm-up and in the timed run (no size-dependent lazy set-up inside the latter)
+        scores = torch.zeros(max(args.steps, n_steps), B, device=dev, dtype=torch.float32)
+        for i in range(n_steps):
+            if events is not None:
+                events[i][0].record()
+            loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=seed0 + i, first_window_id=rank * B)
+            if events is not None:
+                events[i][1].record()   # brackets the scoring launches (cond encoder + persistent kernel) on this stream
+            sc.aggregate(data, loss, None, "best", noise_steps=ns, want_pose=False, out=scores[i])
+        if use_dist:
+            gathered = torch.empty(world * scores.numel(), device=dev, dtype=torch.float32)
+            dist.all_gather_into_tensor(gathered, scores.view(-1))   # RCCL over xGMI
             return gathered
-        return best
+        return scores
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    if args.warmup > 0:
+        run(args.warmup, 0)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=100 + i, first_window_id=rank * B)
-        ev[i][1].record()   # brackets the scoring launches (cond encoder + persistent kernel) on this stream
-        _, best = sc.aggregate(data, loss, None, "best", noise_steps=ns, want_pose=False)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, best)
+    best = run(args.steps, 100, ev)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -191,7 +196,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, ns, S, args.cpu_budget)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

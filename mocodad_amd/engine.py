@@ -171,9 +171,10 @@ class HipScorer:
         return loss, poses
 
     def aggregate(self, data: torch.Tensor, loss_all: torch.Tensor, poses_all: Optional[torch.Tensor], strategy: str,
-                  *, noise_steps: int, loss_fn: str = "smooth_l1", want_pose: bool = True
-                  ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
-        """_aggregation_strategy of the reference on device -> (selected pose | None, loss (B,))."""
+                  *, noise_steps: int, loss_fn: str = "smooth_l1", want_pose: bool = True,
+                  out: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+        """_aggregation_strategy of the reference on device -> (selected pose | None, loss (B,)).
+        out: optional preallocated contiguous fp32 (B,) device tensor receiving the loss."""
         B, S = loss_all.shape
         q = 0.0
         name = strategy
@@ -190,7 +191,10 @@ class HipScorer:
             raise ValueError("the *_pose aggregation strategies need the materialised (B,C,T,V) windows")
         else:
             data = None
-        out = torch.empty(B, device=self.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(B, device=self.device, dtype=torch.float32)
+        elif out.shape != (B,) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float32 (B,) tensor on the scorer's device")
         gives_pose = name in ("best", "worst", "mean_pose", "median_pose")
         pose = None
         if gives_pose and want_pose and poses_all is not None:
