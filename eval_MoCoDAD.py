@@ -43,7 +43,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    use_dist = world > 1 or "LOCAL_RANK" in os.environ     # under torch.distributed.run: RCCL path even with one rank
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -67,6 +68,7 @@ def main():
         raise SystemExit("dataset files are read by the reference's own pipeline (utils/dataset.py); "
                          "pass --synthetic N here, or feed your DataLoader's batches to MoCoDAD.test_step")
 
+    torch.manual_seed(int(getattr(args, "seed", 0)))      # without a checkpoint every rank must draw the same weights
     model = MoCoDAD(args).to(dev)
     if cli.synthetic:
         model.dataset_name = "synthetic"      # synthetic clips have their own lengths: no HR-Avenue / UBnormal frame masks
@@ -78,7 +80,7 @@ def main():
 
     n = len(tw) if tw is not None else data.shape[0]
     shard = WindowShard(n, rank, world)
-    if world > 1:
+    if use_dist:
         shard.host_meta = (trans.numpy(), meta.numpy(), frames.numpy())
         model.shard = shard
     model.save_tensors = False
@@ -95,7 +97,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print(f"windows: {n}  gpus: {world}  time: {dt:.3f}s  ({n / dt:.0f} clips/s)  AUC: {auc:.6f}")
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
