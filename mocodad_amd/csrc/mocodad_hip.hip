@@ -712,11 +712,11 @@ struct Plan {
     static_assert(s32a <= 3 * s16 && s64b <= 2 * s32b && s32a <= s64b && s64b <= s128, "LDS plan: regions would overlap");
     static constexpr int XT = P17 * 4;
     static constexpr int EMB = NB * EMB_STRIDE;
-    static constexpr int SE = 2 * 4 * 4 + 4 * EDIM;   // layer 10's embedding outputs, double-buffered by step parity: [2][NB<=4][4];
+    static constexpr int EAUX = 2 * 4 * 4 + 4 * EDIM;   // layer 10's embedding outputs, double-buffered by step parity: [2][NB<=4][4];
                                                      // then SiLU(pe + cond) of the NEXT pass [NB<=4][16]
     static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
     static constexpr int WM = 4;                // per-chain condition-frame bitmask (NB <= 4 ints)
-    static constexpr int TOTAL = R + XT + EMB + SE + ZN + WM;
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     float* const EMB = XT + PL::XT;
     float* const E10 = EMB + PL::EMB;
     float* const SEN = E10 + 32;
-    float* const ZN = E10 + PL::SE;
+    float* const ZN = E10 + PL::EAUX;
     int* const WM = reinterpret_cast<int*>(ZN + PL::ZN);
 
     const int tid0 = threadIdx.x;
