@@ -17,7 +17,7 @@ from mocodad_amd.utils.model_utils import processing_data
 from oracle import mocodad_oracle as O
 
 
-@pytest.mark.parametrize("variant", ["inject", "concat", "T12", "injtail", "nocond", "encE"])
+@pytest.mark.parametrize("variant", ["inject", "concat", "T12", "injtail", "nocond", "encE", "encU", "imp2", "implist", "rndimp"])
 def test_state_dict_layout_matches_reference_checkpoint(variant):
     sd, cfg = golden_weights(variant)
     m = MoCoDAD(make_args(cfg))
@@ -99,6 +99,24 @@ def test_processing_data_concatenates_batches():
     ro = O.processing_data([a, b])
     for x, y in zip((out, gt, tr, meta, fr), ro):
         assert np.array_equal(x, y)
+
+
+def test_frame_splits_and_random_imp_masks_follow_the_reference():
+    """_frame_split for the imputation strategies, and the per-window frame sets of 'random_imp': the module draws one
+    torch.randperm per window on the default generator like _select_frames does (golden: sets the reference drew)."""
+    from conftest import load_golden
+    _, cfg = golden_weights("imp2")
+    assert MoCoDAD(make_args(cfg))._frame_split() == ([0, 2, 4], [1, 3, 5])
+    _, cfg = golden_weights("implist")
+    assert MoCoDAD(make_args(cfg))._frame_split() == ([1, 4], [0, 2, 3, 5])
+    _, cfg = golden_weights("rndimp")
+    m = MoCoDAD(make_args(cfg))
+    assert (m.n_frames_condition, m.n_frames_corrupt, m.input_n_frames) == (2, 4, 6)
+    g = load_golden("traj_rndimp_ns4_S2.npz")
+    torch.manual_seed(int(g["rng_seed"][0]))
+    mask = m.draw_random_imp_mask(g["data"].shape[0])
+    assert torch.equal(mask, torch.from_numpy(g["cond_mask"]))
+    assert all(bin(int(v)).count("1") == 2 for v in mask)
 
 
 def test_error_behaviour():
