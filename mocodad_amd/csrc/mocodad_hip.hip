@@ -975,9 +975,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // ---- su3.0, then su3.1 (32 -> 2) W-first: P = [W_t; W_r] M32 (4 useful rows), then the 2-channel mix with the PReLU,
         //      embedding, U-Net residual (+X) and the DDPM update fused into its store
         {
-            constexpr int NT = PL::P17 / 16;
             const LayerW lw = layer_w(wb, 10);
-            float4 afr[2];
             MixCoef<16, 17, T, NB> mc10;
             // next pass's embedding rows.  Unconditional (after the last pass the result is simply unused): a
             // conditionally loaded register struct costs ~35 VGPRs of phi copies here.
@@ -987,18 +985,38 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
                                     if constexpr (PF) {
-                                        load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
                                         mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
                                         ef_load();
                                     }
                                 }, nohook);                                                              // su3.0
             STAGE(16);
-            if constexpr (!PF) { load_afrags<1, 2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr); ef_load(); }
+            if constexpr (!PF) ef_load();
             float* Pb = RG + PL::L10_p;
-            gemm_tiles<1, NT, 2, 0, false>(afr, RG + PL::L10_in, 36, RG + PL::L10_in, 36, wave, lane,
-                                           [&](auto, int col, int c0, f32x4 acc) {
-                if (col < COLS17) *reinterpret_cast<float4*>(Pb + col * 20 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            });
+            // P[col][r] = sum_k W4[r][k] X[col][k] for the 4 useful rows (P_t 0,1 ; P_r 2,3) with plain FMAs: as a 16-row MFMA
+            // tile this product is 3/4 padding, and matrix-pipe time is what the kernel is short of.  wave = (row, block
+            // of 64 columns), weights as scalar operands, pad channels 4..15 of the mix input block zeroed by the row-0 waves.
+            {
+                const int r = wave & 3;
+                const cfloat* w4 = (const cfloat*)(wb + lw.wp + r * 32);
+                for (int cblk = wave >> 2; cblk * 64 < COLS17; cblk += NWAVES / 4) {
+                    const int col = cblk * 64 + lane;
+                    if (col < COLS17) {
+                        const float* xp = RG + PL::L10_in + col * 36;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float4 x = *reinterpret_cast<const float4*>(xp + 4 * q);
+                            acc = fmaf(w4[4 * q + 0], x.x, acc); acc = fmaf(w4[4 * q + 1], x.y, acc);
+                            acc = fmaf(w4[4 * q + 2], x.z, acc); acc = fmaf(w4[4 * q + 3], x.w, acc);
+                        }
+                        Pb[col * 20 + r] = acc;
+                        if (r == 0) {
+#pragma unroll
+                            for (int q = 1; q < 4; ++q) *reinterpret_cast<float4*>(Pb + col * 20 + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                }
+            }
             // next pass's U-Net input block: pad channels zeroed here, x written by the fused store below
             for (int u = tid; u < COLS17 * 4; u += NTHREADS)
                 *reinterpret_cast<float4*>(RG + PL::L0_in + (u >> 2) * 20 + (u & 3) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1681,7 +1699,13 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             if (wfirst) return r < D.cout ? wt(r, k) : (r < 2 * D.cout ? wr(r - D.cout, k) : 0.0);
             return k < cinp ? wt(r, k) : wr(r, k - cinp);
         };
-        U.L[l].wp = pack_gemm_frags(B, M, Kc, wcat);
+        if (l == 10) {
+            // layer 10's W-first product has 4 useful rows ([W_t' ; W_r'], 2 + 2): kept as plain rows for the FMA path
+            U.L[l].wp = B.alloc(4 * 32);
+            for (int r = 0; r < 4; ++r) for (int k = 0; k < 32; ++k) B.buf[U.L[l].wp + r * 32 + k] = (float)wcat(r, k);
+        } else {
+            U.L[l].wp = pack_gemm_frags(B, M, Kc, wcat);
+        }
     }
     static const char* rs_names[4] = {"down1", "down2", "up3", "up2"};
     static const int rs_in[4] = {17, 12, 10, 12}, rs_out[4] = {12, 10, 12, 17};
