@@ -107,15 +107,21 @@ __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
     return w;
 }
 
-// Optional in-kernel stage timing (build with -DMCD_PROFILE; tools/stage_profile.py): thread 0 of block 0
-// accumulates s_memtime deltas between stage boundaries into P.prof[stage].
+// Optional in-kernel stage timing (build with -DMCD_PROFILE; tools/stage_profile.py): thread 0 of block 0 adds the
+// s_memtime delta of each stage to an LDS accumulator (fire-and-forget ds_add: the timing wave never waits on global
+// memory for the instrumentation); the accumulators are written to P.prof[] when the kernel ends.
+constexpr int PROF_SLOTS = 96;
 struct Prof {
 #ifdef MCD_PROFILE
-    unsigned long long* p;
+    unsigned* acc;               // LDS, PROF_SLOTS words
     unsigned long long tlast;
     bool on;
     __device__ __forceinline__ void mark(int id) {
-        if (on) { const unsigned long long t = __builtin_readcyclecounter(); p[id] += t - tlast; tlast = t; }
+        if (on) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            __hip_atomic_fetch_add(acc + id, (unsigned)(t - tlast), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tlast = t;
+        }
     }
 #else
     __device__ __forceinline__ void mark(int) {}
@@ -337,10 +343,17 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
-            for (int mt = 0; mt < MTM; ++mt)
+            for (int mt = 0; mt < MTM; ++mt) {
+                // a store functor that takes the whole 4-joint fragment can issue all its LDS reads before its first
+                // write (row-by-row calls serialise: every write may alias the next row's reads)
+                if constexpr (std::is_invocable_v<Store, int, int, int, int, f32x4> && V >= 16 * (MTM > 0 ? MTM : 1)) {
+                    store(n, q0 + qi, mt * 16 + 4 * g, cb * 16 + j, acc[qi][mt]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (mt * 16 + 4 * g + r < V) store(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j, acc[qi][mt][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (mt * 16 + 4 * g + r < V) store(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j, acc[qi][mt][r]);
+                }
+            }
             if constexpr (J16) {
                 // sum the four lane groups' partials (lanes j, j+16, j+32, j+48): two register-swap steps
                 const unsigned u = __float_as_uint(part[qi]);
@@ -670,18 +683,15 @@ __device__ __forceinline__ void emb_row(const EmbRow& f, int o, const float* __r
         else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc;
     }
 }
-// thread tid owns output channel tid (row `f`, fetched ahead by the caller); the EMB_TOTAL - NTHREADS channels beyond
-// are done by the last wave, which has no tile in the GEMM stage this runs in
+// thread tid owns output channel tid (row `f`) and, for the EMB_TOTAL - NTHREADS channels beyond, tid + NTHREADS (row
+// `f2`, loaded by every thread with a clamped index: a conditionally loaded register struct costs phi copies)
+__device__ __forceinline__ int emb_row2(int tid) { return tid + NTHREADS < EMB_TOTAL ? tid + NTHREADS : EMB_TOTAL - 1; }
 template <int NB>
-__device__ __forceinline__ void emb_compute(const EmbRow& f, const float* wb, const float* __restrict__ se,
-                                            float* __restrict__ emb, float* __restrict__ e10, int tid, int wave) {
+__device__ __forceinline__ void emb_compute(const EmbRow& f, const EmbRow& f2, const float* __restrict__ se,
+                                            float* __restrict__ emb, float* __restrict__ e10, int tid) {
+    static_assert(EMB_TOTAL <= 2 * NTHREADS, "two rows per thread cover the embedding outputs");
     emb_row<NB>(f, tid, se, emb, e10);
-    if (wave == NWAVES - 1) {
-        const int o = NTHREADS + (tid & 63);
-        EmbRow g;
-        g.load(wb, o < EMB_TOTAL ? o : EMB_TOTAL - 1);
-        emb_row<NB>(g, o, se, emb, e10);
-    }
+    if (tid + NTHREADS < EMB_TOTAL) emb_row<NB>(f2, tid + NTHREADS, se, emb, e10);
 }
 
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
@@ -716,7 +726,14 @@ struct Plan {
                                                      // then SiLU(pe + cond) of the NEXT pass [NB<=4][16]
     static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
     static constexpr int WM = 4;                // per-chain condition-frame bitmask (NB <= 4 ints)
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM;
+    static constexpr int BIA = 64 + 16;         // biases of the two W-first layers (6: 64, 10: 2), read inside their store functors
+    static constexpr int UPD = 16;              // per (chain, U-Net frame): first column of the frame its prediction updates, or -1
+#ifdef MCD_PROFILE
+    static constexpr int PROF = PROF_SLOTS;
+#else
+    static constexpr int PROF = 0;
+#endif
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + PROF;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -737,6 +754,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     float* const SEN = E10 + 32;
     float* const ZN = E10 + PL::EAUX;
     int* const WM = reinterpret_cast<int*>(ZN + PL::ZN);
+    float* const BIA = reinterpret_cast<float*>(WM + PL::WM);
+    int* const UPD = reinterpret_cast<int*>(BIA + PL::BIA);
 
     const int tid0 = threadIdx.x;
     int tid = tid0;
@@ -749,6 +768,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         if (chain >= P.n_chains) chain = P.n_chains - 1;
         WM[threadIdx.x] = P.win_mask ? P.win_mask[chain / P.S] : P.fixed_mask;
     }
+    // biases the W-first layers add inside their mix store functors: from LDS there, not from global memory (a global
+    // load in a functor that also stores to LDS is re-issued per call: one L2 round trip per output row)
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + NB * T) {
+        // the prediction at frame t drives corrupt frame k = upd_of[t], which lives at frame pos_of[k] (the same frame except
+        // for 'concat' with the condition at the END of the window, where the reference reads the prediction at the corrupt
+        // frames' ORIGINAL indices, mocodad.py:829-838); with per-window frame sets (random_imp) every clear bit updates itself
+        const int i = threadIdx.x - 128, n = i / T, t = i % T;
+        int chain = chain0 + n;
+        if (chain >= P.n_chains) chain = P.n_chains - 1;
+        const int fixed = P.win_mask ? P.win_mask[chain / P.S] : P.fixed_mask;
+        const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
+        UPD[i] = k < 0 ? -1 : (n * T + (P.win_mask ? t : P.pos_of[k])) * 17;
+    }
+    if (threadIdx.x < 64) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 6 * F_STRIDE + F_BIAS) + threadIdx.x];
+    else if (threadIdx.x < 64 + C0) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 10 * F_STRIDE + F_BIAS) + threadIdx.x - 64];
     const int CTV = C0 * Tx * 17;          // elements of one generated pose
     const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
 
@@ -792,7 +826,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.p = P.prof; prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
+    prof.acc = reinterpret_cast<unsigned*>(UPD + PL::UPD);
+    if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
+    prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
     // U-Net skip tensors d1 / d2, register-resident between the down- and the up-samplers
     using RS1 = RsCfg<32, 17, 12, T, NB, true>;
@@ -814,15 +850,17 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
     };
     {
-        EmbRow er;
+        EmbRow er, er2;
         er.load(P.wbuf, tid0);
+        er2.load(P.wbuf, emb_row2(tid0));
         silu_row(i_first, tid0);
         __syncthreads();
-        emb_compute<NB>(er, P.wbuf, SEN, EMB, E10 + (i_first & 1) * 16, tid0, wave);
+        emb_compute<NB>(er, er2, SEN, EMB, E10 + (i_first & 1) * 16, tid0);
         __syncthreads();
     }
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
+        const float ca = srow[0], cb = srow[1], csg = srow[2];     // DDPM coefficients of this step, used by the last stage
         const float* wb = P.wbuf;
         asm volatile("" : "+s"(wb));   // opaque per step: offset-table loads stay inside the loop
         // same for the thread id: otherwise every per-lane LDS address of every stage is hoisted out of the
@@ -935,14 +973,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             }
             __syncthreads();
             STAGE(10);
-            gfloat* bias6 = as_global(wb + lw.bias);
             const float slope6 = lw.slope;
             if constexpr (!PF) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w, int c) { return Pb[((n * T + q) * 10 + w) * 132 + 64 + c]; },
                                      [&](int n, int q, int w, int c, float v) {
                                          Pb[((n * T + q) * 10 + w) * 132 + 64 + c] =
-                                             prelu(v + bias6[c], slope6) + EMB[n * EMB_STRIDE + emb_off(6) + c];
+                                             prelu(v + BIA[c], slope6) + EMB[n * EMB_STRIDE + emb_off(6) + c];
                                      });
         }
         RsCoef<64, 10, 12, T, NB, false> rc3;
@@ -991,6 +1028,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                 }, nohook);                                                              // su3.0
             STAGE(16);
             if constexpr (!PF) ef_load();
+            EmbRow ef2;                                   // the 20 rows beyond the first NTHREADS: fetched here, used after
+            ef2.load(wb, emb_row2(tid));                  // the FMA product below
             float* Pb = RG + PL::L10_p;
             // P[col][r] = sum_k W4[r][k] X[col][k] for the 4 useful rows (P_t 0,1 ; P_r 2,3) with plain FMAs: as a 16-row MFMA
             // tile this product is 3/4 padding, and matrix-pipe time is what the kernel is short of.  wave = (row, block
@@ -1017,52 +1056,63 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     }
                 }
             }
+            STAGE(18);
             // next pass's U-Net input block: pad channels zeroed here, x written by the fused store below
             for (int u = tid; u < COLS17 * 4; u += NTHREADS)
                 *reinterpret_cast<float4*>(RG + PL::L0_in + (u >> 2) * 20 + (u & 3) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             // next pass's embeddings: layers 0..9 straight into EMB (dead by now), layer 10's into the other E10 half
-            emb_compute<NB>(ef, wb, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid, wave);
+            emb_compute<NB>(ef, ef2, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid);
+            STAGE(19);
             __syncthreads();
-            const float ca = srow[0], cb = srow[1], csg = srow[2];
-            gfloat* bias = as_global(wb + lw.bias);
+            STAGE(20);
             const float slope10 = lw.slope;
+            const bool single = P.mode == 1, zadd = sidx > 1;
+            const int e10_off = (sidx & 1) * 16;
             if constexpr (!PF) mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
             mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      [](int, int, int, int) { return 0.f; },
-                                     [&](int n, int t, int v, int c, float val) {
+                                     [&](int n, int t, int v0, int c, auto vals) {
+                // vals: one joint (float: joint 16) or the 4 joints v0..v0+3 of an MFMA fragment (f32x4)
+                constexpr int NR = std::is_same_v<decltype(vals), float> ? 1 : 4;
                 if (c < C0) {
-                    const int col = (n * T + t) * 17 + v;
-                    int chain = chain0 + n;
-                    const bool valid = chain < P.n_chains;
-                    if (!valid) chain = P.n_chains - 1;
-                    const int b = chain / P.S;
-                    const float x = XT[col * 4 + c];
-                    const float eps = prelu(val + Pb[col * 20 + C0 + c] + bias[c], slope10) +
-                                      E10[(sidx & 1) * 16 + n * 4 + c] + x;
-                    if (P.mode == 1) {
-                        if (valid) P.eps_out[((b * C0 + c) * T + t) * 17 + v] = eps;
-                    } else {
-                        const int fixed = WM[n];
-                        if ((fixed >> t) & 1) RG[PL::L0_in + col * 20 + c] = x;
-                        // the prediction at frame t drives corrupt frame k = upd_of[t], which lives at frame pos_of[k]
-                        // (the same frame except for 'concat' with the condition at the END of the window, where the
-                        // reference reads the prediction at the corrupt frames' ORIGINAL indices, mocodad.py:829-838)
-                        const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
-                        if (k >= 0) {
-                            const int colp = (n * T + (P.win_mask ? t : P.pos_of[k])) * 17 + v;
-                            const float xo = XT[colp * 4 + c];
-                            const float z = sidx > 1 ? ZN[colp * C0 + c] : 0.f;
-                            const float xn = ca * (xo - cb * eps) + csg * z;
-                            XT[colp * 4 + c] = xn;
-                            RG[PL::L0_in + colp * 20 + c] = xn;
+                    float val[NR], x[NR], pr[NR], xo[NR], z[NR];
+                    if constexpr (NR == 1) val[0] = vals; else for (int r = 0; r < 4; ++r) val[r] = vals[r];
+                    const int col0 = (n * T + t) * 17 + v0;
+                    const int cbase = single ? -1 : UPD[n * T + t];
+                    const bool fixed = (WM[n] >> t) & 1;
+                    const float bias = BIA[64 + c], e = E10[e10_off + n * 4 + c];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {        // every LDS read first ...
+                        x[r] = XT[(col0 + r) * 4 + c];
+                        pr[r] = Pb[(col0 + r) * 20 + C0 + c];
+                        xo[r] = cbase >= 0 ? XT[(cbase + v0 + r) * 4 + c] : 0.f;
+                        z[r] = (cbase >= 0 && zadd) ? ZN[(cbase + v0 + r) * C0 + c] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {        // ... then the writes
+                        const float eps = prelu(val[r] + pr[r] + bias, slope10) + e + x[r];
+                        if (single) {
+                            const int chain = chain0 + n;
+                            if (chain < P.n_chains) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v0 + r] = eps;
+                        } else {
+                            if (fixed) RG[PL::L0_in + (col0 + r) * 20 + c] = x[r];     // condition frame: copied to the next pass's input
+                            if (cbase >= 0) {
+                                const float xn = ca * (xo[r] - cb * eps) + csg * z[r];
+                                XT[(cbase + v0 + r) * 4 + c] = xn;
+                                RG[PL::L0_in + (cbase + v0 + r) * 20 + c] = xn;
+                            }
                         }
                     }
                 }
             });
+            STAGE(21);
             __syncthreads();
             STAGE(17);
         }
     }
+#ifdef MCD_PROFILE
+    if (prof.on) for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];    // thread 0's own ds_adds: in order
+#endif
     if (P.mode == 1) return;
 
     // ---- per-chain loss: mean over (C, Tx, V) of loss_fn(x_0 - corrupt)   (mocodad.py:484)
@@ -1130,7 +1180,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
     const int b0 = blockIdx.x * NB;
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.on = false; prof.p = nullptr; prof.tlast = 0;
+    prof.on = false; prof.acc = nullptr; prof.tlast = 0;
 #endif
     for (int u = tid; u < 2 * s16 + 2 * s32; u += NTHREADS) smem[u] = 0.f;
     __syncthreads();
@@ -1196,7 +1246,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
     const int b0 = blockIdx.x * NB;
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.on = false; prof.p = nullptr; prof.tlast = 0;
+    prof.on = false; prof.acc = nullptr; prof.tlast = 0;
 #endif
     for (int u = tid; u < CondUnetLds<T, NB>::FLOATS; u += NTHREADS) smem[u] = 0.f;
     __syncthreads();

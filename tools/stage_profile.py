@@ -33,13 +33,15 @@ L.mcd_debug_set_prof(C.c_void_p(prof.data_ptr()))
 sc.score(data, n_samples=5, noise_steps=10, seed=1)
 torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(float)
-names = ["SE + X20 expand", "emb table (MFMA)", "L0 sp1a", "L1 sd1.0", "L2 sd1.1", "down1", "L3 sd2.0", "L4 sd2.1", "down2", "L5 sd3.0",
-         "L6 gemm(P)", "L6 mix+epi", "up3+skip", "L7 su4.0", "L8 su4.1", "up2+skip", "L9 su3.0", "L10+ddpm"]
+names = ["pass prologue", "-", "L0 sp1a", "L1 sd1.0", "L2 sd1.1", "down1", "L3 sd2.0", "L4 sd2.1", "down2", "L5 sd3.0",
+         "L6 gemm(P)", "L6 mix+epi(+up3)", "up3+skip", "L7 su4.0", "L8 su4.1", "up2+skip", "L9 su3.0", "L10+ddpm"]
 sub = p[32:32 + 33].reshape(11, 3)   # per layer: mix, gemm (epilogue time is accounted to the stage ids below)
 for l in range(11):
     if sub[l, :2].sum() > 0:
         idx = {0: 2, 1: 3, 2: 4, 3: 6, 4: 7, 5: 9, 7: 13, 8: 14, 9: 16}[l]
         p[idx] += sub[l, 0] + sub[l, 1]
+sub10 = p[18:22].copy()        # layer 10: FMA product | x-block zeroing + next pass's embeddings | barrier | mix + DDPM store (then barrier = p[17])
+p[17] += sub10.sum()
 tot = p[:18].sum()
 print(f"variant={os.environ.get('MCD_VARIANT','0')}  cycles per pass (9 passes): total {tot/9:.0f}")
 lay = {2: 0, 3: 1, 4: 2, 6: 3, 7: 4, 9: 5, 13: 7, 14: 8, 16: 9}
@@ -48,4 +50,6 @@ for i, (n, v) in enumerate(zip(names, p)):
     if i in lay:
         l = lay[i]
         extra = f"   mix {sub[l,0]/9:7.0f}  gemm {sub[l,1]/9:7.0f}  epilogue {(v - sub[l,0] - sub[l,1])/9:7.0f}"
+    if i == 17:
+        extra = f"   product {sub10[0]/9:6.0f}  zero+emb {sub10[1]/9:6.0f}  barrier {sub10[2]/9:6.0f}  mix+ddpm {sub10[3]/9:6.0f}  barrier {(v - sub10.sum())/9:6.0f}"
     print(f"  {n:14s} {v/9:9.0f}  {100*v/tot:5.1f}%{extra}")
