@@ -346,7 +346,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             for (int mt = 0; mt < MTM; ++mt) {
                 // a store functor that takes the whole 4-joint fragment can issue all its LDS reads before its first
                 // write (row-by-row calls serialise: every write may alias the next row's reads)
-                if constexpr (std::is_invocable_v<Store, int, int, int, int, f32x4> && V >= 16 * (MTM > 0 ? MTM : 1)) {
+                if constexpr (std::is_invocable_v<Store, int, int, int, int, f32x4>) {     // (the functor masks joints >= V)
                     store(n, q0 + qi, mt * 16 + 4 * g, cb * 16 + j, acc[qi][mt]);
                 } else {
 #pragma unroll
@@ -453,12 +453,30 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     const int j = lane & 15, g = lane >> 4;
     const auto& aop = rc.aop;
     const auto& bias = rc.bias;
+    // all the X reads of this wave's units first (for the down-samplers they ARE the skip registers): a unit's stores
+    // may alias the next unit's reads, so reading inside the unit loop would serialise the units on LDS latency
+    float xr[PER][KS];
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
         if (u < UNITS) {
             const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
             const float* xin = in + (nt * VIN) * cs_in + cb * 16 + j;
+            static_for<KS>([&](auto si) {
+                constexpr int ks = decltype(si)::value;
+                int row;
+                if (CAPTURE) row = ks < 4 ? 4 * g + ks : 16 + g;
+                else row = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 4 * KP + g;
+                xr[i][ks] = xin[row * cs_in];
+                if constexpr (CAPTURE) skip[i * SK + ks] = xr[i][ks];
+            });
+        }
+    });
+    static_for<PER>([&](auto pi) {
+        constexpr int i = decltype(pi)::value;
+        const int u = wave + i * NWAVES;
+        if (u < UNITS) {
+            const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
             // VOUT = 17: output joint 16 on the VALU (partial sums per lane group, permlane-swap reduction) instead of a
             // second m-tile with one useful row -- same trade as in mix_stage
             constexpr bool J16 = VOUT == 17;
@@ -469,11 +487,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             for (int mt = 0; mt < MTM; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
             static_for<KS>([&](auto si) {
                 constexpr int ks = decltype(si)::value;
-                int row;
-                if (CAPTURE) row = ks < 4 ? 4 * g + ks : 16 + g;
-                else row = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 4 * KP + g;
-                const float x = xin[row * cs_in];
-                if constexpr (CAPTURE) skip[i * SK + ks] = x;
+                const float x = xr[i][ks];
 #pragma unroll
                 for (int mt = 0; mt < MTM; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
                 if constexpr (J16) part = fmaf(aop[1][ks], x, part);
@@ -728,12 +742,13 @@ struct Plan {
     static constexpr int WM = 4;                // per-chain condition-frame bitmask (NB <= 4 ints)
     static constexpr int BIA = 64 + 16;         // biases of the two W-first layers (6: 64, 10: 2), read inside their store functors
     static constexpr int UPD = 16;              // per (chain, U-Net frame): first column of the frame its prediction updates, or -1
+    static constexpr int ZO = P17 * 2;          // layer 10's mixed output Z[col][c] between its mix and the element-wise tail
 #ifdef MCD_PROFILE
     static constexpr int PROF = PROF_SLOTS;
 #else
     static constexpr int PROF = 0;
 #endif
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + PROF;
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + PROF;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -756,6 +771,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int* const WM = reinterpret_cast<int*>(ZN + PL::ZN);
     float* const BIA = reinterpret_cast<float*>(WM + PL::WM);
     int* const UPD = reinterpret_cast<int*>(BIA + PL::BIA);
+    float* const ZO = reinterpret_cast<float*>(UPD + PL::UPD);
 
     const int tid0 = threadIdx.x;
     int tid = tid0;
@@ -826,7 +842,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.acc = reinterpret_cast<unsigned*>(UPD + PL::UPD);
+    prof.acc = reinterpret_cast<unsigned*>(ZO + PL::ZO);
     if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
@@ -977,9 +993,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if constexpr (!PF) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w, int c) { return Pb[((n * T + q) * 10 + w) * 132 + 64 + c]; },
-                                     [&](int n, int q, int w, int c, float v) {
-                                         Pb[((n * T + q) * 10 + w) * 132 + 64 + c] =
-                                             prelu(v + BIA[c], slope6) + EMB[n * EMB_STRIDE + emb_off(6) + c];
+                                     [&](int n, int q, int w0, int c, f32x4 v) {       // the fragment's 4 joints at once
+                                         const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
+#pragma unroll
+                                         for (int r = 0; r < 4; ++r)
+                                             if (w0 + r < 10)
+                                                 Pb[((n * T + q) * 10 + w0 + r) * 132 + 64 + c] = prelu(v[r] + bias, slope6) + e;
                                      });
         }
         RsCoef<64, 10, 12, T, NB, false> rc3;
@@ -1071,40 +1090,33 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if constexpr (!PF) mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
             mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      [](int, int, int, int) { return 0.f; },
-                                     [&](int n, int t, int v0, int c, auto vals) {
-                // vals: one joint (float: joint 16) or the 4 joints v0..v0+3 of an MFMA fragment (f32x4)
-                constexpr int NR = std::is_same_v<decltype(vals), float> ? 1 : 4;
-                if (c < C0) {
-                    float val[NR], x[NR], pr[NR], xo[NR], z[NR];
-                    if constexpr (NR == 1) val[0] = vals; else for (int r = 0; r < 4; ++r) val[r] = vals[r];
-                    const int col0 = (n * T + t) * 17 + v0;
-                    const int cbase = single ? -1 : UPD[n * T + t];
-                    const bool fixed = (WM[n] >> t) & 1;
-                    const float bias = BIA[64 + c], e = E10[e10_off + n * 4 + c];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {        // every LDS read first ...
-                        x[r] = XT[(col0 + r) * 4 + c];
-                        pr[r] = Pb[(col0 + r) * 20 + C0 + c];
-                        xo[r] = cbase >= 0 ? XT[(cbase + v0 + r) * 4 + c] : 0.f;
-                        z[r] = (cbase >= 0 && zadd) ? ZN[(cbase + v0 + r) * C0 + c] : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {        // ... then the writes
-                        const float eps = prelu(val[r] + pr[r] + bias, slope10) + e + x[r];
-                        if (single) {
-                            const int chain = chain0 + n;
-                            if (chain < P.n_chains) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v0 + r] = eps;
-                        } else {
-                            if (fixed) RG[PL::L0_in + (col0 + r) * 20 + c] = x[r];     // condition frame: copied to the next pass's input
-                            if (cbase >= 0) {
-                                const float xn = ca * (xo[r] - cb * eps) + csg * z[r];
-                                XT[(cbase + v0 + r) * 4 + c] = xn;
-                                RG[PL::L0_in + (cbase + v0 + r) * 20 + c] = xn;
-                            }
-                        }
+                                     [&](int n, int t, int v, int c, float val) {
+                                         if (c < C0) ZO[((n * T + t) * 17 + v) * C0 + c] = val;
+                                     });
+            __syncthreads();
+            // element-wise tail of the pass, one (column, coordinate) per thread: eps = PReLU(mix(P_t) + P_r + b) + e + x
+            // (layer 10 + the U-Net's residual), then the DDPM update of the frame this prediction drives and the next
+            // pass's input block.  (Inside the mix's store functor this ran on 2 of every 16 lanes of 6 waves.)
+            for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
+                const int c = u % C0, col = u / C0;
+                const int n = col / TV17, t = (col / 17) % T, v = col % 17;
+                const float x = XT[col * 4 + c];
+                const float eps = prelu(ZO[u] + Pb[col * 20 + C0 + c] + BIA[64 + c], slope10) + E10[e10_off + n * 4 + c] + x;
+                if (single) {
+                    const int chain = chain0 + n;
+                    if (chain < P.n_chains) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v] = eps;
+                } else {
+                    if ((WM[n] >> t) & 1) RG[PL::L0_in + col * 20 + c] = x;     // condition frame: copied to the next pass's input
+                    const int cbase = UPD[n * T + t];
+                    if (cbase >= 0) {
+                        const int colp = cbase + v;
+                        const float z = zadd ? ZN[colp * C0 + c] : 0.f;
+                        const float xn = ca * (XT[colp * 4 + c] - cb * eps) + csg * z;
+                        XT[colp * 4 + c] = xn;
+                        RG[PL::L0_in + colp * 20 + c] = xn;
                     }
                 }
-            });
+            }
             STAGE(21);
             __syncthreads();
             STAGE(17);
