@@ -455,7 +455,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     const auto& bias = rc.bias;
     // all the X reads of this wave's units first (for the down-samplers they ARE the skip registers): a unit's stores
     // may alias the next unit's reads, so reading inside the unit loop would serialise the units on LDS latency
-    float xr[PER][KS];
+    float xr[CAPTURE ? 1 : PER][CAPTURE ? 1 : KS];      // (the down-samplers read straight into `skip`)
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
@@ -467,8 +467,8 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
                 int row;
                 if (CAPTURE) row = ks < 4 ? 4 * g + ks : 16 + g;
                 else row = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 4 * KP + g;
-                xr[i][ks] = xin[row * cs_in];
-                if constexpr (CAPTURE) skip[i * SK + ks] = xr[i][ks];
+                if constexpr (CAPTURE) skip[i * SK + ks] = xin[row * cs_in];
+                else xr[i][ks] = xin[row * cs_in];
             });
         }
     });
@@ -487,7 +487,8 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             for (int mt = 0; mt < MTM; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
             static_for<KS>([&](auto si) {
                 constexpr int ks = decltype(si)::value;
-                const float x = xr[i][ks];
+                float x;
+                if constexpr (CAPTURE) x = skip[i * SK + ks]; else x = xr[i][ks];
 #pragma unroll
                 for (int mt = 0; mt < MTM; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
                 if constexpr (J16) part = fmaf(aop[1][ks], x, part);
@@ -565,25 +566,26 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
                 c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
             }
             const float* p1 = b1 + col * cs1 + 4 * g;
-#pragma unroll
-            for (int kq = 0; kq < KQ1; ++kq) {
-                const float4 u = *reinterpret_cast<const float4*>(p1 + kq * 16);   // one ds_read_b128 = 4 k-steps
+            const float* p2 = b2 + col * cs2 + 4 * g;
+            // B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH reads ahead of the MFMAs that consume them: read
+            // right before its use each fragment exposes an LDS round trip per 4 MFMAs on this wave's matrix-pipe stream
+            constexpr int KQ = KQ1 + KQ2;
+            constexpr int DEPTH = KQ < 3 ? KQ : 3;
+            auto rd = [&](auto kk) {
+                constexpr int kq = decltype(kk)::value;
+                return *reinterpret_cast<const float4*>(kq < KQ1 ? p1 + kq * 16 : p2 + (kq - KQ1) * 16);
+            };
+            float4 buf[DEPTH];
+            static_for<DEPTH>([&](auto dd) { buf[decltype(dd)::value] = rd(dd); });
+            static_for<KQ>([&](auto kk) {
+                constexpr int kq = decltype(kk)::value;
+                const float4 u = buf[kq % DEPTH];
+                if constexpr (kq + DEPTH < KQ) buf[kq % DEPTH] = rd(std::integral_constant<int, kq + DEPTH>{});
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u.z, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u.w, c, 0, 0, 0);
-            }
-            if (KQ2 > 0) {
-                const float* p2 = b2 + col * cs2 + 4 * g;
-#pragma unroll
-                for (int kq = 0; kq < KQ2; ++kq) {
-                    const float4 u = *reinterpret_cast<const float4*>(p2 + kq * 16);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].x, u.x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].y, u.y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].z, u.z, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[KQ1 + kq].w, u.w, c, 0, 0, 0);
-                }
-            }
+            });
             epi(ii, col, c0, c);
         }
     });
@@ -876,7 +878,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
-        const float ca = srow[0], cb = srow[1], csg = srow[2];     // DDPM coefficients of this step, used by the last stage
         const float* wb = P.wbuf;
         asm volatile("" : "+s"(wb));   // opaque per step: offset-table loads stay inside the loop
         // same for the thread id: otherwise every per-lane LDS address of every stage is hoisted out of the
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         constexpr bool NZ_TAIL = MixCfg<16, 17, T, NB>::UNITS <= NWAVES - 2;
         constexpr int NZ_T0 = NZ_TAIL ? NTHREADS - 128 : 0, NZ_N = NZ_TAIL ? 128 : NTHREADS;
         if (P.mode == 0 && sidx > 1 && tid >= NZ_T0) {
+#pragma unroll 1
             for (int u = tid - NZ_T0; u < COLS17 * C0; u += NZ_N) {
                 const int c = u % C0, col = u / C0;
                 const int n = col / TV17, t = (col / 17) % T, v = col % 17;
@@ -1047,6 +1049,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                 }, nohook);                                                              // su3.0
             STAGE(16);
             if constexpr (!PF) ef_load();
+            const float ca = srow[0], cb = srow[1], csg = srow[2];     // DDPM coefficients of this step (used two stages on)
             EmbRow ef2;                                   // the 20 rows beyond the first NTHREADS: fetched here, used after
             ef2.load(wb, emb_row2(tid));                  // the FMA product below
             float* Pb = RG + PL::L10_p;
@@ -1633,8 +1636,8 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
             if (variant == 3) return launch_score_t<3, 1, 4>(P, st);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
             return launch_score_t<3, 2, 4>(P, st);                     // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
         case 6:
-            if (variant == 1) return launch_score_t<6, 2, 2>(P, st);
-            return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
+            if (variant == 1) return launch_score_t<6, 1, 4>(P, st);   // 1 chain / WG, 2 WGs per CU: spills ~30 VGPRs, 3 % slower
+            return launch_score_t<6, 2, 2>(P, st);                     // 2 chains / WG, 1 WG per CU (no register cap)
         case 12: return launch_score_t<12, 1, 2>(P, st);
         case 4: return launch_score_t<4, 1, 4>(P, st);                 // e.g. seg_len 8 split in halves
         case 8: return launch_score_t<8, 1, 2>(P, st);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
