@@ -297,11 +297,23 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
     constexpr int KS = M::KS, KP = M::KP, MT = M::MT, CB = M::CB, QC = M::QC, NQ = M::NQ, UNITS = M::UNITS, PER = M::PER;
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
-    auto unit = [&](const MixCoef<CIN, V, T, NB>& cur, int u) {
-        const int q0 = (u % NQ) * QC, rest = u / NQ;
+    // the X values of one unit: x[ks][t] = X[(n, t, joint of (ks, lane group))][channel cb*16 + j]
+    auto load_x = [&](int u, float (&x)[KS][T]) {
+        const int rest = u / NQ;
         const int cb = rest % CB, n = rest / CB;
         const float* xin_p = in + (n * T * V + voff_pair) * cs_in + cb * 16 + j;
         const float* xin_l = in + (n * T * V + g) * cs_in + cb * 16 + j;
+        static_for<KS>([&](auto si) {
+            constexpr int ks = decltype(si)::value;
+            constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
+            const float* xb = ks < KP ? xin_p : xin_l;
+#pragma unroll
+            for (int t = 0; t < T; ++t) x[ks][t] = xb[(t * V + vbase) * cs_in];
+        });
+    };
+    auto unit = [&](const MixCoef<CIN, V, T, NB>& cur, int u, const float (&xs)[KS][T]) {
+        const int q0 = (u % NQ) * QC, rest = u / NQ;
+        const int cb = rest % CB, n = rest / CB;
         // V = 17: output joint 16 would cost a whole second m-tile (15/16 wasted, and the kernel is bound by matrix-pipe
         // time); it is accumulated with plain FMAs instead -- 5 per frame, partial sums over this lane group's joints
         constexpr bool J16 = V == 17;
@@ -321,11 +333,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         }
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
-            constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
-            const float* xb = ks < KP ? xin_p : xin_l;
-            float x[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) x[t] = xb[(t * V + vbase) * cs_in];
+            const float (&x)[T] = xs[ks];
             static_for<QC>([&](auto qq) {
                 constexpr int qi = decltype(qq)::value;
                 // y = sum_t X[t, v] * T[v, t, q]   (coefficient (ks,t) = lane ks*T+t of this DPP row)
@@ -367,13 +375,21 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
     };
     // later rounds: coefficients fetched one round ahead where the register budget allows (T = 3), else in place
     if constexpr (T == 3) {
+        // every round's X reads up front as well: a round's stores may alias the next round's reads, which would
+        // otherwise wait for them (one LDS round trip per round on the wave's serial path)
+        float xs[PER][KS][T];
+        static_for<PER>([&](auto ri) {
+            constexpr int rnd = decltype(ri)::value;
+            const int u = wave + rnd * NWAVES;
+            load_x(u < UNITS ? u : UNITS - 1, xs[rnd]);
+        });
         MixCoef<CIN, V, T, NB> cur = pre;
         static_for<PER>([&](auto ri) {
             constexpr int rnd = decltype(ri)::value;
             const int u = wave + rnd * NWAVES;
             MixCoef<CIN, V, T, NB> nxt;
             if constexpr (rnd + 1 < PER) nxt.load(tqd, af, u + NWAVES, lane);
-            if (u < UNITS) unit(cur, u);
+            if (u < UNITS) unit(cur, u, xs[rnd]);
             if constexpr (rnd + 1 < PER) cur = nxt;
         });
     } else {
@@ -381,7 +397,9 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
 #pragma unroll 1
         for (int u = wave; u < UNITS; u += NWAVES) {
             if (u != wave) cur.load(tqd, af, u, lane);
-            unit(cur, u);
+            float xs[KS][T];
+            load_x(u, xs);
+            unit(cur, u, xs);
         }
     }
 }

@@ -51,5 +51,5 @@ for i, (n, v) in enumerate(zip(names, p)):
         l = lay[i]
         extra = f"   mix {sub[l,0]/9:7.0f}  gemm {sub[l,1]/9:7.0f}  epilogue {(v - sub[l,0] - sub[l,1])/9:7.0f}"
     if i == 17:
-        extra = f"   product {sub10[0]/9:6.0f}  zero+emb {sub10[1]/9:6.0f}  barrier {sub10[2]/9:6.0f}  mix+ddpm {sub10[3]/9:6.0f}  barrier {(v - sub10.sum())/9:6.0f}"
+        extra = f"   product {sub10[0]/9:6.0f}  zero+emb {sub10[1]/9:6.0f}  barrier {sub10[2]/9:6.0f}  mix+barrier+tail {sub10[3]/9:6.0f}  barrier {(v - sub10.sum())/9:6.0f}"
     print(f"  {n:14s} {v/9:9.0f}  {100*v/tot:5.1f}%{extra}")
