@@ -265,6 +265,20 @@ struct MixCfg {
     static constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
     static constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;   // rounds
     static constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
+    // 12 single-frame units on 8 waves (the 32-channel layers at T = 3, NB = 2): four waves take two units.  SAMEQ gives
+    // those waves two units of the SAME output frame -- waves 0-3: frame w/2, groups 2(w&1) + round; waves 4-7: frame 2,
+    // group w-4 -- so the coefficients (which depend on the frame only) serve both rounds and nothing is fetched mid-stage
+    static constexpr bool SAMEQ = QC == 1 && NQ == 3 && UNITS == 12 && NWAVES == 8;
+    // unit (frame chunk index, group = chain * CB + channel block) of (wave, round); u < 0: none
+    __device__ static __forceinline__ int unit_of(int wave, int round) {
+        if constexpr (SAMEQ) {
+            if (wave < 4) return (wave >> 1) + NQ * ((wave & 1) * 2 + round);
+            return round == 0 ? 2 + NQ * (wave - 4) : -1;
+        } else {
+            const int u = wave + round * NWAVES;
+            return u < UNITS ? u : -1;
+        }
+    }
 };
 // time-mix rows + joint-mix A fragments of one unit.  Loaded one stage ahead of their use (behind the barrier of the
 // previous stage their ~L2 latency would sit on the critical path of every mix).
@@ -272,10 +286,14 @@ template <int CIN, int V, int T, int NB>
 struct MixCoef {
     using M = MixCfg<CIN, V, T, NB>;
     float tq[M::QC][M::NR], aop[M::QC][M::MT][M::KS];
-    __device__ __forceinline__ void load(const float* tqd, const float* af, int u, int lane) {
+    // the coefficients of the wave's first unit
+    __device__ __forceinline__ void load(const float* tqd, const float* af, int wave, int lane) {
+        load_unit(tqd, af, M::unit_of(wave, 0), lane);
+    }
+    __device__ __forceinline__ void load_unit(const float* tqd, const float* af, int u, int lane) {
         gfloat* tqd_g = as_global(tqd);
         gfloat* af_g = as_global(af);
-        const int uc = u < M::UNITS ? u : M::UNITS - 1;
+        const int uc = u < 0 ? 0 : (u < M::UNITS ? u : M::UNITS - 1);
         const int q0 = (uc % M::NQ) * M::QC;
 #pragma unroll
         for (int qi = 0; qi < M::QC; ++qi) {
@@ -380,23 +398,23 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         float xs[PER][KS][T];
         static_for<PER>([&](auto ri) {
             constexpr int rnd = decltype(ri)::value;
-            const int u = wave + rnd * NWAVES;
-            load_x(u < UNITS ? u : UNITS - 1, xs[rnd]);
+            const int u = M::unit_of(wave, rnd);
+            load_x(u < 0 ? 0 : u, xs[rnd]);
         });
         MixCoef<CIN, V, T, NB> cur = pre;
         static_for<PER>([&](auto ri) {
             constexpr int rnd = decltype(ri)::value;
-            const int u = wave + rnd * NWAVES;
+            const int u = M::unit_of(wave, rnd);
             MixCoef<CIN, V, T, NB> nxt;
-            if constexpr (rnd + 1 < PER) nxt.load(tqd, af, u + NWAVES, lane);
-            if (u < UNITS) unit(cur, u, xs[rnd]);
-            if constexpr (rnd + 1 < PER) cur = nxt;
+            if constexpr (rnd + 1 < PER && !M::SAMEQ) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
+            if (u >= 0) unit(cur, u, xs[rnd]);
+            if constexpr (rnd + 1 < PER && !M::SAMEQ) cur = nxt;
         });
     } else {
         MixCoef<CIN, V, T, NB> cur = pre;     // one copy of the unit body: these shapes are I-cache bound
 #pragma unroll 1
         for (int u = wave; u < UNITS; u += NWAVES) {
-            if (u != wave) cur.load(tqd, af, u, lane);
+            if (u != wave) cur.load_unit(tqd, af, u, lane);
             float xs[KS][T];
             load_x(u, xs);
             unit(cur, u, xs);
