@@ -912,6 +912,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         emb_compute<NB>(er, er2, SEN, EMB, E10 + (i_first & 1) * 16, tid0);
         __syncthreads();
     }
+    LMix<0, T, NB> mc0;                              // layer 0's mix coefficients: fetched one stage ahead like all the others,
+    mc0.load(P.wbuf + tab_i(P.wbuf, F_TQ), P.wbuf + tab_i(P.wbuf, F_AM), wave, lane);   // i.e. in the last stage of the previous pass
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
         const float* wb = P.wbuf;
@@ -922,9 +924,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // ---- step prologue: layer-0 mix coefficients and this step's noise z
-        LMix<0, T, NB> mc0;
-        mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);
+        // ---- step prologue: this step's noise z (layer 0's mix coefficients were fetched at the end of the previous pass)
         silu_row(sidx > 0 ? sidx - 1 : 0, tid);       // for the NEXT pass's embeddings (consumed in this pass's last layer)
         // this step's noise z (one element per thread: the Philox + Box-Muller cost is paid here, fully parallel,
         // not in the narrow epilogue of the last layer)
@@ -1156,6 +1156,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     }
                 }
             }
+            mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);      // for the next pass
             STAGE(21);
             __syncthreads();
             STAGE(17);
