@@ -926,30 +926,34 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // ---- step prologue: this step's noise z (layer 0's mix coefficients were fetched at the end of the previous pass)
         silu_row(sidx > 0 ? sidx - 1 : 0, tid);       // for the NEXT pass's embeddings (consumed in this pass's last layer)
-        // this step's noise z (one element per thread: the Philox + Box-Muller cost is paid here, fully parallel,
-        // not in the narrow epilogue of the last layer)
-        // -- by the last two waves when they have no unit in the layer-0 mix that follows, else by everybody
+        // this step's noise z: the Philox + Box-Muller cost is paid by the two waves that have no unit in the mixes of
+        // layers 0 and 1 (6 units on 8 waves), half of the elements in each of those two stages; shapes whose layer-0 mix
+        // keeps every wave busy generate it here with all threads
         constexpr bool NZ_TAIL = MixCfg<16, 17, T, NB>::UNITS <= NWAVES - 2;
         constexpr int NZ_T0 = NZ_TAIL ? NTHREADS - 128 : 0, NZ_N = NZ_TAIL ? 128 : NTHREADS;
-        if (P.mode == 0 && sidx > 1 && tid >= NZ_T0) {
+        constexpr int NZ_HALF = NZ_TAIL ? ((COLS17 * C0 + 255) / 256) * 128 : COLS17 * C0;     // elements of the first part
+        auto noise_part = [&](int t_id, int lo, int hi) {
+            if (P.mode == 0 && sidx > 1 && t_id >= NZ_T0) {
 #pragma unroll 1
-            for (int u = tid - NZ_T0; u < COLS17 * C0; u += NZ_N) {
-                const int c = u % C0, col = u / C0;
-                const int n = col / TV17, t = (col / 17) % T, v = col % 17;
-                float z = 0.f;
-                const int fixed = WM[n];
-                if (!((fixed >> t) & 1)) {
-                    int chain = chain0 + n;
-                    if (chain >= P.n_chains) chain = P.n_chains - 1;
-                    const int b = chain / P.S, s = chain % P.S;
-                    const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
-                    const int k = P.ns - sidx;
-                    if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
-                    else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
+                for (int u = lo + t_id - NZ_T0; u < hi; u += NZ_N) {
+                    const int c = u % C0, col = u / C0;
+                    const int n = col / TV17, t = (col / 17) % T, v = col % 17;
+                    float z = 0.f;
+                    const int fixed = WM[n];
+                    if (!((fixed >> t) & 1)) {
+                        int chain = chain0 + n;
+                        if (chain >= P.n_chains) chain = P.n_chains - 1;
+                        const int b = chain / P.S, s = chain % P.S;
+                        const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
+                        const int k = P.ns - sidx;
+                        if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
+                        else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
+                    }
+                    ZN[u] = z;
                 }
-                ZN[u] = z;
             }
-        }
+        };
+        noise_part(tid, 0, NZ_HALF < COLS17 * C0 ? NZ_HALF : COLS17 * C0);
         STAGE(0);
         STAGE(1);
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
@@ -969,6 +973,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(2);
         // ---- down path
         LMix<2, T, NB> mc2;
+        if constexpr (NZ_TAIL) noise_part(tid, NZ_HALF, COLS17 * C0);      // second half of the noise (idle waves of this mix)
         mix_late(mc1, 1);
         layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
