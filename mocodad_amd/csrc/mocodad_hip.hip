@@ -110,7 +110,9 @@ __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
 // Optional in-kernel stage timing (build with -DMCD_PROFILE; tools/stage_profile.py): thread 0 of block 0 adds the
 // s_memtime delta of each stage to an LDS accumulator (fire-and-forget ds_add: the timing wave never waits on global
 // memory for the instrumentation); the accumulators are written to P.prof[] when the kernel ends.
+#ifdef MCD_PROFILE
 constexpr int PROF_SLOTS = 96;
+#endif
 struct Prof {
 #ifdef MCD_PROFILE
     unsigned* acc;               // LDS, PROF_SLOTS words
@@ -312,7 +314,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                                           const float* __restrict__ tqd, const float* __restrict__ af, int wave, int lane,
                                           Init&& init, Store&& store) {
     using M = MixCfg<CIN, V, T, NB>;
-    constexpr int KS = M::KS, KP = M::KP, MT = M::MT, CB = M::CB, QC = M::QC, NQ = M::NQ, UNITS = M::UNITS, PER = M::PER;
+    constexpr int KS = M::KS, KP = M::KP, MT = M::MT, CB = M::CB, QC = M::QC, NQ = M::NQ, PER = M::PER;
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
     // the X values of one unit: x[ks][t] = X[(n, t, joint of (ks, lane group))][channel cb*16 + j]
@@ -392,7 +394,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         }
     };
     // later rounds: coefficients fetched one round ahead where the register budget allows (T = 3), else in place
-    if constexpr (T == 3) {
+    {
         // every round's X reads up front as well: a round's stores may alias the next round's reads, which would
         // otherwise wait for them (one LDS round trip per round on the wave's serial path)
         float xs[PER][KS][T];
@@ -410,15 +412,6 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             if (u >= 0) unit(cur, u, xs[rnd]);
             if constexpr (rnd + 1 < PER && !M::SAMEQ) cur = nxt;
         });
-    } else {
-        MixCoef<CIN, V, T, NB> cur = pre;     // one copy of the unit body: these shapes are I-cache bound
-#pragma unroll 1
-        for (int u = wave; u < UNITS; u += NWAVES) {
-            if (u != wave) cur.load_unit(tqd, af, u, lane);
-            float xs[KS][T];
-            load_x(u, xs);
-            unit(cur, u, xs);
-        }
     }
 }
 // coefficients loaded at the top of the stage itself (condition encoder)
@@ -958,14 +951,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(1);
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
         // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.
-        //      (PF: only where the register budget allows it -- the T = 3 shapes; otherwise loaded at the top of the stage.)
-        constexpr bool PF = T == 3;
         auto mixload = [&](auto& mc, int l) { mc.load(wb + tab_i(wb, l * F_STRIDE + F_TQ), wb + tab_i(wb, l * F_STRIDE + F_AM), wave, lane); };
         auto rsload = [&](auto& rc, int r) { rc.load(wb + tab_i(wb, TAB_RSW + r), wb + tab_i(wb, TAB_RSB + r), lane); };
-        auto mix_early = [&](auto& mc, int l) { if constexpr (PF) mixload(mc, l); };
-        auto mix_late = [&](auto& mc, int l) { if constexpr (!PF) mixload(mc, l); };
-        auto rs_early = [&](auto& rc, int r) { if constexpr (PF) rsload(rc, r); };
-        auto rs_late = [&](auto& rc, int r) { if constexpr (!PF) rsload(rc, r); };
+        auto mix_early = mixload;
+        auto rs_early = rsload;
         NoHook nohook;
         LMix<1, T, NB> mc1;
         layer_std<0, T, NB>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
@@ -974,34 +963,28 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // ---- down path
         LMix<2, T, NB> mc2;
         if constexpr (NZ_TAIL) noise_part(tid, NZ_HALF, COLS17 * C0);      // second half of the noise (idle waves of this mix)
-        mix_late(mc1, 1);
         layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
         RsCoef<32, 17, 12, T, NB, true> rc1;
-        mix_late(mc2, 2);
         layer_std<2, T, NB>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
         STAGE(4);
         LMix<3, T, NB> mc3;
         mix_early(mc3, 3);
-        rs_late(rc1, 0);
         resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         __syncthreads();
         STAGE(5);
         LMix<4, T, NB> mc4;
-        mix_late(mc3, 3);
         layer_std<3, T, NB>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
         STAGE(6);
         RsCoef<64, 12, 10, T, NB, true> rc2;
-        mix_late(mc4, 4);
         layer_std<4, T, NB>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
         STAGE(7);
         LMix<5, T, NB> mc5;
         mix_early(mc5, 5);
-        rs_late(rc2, 1);
         resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
@@ -1013,14 +996,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
-            mix_late(mc5, 5);
             layer_std<5, T, NB>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
-                                [&] { if constexpr (PF) load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0); });  // sd3.0
+                                [&] { load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0); });  // sd3.0
             STAGE(9);
-            if constexpr (!PF) load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
             float* Pb = RG + PL::L6_p;
             MixCoef<64, 10, T, NB> mc6;
-            if constexpr (PF) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
+            mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
@@ -1033,7 +1014,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             __syncthreads();
             STAGE(10);
             const float slope6 = lw.slope;
-            if constexpr (!PF) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w, int c) { return Pb[((n * T + q) * 10 + w) * 132 + 64 + c]; },
                                      [&](int n, int q, int w0, int c, f32x4 v) {       // the fragment's 4 joints at once
@@ -1051,23 +1031,19 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // ---- up path
         LMix<7, T, NB> mc7;
         mix_early(mc7, 7);
-        rs_late(rc3, 2);
         resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         __syncthreads();
         STAGE(12);
         LMix<8, T, NB> mc8;
-        mix_late(mc7, 7);
         layer_std<7, T, NB>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
         STAGE(13);
         RsCoef<32, 12, 17, T, NB, false> rc4;
-        mix_late(mc8, 8);
         layer_std<8, T, NB>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
         STAGE(14);
         LMix<9, T, NB> mc9;
         mix_early(mc9, 9);
-        rs_late(rc4, 3);
         resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         __syncthreads();
         STAGE(15);
@@ -1080,16 +1056,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // conditionally loaded register struct costs ~35 VGPRs of phi copies here.
             EmbRow ef;
             auto ef_load = [&] { ef.load(wb, tid); };
-            mix_late(mc9, 9);
             layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
-                                    if constexpr (PF) {
-                                        mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
-                                        ef_load();
-                                    }
+                                    mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
+                                    ef_load();
                                 }, nohook);                                                              // su3.0
             STAGE(16);
-            if constexpr (!PF) ef_load();
             const float ca = srow[0], cb = srow[1], csg = srow[2];     // DDPM coefficients of this step (used two stages on)
             EmbRow ef2;                                   // the 20 rows beyond the first NTHREADS: fetched here, used after
             ef2.load(wb, emb_row2(tid));                  // the FMA product below
@@ -1131,7 +1103,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope10 = lw.slope;
             const bool single = P.mode == 1, zadd = sidx > 1;
             const int e10_off = (sidx & 1) * 16;
-            if constexpr (!PF) mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
             mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      [](int, int, int, int) { return 0.f; },
                                      [&](int n, int t, int v, int c, float val) {
@@ -1678,8 +1649,8 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
             if (variant == 3) return launch_score_t<3, 1, 4>(P, st);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
             return launch_score_t<3, 2, 4>(P, st);                     // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
         case 6:
-            if (variant == 1) return launch_score_t<6, 1, 4>(P, st);   // 1 chain / WG, 2 WGs per CU: spills ~30 VGPRs, 3 % slower
-            return launch_score_t<6, 2, 2>(P, st);                     // 2 chains / WG, 1 WG per CU (no register cap)
+            if (variant == 1) return launch_score_t<6, 2, 2>(P, st);   // 2 chains / WG, 1 WG per CU (no register cap)
+            return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
         case 12: return launch_score_t<12, 1, 2>(P, st);
         case 4: return launch_score_t<4, 1, 4>(P, st);                 // e.g. seg_len 8 split in halves
         case 8: return launch_score_t<8, 1, 2>(P, st);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
