@@ -887,7 +887,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     const int i_last = P.mode == 1 ? P.step_single : 1;
     // embeddings of the first pass; those of pass i-1 are computed during the last layer of pass i
     auto silu_row = [&](int step, int t_id) {      // SEN[n][k] = SiLU(pe(step)[k] + cond[window of chain n][k])
-        if (t_id < NB * EDIM) {
+        if (t_id >= 0 && t_id < NB * EDIM) {
             const int n = t_id / EDIM, k = t_id % EDIM;
             int chain = chain0 + n;
             if (chain >= P.n_chains) chain = P.n_chains - 1;
@@ -918,7 +918,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // ---- step prologue: this step's noise z (layer 0's mix coefficients were fetched at the end of the previous pass)
-        silu_row(sidx > 0 ? sidx - 1 : 0, tid);       // for the NEXT pass's embeddings (consumed in this pass's last layer)
         // this step's noise z: the Philox + Box-Muller cost is paid by the two waves that have no unit in the mixes of
         // layers 0 and 1 (6 units on 8 waves), half of the elements in each of those two stages; shapes whose layer-0 mix
         // keeps every wave busy generate it here with all threads
@@ -963,6 +962,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // ---- down path
         LMix<2, T, NB> mc2;
         if constexpr (NZ_TAIL) noise_part(tid, NZ_HALF, COLS17 * C0);      // second half of the noise (idle waves of this mix)
+        // SiLU(pe + cond) for the NEXT pass's embeddings (consumed in this pass's last layer): two global loads and an
+        // exp -- by the idle waves too, not on wave 0's path at the top of the pass
+        silu_row(sidx > 0 ? sidx - 1 : 0, tid - NZ_T0);
         layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
