@@ -195,3 +195,29 @@ def test_window_views_score_like_materialised_windows(tmp_path):
             m.test_step(batch, i)
         aucs.append(m.on_test_epoch_end())
     assert abs(aucs[0] - aucs[1]) < 1e-6, aucs
+
+
+def test_c_abi_error_paths():
+    """Argument / capability errors come back as negative codes + a message (raised as RuntimeError by the ctypes layer),
+    never as a crash: unsupported frame count, random_imp without its per-window masks, a wrong frame split, S > 64."""
+    from mocodad_amd.engine import HipScorer
+    from mocodad_amd.models.mocodad import MoCoDAD
+    sd, cfg = golden_weights("inject")
+    # seg_len 10 split 5 + 5: U-Net frame count 5 is not instantiated -> MCD_EUNSUPPORTED at pack time
+    m = MoCoDAD(make_args(cfg, seg_len=10, conditioning_indices=2)).to("cuda:0")
+    with pytest.raises(RuntimeError, match="not instantiated"):
+        m.scorer()
+    # random_imp needs the per-window condition-frame masks
+    sdr, cfgr = golden_weights("rndimp")
+    sc = HipScorer(sdr, strategy="random_imp", seg_len=6, cond_idx=[0, 1], corrupt_idx=[2, 3, 4, 5], device="cuda:0")
+    with pytest.raises(ValueError, match="cond_mask"):
+        sc.score(torch.zeros(2, 2, 6, 17), n_samples=1, noise_steps=3)
+    # a frame split the checkpoint was not trained for: the gcn.T / gcn.A tensors have the wrong size -> MCD_EMISSING
+    with pytest.raises(RuntimeError, match="elements, expected"):
+        HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1], corrupt_idx=[2, 3, 4, 5],
+                  cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+    # aggregation over more than 64 samples
+    sc3, = (HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5],
+                      cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0"),)
+    with pytest.raises(RuntimeError, match="<= 64"):
+        sc3.aggregate(torch.zeros(2, 2, 6, 17), torch.zeros(2, 65, device="cuda:0"), None, "best", noise_steps=3)
