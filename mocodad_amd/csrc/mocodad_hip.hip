@@ -576,7 +576,9 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
     for (int kq = 0; kq < KQ; ++kq) a[kq] = load_global4(wpl + kq * 256);
 }
 
-template <int MT, int NT, int KQ1, int KQ2, bool IDRES, class Epi>
+// FORCE: pin the read-ahead order with scheduling barriers -- only for the kernels without a register cap (the
+// scheduler otherwise sinks every read to its use; with the 128-VGPR cap pinning costs spills and loses)
+template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, class Epi>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
                                            const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0) {
     constexpr int NG = Tiling<MT, NT>::NG;
@@ -606,10 +608,12 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
             };
             float4 buf[DEPTH];
             static_for<DEPTH>([&](auto dd) { buf[decltype(dd)::value] = rd(dd); });
+            if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
             static_for<KQ>([&](auto kk) {
                 constexpr int kq = decltype(kk)::value;
                 const float4 u = buf[kq % DEPTH];
                 if constexpr (kq + DEPTH < KQ) buf[kq % DEPTH] = rd(std::integral_constant<int, kq + DEPTH>{});
+                if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u.z, c, 0, 0, 0);
@@ -627,7 +631,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `mc`: this layer's mix coefficients (already loaded); `pre_gemm` runs between the mix barrier and the GEMM, `pre_barrier`
 // between the GEMM and the closing barrier -- the callers use them to issue the NEXT stage's coefficient loads.
-template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, class H1, class H2>
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, class H1, class H2>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
                                               const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
                                               const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
@@ -661,12 +665,12 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
         }
     };
-    gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi);
+    gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSI, wave, lane, epi);
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
         load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
         bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
-        gemm_tiles<MT, NT, KQ1, KQ2, !RES>(afr, z, CSI, in, CSI, wave, lane, epi, mi);
+        gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSI, wave, lane, epi, mi);
     }
     pre_barrier();
     __syncthreads();
@@ -685,11 +689,11 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 // U-Net layer L of the fixed channel plan
 template <int L, int T, int NB>
 using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
-template <int L, int T, int NB, class H1, class H2>
+template <int L, int T, int NB, bool FORCE = false, class H1, class H2>
 __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
                                           const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
     constexpr LDesc D = layer_desc(L);
-    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
                                                                prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         auto rs_early = rsload;
         NoHook nohook;
         LMix<1, T, NB> mc1;
-        layer_std<0, T, NB>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
+        layer_std<0, T, NB, (MINW <= 2)>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc1, 1); }, nohook);                                           // sp1a (2 -> 16)
         STAGE(2);
         // ---- down path
@@ -965,11 +969,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // SiLU(pe + cond) for the NEXT pass's embeddings (consumed in this pass's last layer): two global loads and an
         // exp -- by the idle waves too, not on wave 0's path at the top of the pass
         silu_row(sidx > 0 ? sidx - 1 : 0, tid - NZ_T0);
-        layer_std<1, T, NB>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
+        layer_std<1, T, NB, (MINW <= 2)>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
         RsCoef<32, 17, 12, T, NB, true> rc1;
-        layer_std<2, T, NB>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
+        layer_std<2, T, NB, (MINW <= 2)>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
         STAGE(4);
         LMix<3, T, NB> mc3;
@@ -978,11 +982,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         __syncthreads();
         STAGE(5);
         LMix<4, T, NB> mc4;
-        layer_std<3, T, NB>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
+        layer_std<3, T, NB, (MINW <= 2)>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
         STAGE(6);
         RsCoef<64, 12, 10, T, NB, true> rc2;
-        layer_std<4, T, NB>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
+        layer_std<4, T, NB, (MINW <= 2)>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
         STAGE(7);
         LMix<5, T, NB> mc5;
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
-            layer_std<5, T, NB>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
+            layer_std<5, T, NB, (MINW <= 2)>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
                                 [&] { load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0); });  // sd3.0
             STAGE(9);
             float* Pb = RG + PL::L6_p;
@@ -1007,11 +1011,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
-            gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
+            gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
 #pragma unroll
             for (int mi = 1; mi < Tiling<8, NT>::MW; ++mi) {
                 load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
-                gemm_tiles<8, NT, 8, 0, false>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+                gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
             }
             __syncthreads();
             STAGE(10);
@@ -1037,11 +1041,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         __syncthreads();
         STAGE(12);
         LMix<8, T, NB> mc8;
-        layer_std<7, T, NB>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
+        layer_std<7, T, NB, (MINW <= 2)>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
         STAGE(13);
         RsCoef<32, 12, 17, T, NB, false> rc4;
-        layer_std<8, T, NB>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
+        layer_std<8, T, NB, (MINW <= 2)>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
         STAGE(14);
         LMix<9, T, NB> mc9;
@@ -1058,7 +1062,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // conditionally loaded register struct costs ~35 VGPRs of phi copies here.
             EmbRow ef;
             auto ef_load = [&] { ef.load(wb, tid); };
-            layer_std<9, T, NB>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
+            layer_std<9, T, NB, (MINW <= 2)>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
                                     mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
                                     ef_load();
