@@ -656,7 +656,8 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     auto epi = [&](auto, int col, int c0, f32x4 acc) {
         if (col < COLS && c0 < COUT) {
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HASEMB) e = *reinterpret_cast<const float4*>(embl + (col / TV) * EMB_STRIDE + c0);
+            if (HASEMB)      // this column's chain: no integer division on the tile epilogue's path when there are two chains
+                e = *reinterpret_cast<const float4*>(embl + (NB == 2 ? (col >= TV ? EMB_STRIDE : 0) : (col / TV) * EMB_STRIDE) + c0);
             float4 v;
             v.x = prelu(acc[0] + bcur.x, slope) + e.x;
             v.y = prelu(acc[1] + bcur.y, slope) + e.y;
