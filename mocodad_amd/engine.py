@@ -46,7 +46,8 @@ class HipScorer:
         self.t_cond = len(self.cond_idx) if strategy == "inject" else 0
         self.t_unet = len(self.corrupt_idx) + (len(self.cond_idx) if strategy in ("concat", "inbetween_imp", "random_imp") else 0)
         self._tables: Dict[int, torch.Tensor] = {}
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}   # condition-embedding workspace, one per stream (launches on different
+        #                                          streams may overlap, each needs its own)
 
         cfg = _lib.ModelCfg()
         cfg.num_coords, cfg.n_joints, cfg.t_unet, cfg.t_cond = num_coords, n_joints, self.t_unet, self.t_cond
@@ -161,12 +162,14 @@ class HipScorer:
             if tuple(noise.shape) != exp:
                 raise ValueError(f"noise must have shape {exp}, got {tuple(noise.shape)}")
         need = int(self.L.mcd_score_workspace_bytes(self._h, C.byref(cfg)))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
         with torch.cuda.device(self.device):
+            sid = torch.cuda.current_stream().cuda_stream
+            ws = self._ws.get(sid)
+            if ws is None or ws.numel() < need:
+                ws = self._ws[sid] = torch.empty(need, device=self.device, dtype=torch.uint8)
             _lib.check(self.L.mcd_score_view(self._h, C.byref(cfg), _ptr(data), C.byref(view) if view is not None else None,
                                              _ptr(noise), C.c_uint64(seed & (2**64 - 1)), C.c_int64(first_window_id),
-                                             _ptr(self.table(noise_steps)), _ptr(self._ws), _ptr(loss), _ptr(poses), _stream()))
+                                             _ptr(self.table(noise_steps)), _ptr(ws), _ptr(loss), _ptr(poses), _stream()))
         del keep
         return loss, poses
 

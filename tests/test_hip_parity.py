@@ -146,3 +146,21 @@ def test_philox_noise_statistics_and_determinism():
     # window-id keyed: scoring the second half alone with first_window_id=32 reproduces the same scores
     h, _ = sc.score(data[32:], n_samples=4, noise_steps=5, seed=11, first_window_id=32)
     assert torch.equal(a[32:], h)
+
+
+def test_overlapping_launches_on_two_streams():
+    """Batches scored on alternating HIP streams (bench.py --streams 2) overlap on the GPU; each stream has its own
+    condition-embedding workspace, so the results equal the one-stream ones bit for bit."""
+    sc, _, _ = _scorer("inject")
+    gen = torch.Generator().manual_seed(9)
+    batches = [torch.randn(700, 2, 6, 17, generator=gen).cuda() for _ in range(6)]
+    ref = [sc.score(b, n_samples=3, noise_steps=6, seed=40 + i)[0].clone() for i, b in enumerate(batches)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = []
+    for i, b in enumerate(batches):
+        with torch.cuda.stream(streams[i % 2]):
+            out.append(sc.score(b, n_samples=3, noise_steps=6, seed=40 + i)[0])
+    torch.cuda.synchronize()
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
