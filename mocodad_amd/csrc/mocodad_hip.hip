@@ -40,6 +40,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // read-only model coefficients addressed wave-uniformly go through the constant address space so that the
 // compiler emits scalar loads (s_load_dwordx16) and feeds them to v_fmac as SGPR operands
 typedef const float __attribute__((address_space(4))) cfloat;
@@ -201,7 +202,12 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     return __fsqrt_rn(-1.38629436111989f * __log2f(u1)) * __cosf(6.28318530717958647692f * u2);
 }
 
-__device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
+// PReLU(x) = x >= 0 ? x : a x  ==  max(x, a x) for a <= 1, min(x, a x) for a > 1: one multiply and one v_med3_f32 against
+// +-inf picked by the (wave-uniform) slope -- the compare + select form costs a third VALU instruction per element, and
+// the fp32 MFMAs share the SIMD's issue time with the VALU (tools/ubench/coissue.hip)
+__device__ __forceinline__ float prelu(float x, float a) {
+    return __builtin_amdgcn_fmed3f(x, a * x, a <= 1.f ? __builtin_inff() : -__builtin_inff());
+}
 
 // ------------------------------------------------------------------------------------------------
 // DPP helpers.  A coefficient row (<= 16 values) lives in ONE VGPR, value i in lane i of every 16-lane row
@@ -345,10 +351,14 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             part[qi] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt)
+                if constexpr (std::is_invocable_v<Init, int, int, int, int, std::true_type>) {
+                    acc[qi][mt] = init(n, q0 + qi, mt * 16 + 4 * g, cb * 16 + j, std::true_type{});   // whole fragment (masks joints >= V)
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[qi][mt][r] = 0.f;
-                    if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = init(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j);
+                    for (int r = 0; r < 4; ++r) {
+                        acc[qi][mt][r] = 0.f;
+                        if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = init(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j);
+                    }
                 }
         }
         static_for<KS>([&](auto si) {
@@ -647,23 +657,36 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     const float* bias = wb + lw.bias;
     mix_stage<CIN, V, T, NB>(in, CSI, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              [](int, int, int, int) { return 0.f; },
-                             [&](int n, int q, int w, int c, float v) { z[((n * T + q) * V + w) * CSI + c] = v; });
+                             [&](int n, int q, int w0, int c, auto v) {
+                                 // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
+                                 // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store)
+                                 float* zp = z + ((n * T + q) * V + w0) * CSI + c;
+                                 if constexpr (std::is_same_v<decltype(v), f32x4>) {
+#pragma unroll
+                                     for (int r = 0; r < 4; ++r)
+                                         if (w0 + r < V) zp[r * CSI] = v[r];
+                                 } else {
+                                     *zp = v;
+                                 }
+                             });
     __syncthreads();
     prof.mark(prof_id);
     float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
     pre_gemm();
     const float slope = lw.slope;
+    const float pinf = slope <= 1.f ? __builtin_inff() : -__builtin_inff();     // see prelu()
     auto epi = [&](auto, int col, int c0, f32x4 acc) {
         if (col < COLS && c0 < COUT) {
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
             if (HASEMB)      // this column's chain: no integer division on the tile epilogue's path when there are two chains
                 e = *reinterpret_cast<const float4*>(embl + (NB == 2 ? (col >= TV ? EMB_STRIDE : 0) : (col / TV) * EMB_STRIDE) + c0);
-            float4 v;
-            v.x = prelu(acc[0] + bcur.x, slope) + e.x;
-            v.y = prelu(acc[1] + bcur.y, slope) + e.y;
-            v.z = prelu(acc[2] + bcur.z, slope) + e.z;
-            v.w = prelu(acc[3] + bcur.w, slope) + e.w;
-            *reinterpret_cast<float4*>(out + col * CSO + c0) = v;
+            // packed adds / multiply on channel pairs (v_pk_add_f32, v_pk_mul_f32) around the four v_med3_f32 of the PReLU:
+            // 10 VALU instructions for the lane's 4 channels
+            const f32x2 t0 = f32x2{acc[0], acc[1]} + f32x2{bcur.x, bcur.y}, t1 = f32x2{acc[2], acc[3]} + f32x2{bcur.z, bcur.w};
+            const f32x2 m0 = t0 * slope, m1 = t1 * slope;
+            const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf)} + f32x2{e.x, e.y};
+            const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf)} + f32x2{e.z, e.w};
+            *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
         }
     };
     gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSI, wave, lane, epi);
@@ -1022,13 +1045,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(10);
             const float slope6 = lw.slope;
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
-                                     [&](int n, int q, int w, int c) { return Pb[((n * T + q) * 10 + w) * 132 + 64 + c]; },
-                                     [&](int n, int q, int w0, int c, f32x4 v) {       // the fragment's 4 joints at once
-                                         const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
+                                     [&](int n, int q, int w0, int c, std::true_type) {   // the fragment's 4 joints at once
+                                         const float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
+                                         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                                          for (int r = 0; r < 4; ++r)
-                                             if (w0 + r < 10)
-                                                 Pb[((n * T + q) * 10 + w0 + r) * 132 + 64 + c] = prelu(v[r] + bias, slope6) + e;
+                                             if (w0 + r < 10) a[r] = pp[r * 132];
+                                         return a;
+                                     },
+                                     [&](int n, int q, int w0, int c, f32x4 v) {
+                                         const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
+                                         float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
+#pragma unroll
+                                         for (int r = 0; r < 4; ++r)
+                                             if (w0 + r < 10) pp[r * 132] = prelu(v[r] + bias, slope6) + e;
                                      });
         }
         RsCoef<64, 10, 12, T, NB, false> rc3;
