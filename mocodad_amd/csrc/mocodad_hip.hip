@@ -743,17 +743,36 @@ struct EmbRow {              // W_e row + bias of one output channel
 template <int NB>
 __device__ __forceinline__ void emb_row(const EmbRow& f, int o, const float* __restrict__ se, float* __restrict__ emb,
                                         float* __restrict__ e10) {
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-        float acc = f.b;
+    if constexpr (NB == 2) {
+        // both chains per instruction: se is [k][chain], acc = (chain 0, chain 1) -> 16 v_pk_fma_f32 instead of 32 FMAs
+        f32x2 acc = {f.b, f.b};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 sv = *reinterpret_cast<const float4*>(se + n * EDIM + 4 * q);   // LDS broadcast
-            acc = fmaf(f.w[q].x, sv.x, acc); acc = fmaf(f.w[q].y, sv.y, acc);
-            acc = fmaf(f.w[q].z, sv.z, acc); acc = fmaf(f.w[q].w, sv.w, acc);
+            const float4 s0 = *reinterpret_cast<const float4*>(se + 8 * q);       // LDS broadcast: k = 4q, 4q+1
+            const float4 s1 = *reinterpret_cast<const float4*>(se + 8 * q + 4);   //                k = 4q+2, 4q+3
+            acc = f32x2{f.w[q].x, f.w[q].x} * f32x2{s0.x, s0.y} + acc;
+            acc = f32x2{f.w[q].y, f.w[q].y} * f32x2{s0.z, s0.w} + acc;
+            acc = f32x2{f.w[q].z, f.w[q].z} * f32x2{s1.x, s1.y} + acc;
+            acc = f32x2{f.w[q].w, f.w[q].w} * f32x2{s1.z, s1.w} + acc;
         }
-        if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = acc;
-        else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = acc[n];
+            else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc[n];
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            float acc = f.b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 sv = *reinterpret_cast<const float4*>(se + n * EDIM + 4 * q);   // LDS broadcast
+                acc = fmaf(f.w[q].x, sv.x, acc); acc = fmaf(f.w[q].y, sv.y, acc);
+                acc = fmaf(f.w[q].z, sv.z, acc); acc = fmaf(f.w[q].w, sv.w, acc);
+            }
+            if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = acc;
+            else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc;
+        }
     }
 }
 // thread tid owns output channel tid (row `f`) and, for the EMB_TOTAL - NTHREADS channels beyond, tid + NTHREADS (row
@@ -802,12 +821,13 @@ struct Plan {
     static constexpr int BIA = 64 + 16;         // biases of the two W-first layers (6: 64, 10: 2), read inside their store functors
     static constexpr int UPD = 16;              // per (chain, U-Net frame): first column of the frame its prediction updates, or -1
     static constexpr int ZO = P17 * 2;          // layer 10's mixed output Z[col][c] between its mix and the element-wise tail
+    static constexpr int TT = P17 * 2;          // per (column, coordinate) of the element-wise tail: packed (chain, frame, joint) indices
 #ifdef MCD_PROFILE
     static constexpr int PROF = PROF_SLOTS;
 #else
     static constexpr int PROF = 0;
 #endif
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + PROF;
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + PROF;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -856,6 +876,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
         UPD[i] = k < 0 ? -1 : (n * T + (P.win_mask ? t : P.pos_of[k])) * 17;
     }
+    // the tail's thread -> (chain n, frame t, joint v) map, packed: n*T+t | n << 4 | t << 5 | v << 9 (the divisions by 17 and
+    // T*17 cost ~35 VALU instructions per thread and pass when done in place)
+    int* const TT = reinterpret_cast<int*>(ZO + PL::ZO);
+    for (int u = threadIdx.x; u < COLS17 * C0; u += NTHREADS) {
+        const int col = u / C0, n = col / TV17, t = (col / 17) % T, v = col % 17;
+        TT[u] = (n * T + t) | (n << 4) | (t << 5) | (v << 9);
+    }
     if (threadIdx.x < 64) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 6 * F_STRIDE + F_BIAS) + threadIdx.x];
     else if (threadIdx.x < 64 + C0) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 10 * F_STRIDE + F_BIAS) + threadIdx.x - 64];
     const int CTV = C0 * Tx * 17;          // elements of one generated pose
@@ -901,7 +928,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.acc = reinterpret_cast<unsigned*>(ZO + PL::ZO);
+    prof.acc = reinterpret_cast<unsigned*>(ZO + PL::ZO + PL::TT);
     if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
@@ -921,7 +948,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (chain >= P.n_chains) chain = P.n_chains - 1;
             float e = P.step_table[step * (4 + EDIM) + 4 + k];
             if (P.cond_emb) e += P.cond_emb[(chain / P.S) * EDIM + k];
-            SEN[t_id] = e / (1.f + expf(-e));
+            SEN[NB == 2 ? k * 2 + n : t_id] = e / (1.f + expf(-e));   // NB = 2: [k][n], a chain pair per packed FMA (emb_row)
         }
     };
     {
@@ -1044,21 +1071,23 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             __syncthreads();
             STAGE(10);
             const float slope6 = lw.slope;
+            const float pinf6 = slope6 <= 1.f ? __builtin_inff() : -__builtin_inff();
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w0, int c, std::true_type) {   // the fragment's 4 joints at once
                                          const float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
-                                         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                         for (int r = 0; r < 4; ++r)
-                                             if (w0 + r < 10) a[r] = pp[r * 132];
-                                         return a;
+                                         // joints >= 10 read the next frame's rows (inside the 64-column region): an MFMA's D rows
+                                         // are independent and those rows are never stored
+                                         return f32x4{pp[0], pp[132], pp[264], pp[396]};
                                      },
                                      [&](int n, int q, int w0, int c, f32x4 v) {
                                          const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
                                          float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
-#pragma unroll
-                                         for (int r = 0; r < 4; ++r)
-                                             if (w0 + r < 10) pp[r * 132] = prelu(v[r] + bias, slope6) + e;
+                                         const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{bias, bias}, t1 = f32x2{v[2], v[3]} + f32x2{bias, bias};
+                                         const f32x2 m0 = t0 * slope6, m1 = t1 * slope6;
+                                         const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf6), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf6)} + f32x2{e, e};
+                                         const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf6), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf6)} + f32x2{e, e};
+                                         if (w0 < 10) { pp[0] = r0[0]; pp[132] = r0[1]; }
+                                         if (w0 + 2 < 10) { pp[264] = r1[0]; pp[396] = r1[1]; }
                                      });
         }
         RsCoef<64, 10, 12, T, NB, false> rc3;
@@ -1105,7 +1134,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             float* Pb = RG + PL::L10_p;
             // P[col][r] = sum_k W4[r][k] X[col][k] for the 4 useful rows (P_t 0,1 ; P_r 2,3) with plain FMAs: as a 16-row MFMA
             // tile this product is 3/4 padding, and matrix-pipe time is what the kernel is short of.  wave = (row, block
-            // of 64 columns), weights as scalar operands, pad channels 4..15 of the mix input block zeroed by the row-0 waves.
+            // of 64 columns), weights as scalar operands.
             {
                 const int r = wave & 3;
                 const cfloat* w4 = (const cfloat*)(wb + lw.wp + r * 32);
@@ -1113,18 +1142,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     const int col = cblk * 64 + lane;
                     if (col < COLS17) {
                         const float* xp = RG + PL::L10_in + col * 36;
-                        float acc = 0.f;
+                        f32x2 acc2 = {0.f, 0.f};             // even / odd k partial sums: 16 v_pk_fma_f32
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const float4 x = *reinterpret_cast<const float4*>(xp + 4 * q);
-                            acc = fmaf(w4[4 * q + 0], x.x, acc); acc = fmaf(w4[4 * q + 1], x.y, acc);
-                            acc = fmaf(w4[4 * q + 2], x.z, acc); acc = fmaf(w4[4 * q + 3], x.w, acc);
+                            acc2 = f32x2{w4[4 * q + 0], w4[4 * q + 1]} * f32x2{x.x, x.y} + acc2;
+                            acc2 = f32x2{w4[4 * q + 2], w4[4 * q + 3]} * f32x2{x.z, x.w} + acc2;
                         }
-                        Pb[col * 20 + r] = acc;
-                        if (r == 0) {
-#pragma unroll
-                            for (int q = 1; q < 4; ++q) *reinterpret_cast<float4*>(Pb + col * 20 + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
+                        // (channels 4..15 of the mix input block keep whatever the region held: the mix never combines
+                        // channels -- they are the N dimension of its MFMAs -- and only channels 0,1 of its output are stored)
+                        Pb[col * 20 + r] = acc2[0] + acc2[1];
                     }
                 }
             }
@@ -1151,7 +1178,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // pass's input block.  (Inside the mix's store functor this ran on 2 of every 16 lanes of 6 waves.)
             for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
                 const int c = u % C0, col = u / C0;
-                const int n = col / TV17, t = (col / 17) % T, v = col % 17;
+                const int tt = TT[u];
+                const int n = (tt >> 4) & 1, t = (tt >> 5) & 15, v = tt >> 9;
                 const float x = XT[col * 4 + c];
                 const float eps = prelu(ZO[u] + Pb[col * 20 + C0 + c] + BIA[64 + c], slope10) + E10[e10_off + n * 4 + c] + x;
                 if (single) {
@@ -1159,7 +1187,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     if (chain < P.n_chains) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v] = eps;
                 } else {
                     if ((WM[n] >> t) & 1) RG[PL::L0_in + col * 20 + c] = x;     // condition frame: copied to the next pass's input
-                    const int cbase = UPD[n * T + t];
+                    const int cbase = UPD[tt & 15];
                     if (cbase >= 0) {
                         const int colp = cbase + v;
                         const float z = zadd ? ZN[colp * C0 + c] : 0.f;
