@@ -182,6 +182,31 @@ __device__ __forceinline__ int fm_src(const ScoreParams& P, int t) { return P.wi
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller (perf mode noise; parity mode reads the caller's noise tensor)
 // ------------------------------------------------------------------------------------------------
+// all four output words: two Box-Muller pairs = four normals per call
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                               float (&z)[4]) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned w[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(w[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(w[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = __fsqrt_rn(-1.38629436111989f * __log2f(u1));       // hardware log2 / sqrt / sin / cos, as below
+        z[2 * h] = r * __cosf(6.28318530717958647692f * u2);
+        z[2 * h + 1] = r * __sinf(6.28318530717958647692f * u2);
+    }
+}
 __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3) {
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
@@ -817,7 +842,7 @@ struct Plan {
     static constexpr int EAUX = 2 * 4 * 4 + 4 * EDIM;   // layer 10's embedding outputs, double-buffered by step parity: [2][NB<=4][4];
                                                      // then SiLU(pe + cond) of the NEXT pass [NB<=4][16]
     static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
-    static constexpr int WM = 4;                // per-chain condition-frame bitmask (NB <= 4 ints)
+    static constexpr int WM = 12;               // per chain (NB <= 4): condition-frame bitmask [0,4), window [4,8), sample [8,12)
     static constexpr int BIA = 64 + 16;         // biases of the two W-first layers (6: 64, 10: 2), read inside their store functors
     static constexpr int UPD = 16;              // per (chain, U-Net frame): first column of the frame its prediction updates, or -1
     static constexpr int ZO = P17 * 2;          // layer 10's mixed output Z[col][c] between its mix and the element-wise tail
@@ -862,6 +887,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         int chain = chain0 + threadIdx.x;
         if (chain >= P.n_chains) chain = P.n_chains - 1;
         WM[threadIdx.x] = P.win_mask ? P.win_mask[chain / P.S] : P.fixed_mask;
+        WM[4 + threadIdx.x] = chain / P.S;
+        WM[8 + threadIdx.x] = chain % P.S;
     }
     // biases the W-first layers add inside their mix store functors: from LDS there, not from global memory (a global
     // load in a functor that also stores to LDS is re-issued per call: one L2 round trip per output row)
@@ -977,30 +1004,35 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // layers 0 and 1 (6 units on 8 waves), half of the elements in each of those two stages; shapes whose layer-0 mix
         // keeps every wave busy generate it here with all threads
         constexpr bool NZ_TAIL = MixCfg<16, 17, T, NB>::UNITS <= NWAVES - 2;
-        constexpr int NZ_T0 = NZ_TAIL ? NTHREADS - 128 : 0, NZ_N = NZ_TAIL ? 128 : NTHREADS;
-        constexpr int NZ_HALF = NZ_TAIL ? ((COLS17 * C0 + 255) / 256) * 128 : COLS17 * C0;     // elements of the first part
-        auto noise_part = [&](int t_id, int lo, int hi) {
-            if (P.mode == 0 && sidx > 1 && t_id >= NZ_T0) {
-#pragma unroll 1
-                for (int u = lo + t_id - NZ_T0; u < hi; u += NZ_N) {
-                    const int c = u % C0, col = u / C0;
-                    const int n = col / TV17, t = (col / 17) % T, v = col % 17;
-                    float z = 0.f;
-                    const int fixed = WM[n];
-                    if (!((fixed >> t) & 1)) {
-                        int chain = chain0 + n;
-                        if (chain >= P.n_chains) chain = P.n_chains - 1;
-                        const int b = chain / P.S, s = chain % P.S;
-                        const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
-                        const int k = P.ns - sidx;
-                        if (P.noise) z = P.noise[((size_t)(s * K + k) * P.B + b) * CTV + e];
-                        else z = philox_normal(P.seed, (unsigned)e, (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b));
+        constexpr int NZ_T0 = NZ_TAIL ? NTHREADS - 128 : 0;
+        // one thread per (chain, U-Net frame, pair of joints): a Philox4x32 call yields the four normals of the pair's two
+        // coordinates -- NB*T*9 threads (54 at T = 3: one wave's worth of Philox per pass instead of four)
+        constexpr int NZ_GROUPS = NB * T * 9;
+        static_assert(NZ_GROUPS <= 128, "noise groups fit the two idle waves");
+        auto noise_part = [&](int t_id) {
+            const int gi = t_id - NZ_T0;
+            if (P.mode == 0 && sidx > 1 && gi >= 0 && gi < NZ_GROUPS) {
+                const int n = gi / (T * 9), r = gi % (T * 9), t = r / 9, v0 = (r % 9) * 2;
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                const int fixed = WM[n];
+                if (!((fixed >> t) & 1)) {
+                    const int b = WM[4 + n], s = WM[8 + n];
+                    const int tx = fm_tx(P, fixed, t);
+                    const int k = P.ns - sidx;
+                    if (P.noise) {
+                        const float* zp = P.noise + ((size_t)(s * K + k) * P.B + b) * CTV + tx * 17 + v0;
+                        z[0] = zp[0]; z[1] = zp[Tx * 17];                                   // (c = 0, v0), (c = 1, v0)
+                        if (v0 + 1 < 17) { z[2] = zp[1]; z[3] = zp[Tx * 17 + 1]; }         // (c = 0, v0+1), (c = 1, v0+1)
+                    } else {
+                        philox_normal4(P.seed, (unsigned)(tx * 9 + (v0 >> 1)), (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b), z);
                     }
-                    ZN[u] = z;
                 }
+                float* zo = ZN + ((n * T + t) * 17 + v0) * C0;          // ZN[col][c], columns v0 and v0+1
+                zo[0] = z[0]; zo[1] = z[1];
+                if (v0 + 1 < 17) { zo[2] = z[2]; zo[3] = z[3]; }
             }
         };
-        noise_part(tid, 0, NZ_HALF < COLS17 * C0 ? NZ_HALF : COLS17 * C0);
+        noise_part(tid);
         STAGE(0);
         STAGE(1);
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
@@ -1016,7 +1048,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(2);
         // ---- down path
         LMix<2, T, NB> mc2;
-        if constexpr (NZ_TAIL) noise_part(tid, NZ_HALF, COLS17 * C0);      // second half of the noise (idle waves of this mix)
         // SiLU(pe + cond) for the NEXT pass's embeddings (consumed in this pass's last layer): two global loads and an
         // exp -- by the idle waves too, not on wave 0's path at the top of the pass
         silu_row(sidx > 0 ? sidx - 1 : 0, tid - NZ_T0);
