@@ -266,6 +266,20 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
+// LDS reads issued by hand (see mix_stage): byte address + immediate offset; the compiler does not track them, so the
+// consumer calls lds_reads_done() (a full lgkmcnt wait) and ties every loaded register behind it with lds_tie()
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+template <class Z>
+__device__ __forceinline__ float ds_read_imm(unsigned addr, Z, int off) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(off) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_tie(float& x) { asm volatile("" : "+v"(x)); }
+
 // Joint handled by lane group g at k-step ks of the mix.  K-steps are paired over 8 consecutive joints so that the two
 // lane groups sharing an LDS access phase (g = 0,1 and g = 2,3) read rows 4 apart: with a row stride of 4*odd floats
 // that is a 16-bank shift, i.e. conflict-free ds_read_b32.  A trailing unpaired k-step uses joints 8p+g.
@@ -358,8 +372,14 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             constexpr int ks = decltype(si)::value;
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
             const float* xb = ks < KP ? xin_p : xin_l;
-#pragma unroll
-            for (int t = 0; t < T; ++t) x[ks][t] = xb[(t * V + vbase) * cs_in];
+            // explicit ds_read_b32 with 16-bit immediate offsets: the compiler merges these reads into ds_read2_b32 (8-bit
+            // offsets) and then re-bases the address with a VALU add for every other pair -- VALU issue time is what the
+            // kernel is short of.  Results are valid after the s_waitcnt in lds_reads_done().
+            const unsigned xa = lds_addr(xb);
+            static_for<T>([&](auto ti) {
+                constexpr int t = decltype(ti)::value;
+                x[ks][t] = ds_read_imm(xa, std::integral_constant<int, 0>{}, (t * V + vbase) * cs_in * 4);
+            });
         });
     };
     auto unit = [&](const MixCoef<CIN, V, T, NB>& cur, int u, const float (&xs)[KS][T]) {
@@ -437,6 +457,12 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             constexpr int rnd = decltype(ri)::value;
             const int u = M::unit_of(wave, rnd);
             load_x(u < 0 ? 0 : u, xs[rnd]);
+        });
+        lds_reads_done();
+        static_for<PER>([&](auto ri) {
+            static_for<KS>([&](auto si) {
+                static_for<T>([&](auto ti) { lds_tie(xs[decltype(ri)::value][decltype(si)::value][decltype(ti)::value]); });
+            });
         });
         MixCoef<CIN, V, T, NB> cur = pre;
         static_for<PER>([&](auto ri) {
@@ -768,36 +794,20 @@ struct EmbRow {              // W_e row + bias of one output channel
 template <int NB>
 __device__ __forceinline__ void emb_row(const EmbRow& f, int o, const float* __restrict__ se, float* __restrict__ emb,
                                         float* __restrict__ e10) {
-    if constexpr (NB == 2) {
-        // both chains per instruction: se is [k][chain], acc = (chain 0, chain 1) -> 16 v_pk_fma_f32 instead of 32 FMAs
-        f32x2 acc = {f.b, f.b};
+    // even / odd k partial sums per packed FMA (weight pairs and SiLU pairs are adjacent registers / LDS words: no
+    // broadcast operand, which the compiler otherwise builds with extra v_mov): 8 v_pk_fma_f32 + 1 add per chain
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        f32x2 acc = {f.b, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 s0 = *reinterpret_cast<const float4*>(se + 8 * q);       // LDS broadcast: k = 4q, 4q+1
-            const float4 s1 = *reinterpret_cast<const float4*>(se + 8 * q + 4);   //                k = 4q+2, 4q+3
-            acc = f32x2{f.w[q].x, f.w[q].x} * f32x2{s0.x, s0.y} + acc;
-            acc = f32x2{f.w[q].y, f.w[q].y} * f32x2{s0.z, s0.w} + acc;
-            acc = f32x2{f.w[q].z, f.w[q].z} * f32x2{s1.x, s1.y} + acc;
-            acc = f32x2{f.w[q].w, f.w[q].w} * f32x2{s1.z, s1.w} + acc;
+            const float4 sv = *reinterpret_cast<const float4*>(se + n * EDIM + 4 * q);   // LDS broadcast
+            acc = f32x2{f.w[q].x, f.w[q].y} * f32x2{sv.x, sv.y} + acc;
+            acc = f32x2{f.w[q].z, f.w[q].w} * f32x2{sv.z, sv.w} + acc;
         }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = acc[n];
-            else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc[n];
-        }
-    } else {
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            float acc = f.b;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 sv = *reinterpret_cast<const float4*>(se + n * EDIM + 4 * q);   // LDS broadcast
-                acc = fmaf(f.w[q].x, sv.x, acc); acc = fmaf(f.w[q].y, sv.y, acc);
-                acc = fmaf(f.w[q].z, sv.z, acc); acc = fmaf(f.w[q].w, sv.w, acc);
-            }
-            if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = acc;
-            else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = acc;
-        }
+        const float r = acc[0] + acc[1];
+        if (o < emb_off(10)) emb[n * EMB_STRIDE + o] = r;
+        else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = r;
     }
 }
 // thread tid owns output channel tid (row `f`) and, for the EMB_TOTAL - NTHREADS channels beyond, tid + NTHREADS (row
@@ -975,7 +985,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (chain >= P.n_chains) chain = P.n_chains - 1;
             float e = P.step_table[step * (4 + EDIM) + 4 + k];
             if (P.cond_emb) e += P.cond_emb[(chain / P.S) * EDIM + k];
-            SEN[NB == 2 ? k * 2 + n : t_id] = e / (1.f + expf(-e));   // NB = 2: [k][n], a chain pair per packed FMA (emb_row)
+            SEN[t_id] = e / (1.f + expf(-e));
         }
     };
     {
