@@ -110,7 +110,7 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
 
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.
  *   data        (B,C,T,V) windows
- *   noise       NULL -> in-kernel Philox4x32-10 keyed by (seed, first_window_id+b, s, step, element);
+ *   noise       NULL -> in-kernel Philox4x32-10 keyed by (seed, first_window_id+b, s, step, element or joint-pair group);
  *               else (S, max(ns-1,1), B, C, Tx, V): slot 0 = x_T, slot k = z added at step i = ns-k
  *               (what torch.randn_like returns at mocodad.py:162,176 in call order)
  *   step_table  (ns, 4+emb_dim): row i = [1/sqrt(alpha_i), (1-alpha_i)/sqrt(1-alpha_hat_i), sqrt(beta_i), 0,

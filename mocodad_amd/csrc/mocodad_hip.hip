@@ -450,27 +450,21 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
     };
     // later rounds: coefficients fetched one round ahead where the register budget allows (T = 3), else in place
     {
-        // every round's X reads up front as well: a round's stores may alias the next round's reads, which would
-        // otherwise wait for them (one LDS round trip per round on the wave's serial path)
-        float xs[PER][KS][T];
-        static_for<PER>([&](auto ri) {
-            constexpr int rnd = decltype(ri)::value;
-            const int u = M::unit_of(wave, rnd);
-            load_x(u < 0 ? 0 : u, xs[rnd]);
-        });
-        lds_reads_done();
-        static_for<PER>([&](auto ri) {
-            static_for<KS>([&](auto si) {
-                static_for<T>([&](auto ti) { lds_tie(xs[decltype(ri)::value][decltype(si)::value][decltype(ti)::value]); });
-            });
-        });
+        // each round reads its own X values (hand-issued reads cannot be sunk by the compiler: all rounds up front would
+        // keep PER*KS*T registers live and spill under the 128-VGPR cap)
         MixCoef<CIN, V, T, NB> cur = pre;
         static_for<PER>([&](auto ri) {
             constexpr int rnd = decltype(ri)::value;
             const int u = M::unit_of(wave, rnd);
+            float xs[KS][T];
+            load_x(u < 0 ? 0 : u, xs);
             MixCoef<CIN, V, T, NB> nxt;
             if constexpr (rnd + 1 < PER && !M::SAMEQ) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
-            if (u >= 0) unit(cur, u, xs[rnd]);
+            lds_reads_done();
+            static_for<KS>([&](auto si) {
+                static_for<T>([&](auto ti) { lds_tie(xs[decltype(si)::value][decltype(ti)::value]); });
+            });
+            if (u >= 0) unit(cur, u, xs);
             if constexpr (rnd + 1 < PER && !M::SAMEQ) cur = nxt;
         });
     }
@@ -692,7 +686,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `mc`: this layer's mix coefficients (already loaded); `pre_gemm` runs between the mix barrier and the GEMM, `pre_barrier`
 // between the GEMM and the closing barrier -- the callers use them to issue the NEXT stage's coefficient loads.
-template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, class H1, class H2>
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, int CSX = cs_of(CIN), class H1, class H2>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
                                               const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
                                               const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
@@ -706,7 +700,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     float4 afr[KQ1 + KQ2];
     load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     const float* bias = wb + lw.bias;
-    mix_stage<CIN, V, T, NB>(in, CSI, mc, wb + lw.tq, wb + lw.am, wave, lane,
+    mix_stage<CIN, V, T, NB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              [](int, int, int, int) { return 0.f; },
                              [&](int n, int q, int w0, int c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
@@ -740,12 +734,12 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
         }
     };
-    gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSI, wave, lane, epi);
+    gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi);
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
         load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
         bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
-        gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSI, wave, lane, epi, mi);
+        gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
     }
     pre_barrier();
     __syncthreads();
@@ -764,11 +758,11 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 // U-Net layer L of the fixed channel plan
 template <int L, int T, int NB>
 using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
-template <int L, int T, int NB, bool FORCE = false, class H1, class H2>
+template <int L, int T, int NB, bool FORCE = false, int CSX = cs_of(layer_desc(L).cin), class H1, class H2>
 __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
                                           const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
     constexpr LDesc D = layer_desc(L);
-    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE, CSX>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
                                                                prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
@@ -953,15 +947,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         XT[u * 4 + 1] = xv[1];
     }
     __syncthreads();
-    // U-Net input as a 16-channel block X20 (x in channels 0,1; 2..15 zero).  Written here for the first pass; the
-    // fused DDPM store of layer 10 rewrites it for every following pass.
-    for (int u = tid; u < COLS17 * 4; u += NTHREADS) {
-        const int col = u >> 2, c4 = (u & 3) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c4 == 0) { v.x = XT[col * 4 + 0]; v.y = XT[col * 4 + 1]; }
-        *reinterpret_cast<float4*>(RG + PL::L0_in + col * 20 + c4) = v;
-    }
-    __syncthreads();
 
     Prof prof;
 #ifdef MCD_PROFILE
@@ -1053,7 +1038,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         auto rs_early = rsload;
         NoHook nohook;
         LMix<1, T, NB> mc1;
-        layer_std<0, T, NB, (MINW <= 2)>(wb, mc0, RG + PL::L0_in, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
+        // layer 0 reads the chain state XT[col][4] in place (x in channels 0,1): its lanes' channels 2..15 are then other
+        // columns' coordinates -- finite, and multiplied by the zero-padded K rows of the layer's weights -- so no 16-channel
+        // copy of x has to be zeroed and rewritten every pass
+        layer_std<0, T, NB, (MINW <= 2), 4>(wb, mc0, XT, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc1, 1); }, nohook);                                           // sp1a (2 -> 16)
         STAGE(2);
         // ---- down path
@@ -1197,9 +1185,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 }
             }
             STAGE(18);
-            // next pass's U-Net input block: pad channels zeroed here, x written by the fused store below
-            for (int u = tid; u < COLS17 * 4; u += NTHREADS)
-                *reinterpret_cast<float4*>(RG + PL::L0_in + (u >> 2) * 20 + (u & 3) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             // next pass's embeddings: layers 0..9 straight into EMB (dead by now), layer 10's into the other E10 half
             emb_compute<NB>(ef, ef2, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid);
             STAGE(19);
@@ -1227,14 +1212,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     const int chain = chain0 + n;
                     if (chain < P.n_chains) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v] = eps;
                 } else {
-                    if ((WM[n] >> t) & 1) RG[PL::L0_in + col * 20 + c] = x;     // condition frame: copied to the next pass's input
                     const int cbase = UPD[tt & 15];
                     if (cbase >= 0) {
                         const int colp = cbase + v;
                         const float z = zadd ? ZN[colp * C0 + c] : 0.f;
                         const float xn = ca * (XT[colp * 4 + c] - cb * eps) + csg * z;
                         XT[colp * 4 + c] = xn;
-                        RG[PL::L0_in + colp * 20 + c] = xn;
                     }
                 }
             }
@@ -1750,10 +1733,10 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
 #else
     switch (T) {
         case 3:
+            if (variant == 0) return launch_score_t<3, 2, 4>(P, st);   // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
             if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st);   // 4 chains / WG, 1 WG per CU
-            if (variant == 2) return launch_score_t<3, 2, 2>(P, st);
             if (variant == 3) return launch_score_t<3, 1, 4>(P, st);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
-            return launch_score_t<3, 2, 4>(P, st);                     // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
+            return launch_score_t<3, 2, 2>(P, st);
         case 6:
             if (variant == 1) return launch_score_t<6, 2, 2>(P, st);   // 2 chains / WG, 1 WG per CU (no register cap)
             return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
