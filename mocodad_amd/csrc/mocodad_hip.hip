@@ -266,20 +266,6 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// LDS reads issued by hand (see mix_stage): byte address + immediate offset; the compiler does not track them, so the
-// consumer calls lds_reads_done() (a full lgkmcnt wait) and ties every loaded register behind it with lds_tie()
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
-}
-template <class Z>
-__device__ __forceinline__ float ds_read_imm(unsigned addr, Z, int off) {
-    float r;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(off) : "memory");
-    return r;
-}
-__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void lds_tie(float& x) { asm volatile("" : "+v"(x)); }
-
 // Joint handled by lane group g at k-step ks of the mix.  K-steps are paired over 8 consecutive joints so that the two
 // lane groups sharing an LDS access phase (g = 0,1 and g = 2,3) read rows 4 apart: with a row stride of 4*odd floats
 // that is a 16-bank shift, i.e. conflict-free ds_read_b32.  A trailing unpaired k-step uses joints 8p+g.
@@ -372,14 +358,8 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             constexpr int ks = decltype(si)::value;
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
             const float* xb = ks < KP ? xin_p : xin_l;
-            // explicit ds_read_b32 with 16-bit immediate offsets: the compiler merges these reads into ds_read2_b32 (8-bit
-            // offsets) and then re-bases the address with a VALU add for every other pair -- VALU issue time is what the
-            // kernel is short of.  Results are valid after the s_waitcnt in lds_reads_done().
-            const unsigned xa = lds_addr(xb);
-            static_for<T>([&](auto ti) {
-                constexpr int t = decltype(ti)::value;
-                x[ks][t] = ds_read_imm(xa, std::integral_constant<int, 0>{}, (t * V + vbase) * cs_in * 4);
-            });
+#pragma unroll
+            for (int t = 0; t < T; ++t) x[ks][t] = xb[(t * V + vbase) * cs_in];
         });
     };
     auto unit = [&](const MixCoef<CIN, V, T, NB>& cur, int u, const float (&xs)[KS][T]) {
@@ -450,8 +430,6 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
     };
     // later rounds: coefficients fetched one round ahead where the register budget allows (T = 3), else in place
     {
-        // each round reads its own X values (hand-issued reads cannot be sunk by the compiler: all rounds up front would
-        // keep PER*KS*T registers live and spill under the 128-VGPR cap)
         MixCoef<CIN, V, T, NB> cur = pre;
         static_for<PER>([&](auto ri) {
             constexpr int rnd = decltype(ri)::value;
@@ -460,10 +438,6 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             load_x(u < 0 ? 0 : u, xs);
             MixCoef<CIN, V, T, NB> nxt;
             if constexpr (rnd + 1 < PER && !M::SAMEQ) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
-            lds_reads_done();
-            static_for<KS>([&](auto si) {
-                static_for<T>([&](auto ti) { lds_tie(xs[decltype(si)::value][decltype(ti)::value]); });
-            });
             if (u >= 0) unit(cur, u, xs);
             if constexpr (rnd + 1 < PER && !M::SAMEQ) cur = nxt;
         });
