@@ -230,9 +230,12 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 // PReLU(x) = x >= 0 ? x : a x  ==  max(x, a x) for a <= 1, min(x, a x) for a > 1: one multiply and one v_med3_f32 against
 // +-inf picked by the (wave-uniform) slope -- the compare + select form costs a third VALU instruction per element, and
 // the fp32 MFMAs share the SIMD's issue time with the VALU (tools/ubench/coissue.hip)
-__device__ __forceinline__ float prelu(float x, float a) {
-    return __builtin_amdgcn_fmed3f(x, a * x, a <= 1.f ? __builtin_inff() : -__builtin_inff());
+// +inf for a slope <= 1, -inf above: as an integer compare of the float's bits (monotonic for non-negative floats, negative
+// ones are negative integers), which stays on the scalar unit for a wave-uniform slope -- gfx950 has no scalar float compare
+__device__ __forceinline__ float prelu_bound(float a) {
+    return __int_as_float(__float_as_int(a) <= 0x3f800000 ? 0x7f800000 : (int)0xff800000);
 }
+__device__ __forceinline__ float prelu(float x, float a) { return __builtin_amdgcn_fmed3f(x, a * x, prelu_bound(a)); }
 
 // ------------------------------------------------------------------------------------------------
 // DPP helpers.  A coefficient row (<= 16 values) lives in ONE VGPR, value i in lane i of every 16-lane row
@@ -340,6 +343,8 @@ struct MixCoef {
     }
 };
 
+// init functor of a mix whose accumulators start at zero (x + 0.f is not folded away: -0.0)
+struct ZeroInit { __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; } };
 template <int CIN, int V, int T, int NB, class Init, class Store>
 __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const MixCoef<CIN, V, T, NB>& pre,
                                           const float* __restrict__ tqd, const float* __restrict__ af, int wave, int lane,
@@ -424,7 +429,11 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                 const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
                 const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
                 const float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]);
-                if (g == 0) store(n, q0 + qi, 16, cb * 16 + j, z16 + init(n, q0 + qi, 16, cb * 16 + j));
+                if constexpr (std::is_same_v<std::decay_t<Init>, ZeroInit>) {
+                    if (g == 0) store(n, q0 + qi, 16, cb * 16 + j, z16);
+                } else {
+                    if (g == 0) store(n, q0 + qi, 16, cb * 16 + j, z16 + init(n, q0 + qi, 16, cb * 16 + j));
+                }
             }
         }
     };
@@ -675,7 +684,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     const float* bias = wb + lw.bias;
     mix_stage<CIN, V, T, NB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
-                             [](int, int, int, int) { return 0.f; },
+                             ZeroInit{},
                              [&](int n, int q, int w0, int c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
                                  // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store)
@@ -693,7 +702,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
     pre_gemm();
     const float slope = lw.slope;
-    const float pinf = slope <= 1.f ? __builtin_inff() : -__builtin_inff();     // see prelu()
+    const float pinf = prelu_bound(slope);     // see prelu()
     auto epi = [&](auto, int col, int c0, f32x4 acc) {
         if (col < COLS && c0 < COUT) {
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1074,7 +1083,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             __syncthreads();
             STAGE(10);
             const float slope6 = lw.slope;
-            const float pinf6 = slope6 <= 1.f ? __builtin_inff() : -__builtin_inff();
+            const float pinf6 = prelu_bound(slope6);
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w0, int c, std::true_type) {   // the fragment's 4 joints at once
                                          const float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
@@ -1168,7 +1177,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const bool single = P.mode == 1, zadd = sidx > 1;
             const int e10_off = (sidx & 1) * 16;
             mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
-                                     [](int, int, int, int) { return 0.f; },
+                                     ZeroInit{},
                                      [&](int n, int t, int v, int c, float val) {
                                          if (c < C0) ZO[((n * T + t) * 17 + v) * C0 + c] = val;
                                      });
