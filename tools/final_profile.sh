@@ -2,13 +2,13 @@ set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-timeout 300 python $R/bench.py > $O/bench_r01r.json 2> $O/bench_r01r.err
-tail -c 600 $O/bench_r01r.json
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_r1r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_r1r.log 2>&1
+timeout 300 python $R/bench.py > $O/bench_r01s.json 2> $O/bench_r01s.err
+tail -c 600 $O/bench_r01s.json
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_r1s -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_r1s.log 2>&1
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc_r$i -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_r$i.log 2>&1
-  tail -1 $O/pmc_r$i.log | head -c 200; echo
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc_s$i -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_s$i.log 2>&1
+  tail -1 $O/pmc_s$i.log | head -c 200; echo
 done
-find $O/prof_r1r $O/pmc_r* -name "*_results.db" | head
+find $O/prof_r1s $O/pmc_s* -name "*_results.db" | head
