@@ -102,9 +102,13 @@ def main():
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams consecutive batches alternate over (2: the ramp of "
                     "batch i+1 fills the tail of batch i, +2 %; per-launch durations then overlap, so the default keeps 1)")
+    ap.add_argument("--bf16x3", action="store_true", help="OPT-IN, not the headline: channel GEMMs on the bf16 matrix path with both "
+                    "operands split into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate; scores within ~1e-6 of the fp32 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
+    if args.bf16x3:
+        os.environ["MCD_BF16X3"] = "1"     # read once by the library, before its first launch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,13 +193,13 @@ def main():
             "metric": "pose-clips/sec (whole node) @ noise_steps=10, 5 samples",
             "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3 split operands, f32 accumulate (opt-in)" if args.bf16x3 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: HR-Avenue-shaped windows (seg_len 6 = 3 cond + 3 denoised, 17 joints), "
                                    f"noise_steps={ns}, {S} generated samples, inject conditioning, 'best' aggregation",
                        "windows_per_step_per_gpu": B, "denoiser_passes_per_window": P, "weights": "seeded random init (tests/golden/weights_inject.npz)",
                        "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), all-gather of scores",
                        "streams": max(args.streams, 1)},
-            "roofline": {"bound": "mfma", "kernel": "score_kernel<3,2,4> (+ cond_fast_kernel<3,2>)", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": ("score_kernel<3,2,4,bf16x3>" if args.bf16x3 else "score_kernel<3,2,4>") + " (+ cond_fast_kernel<3,2>)", "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
                          "hbm_algorithmic_bytes_per_window": 820,

@@ -86,7 +86,7 @@ __host__ __device__ constexpr int emb_off(int l) {
 // buffer start).  The kernel scalar-loads an entry right where it is used; keeping the table out of the
 // kernarg segment stops the compiler from hoisting ~100 pointers into SGPRs for the whole trajectory loop.
 constexpr int TAB_FLOATS = 256;   // [0,128): U-Net table, [128,256): fast condition-encoder table
-enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_STRIDE = 8 };
+enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_WPB = 5, F_STRIDE = 8 };
 //   tab[l*8 + F_TQ]    time-mix coefficients packed 16 per VGPR for DPP row broadcast, TQD[q][r][64]:
 //                      lane 16g+i = gcn.T[v = mix_vmap(s,g)][t][q] with s*T+t = 16r+i
 //   tab[l*8 + F_AM]    MFMA A-operand fragments of A_q^T, AF[q][mt][s][64]: lane (i, g) = gcn.A[q][v=mix_vmap(s,g)][w=16mt+i]
@@ -99,12 +99,13 @@ constexpr int TAB_RSW = 90, TAB_RSB = 94; // down1, down2, up3, up2: MFMA A frag
 typedef const int __attribute__((address_space(4))) cint;
 __device__ __forceinline__ int tab_i(const float* base, int idx) { return ((cint*)base)[idx]; }
 __device__ __forceinline__ float tab_f(const float* base, int idx) { return ((cfloat*)base)[idx]; }
-struct LayerW { int tq, am, wp, bias; float slope; };
+struct LayerW { int tq, am, wp, bias; float slope; int wpb; };   // wpb: split-bf16 fragments (layers 2..9), see gemm_tiles_bf3
 __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
     LayerW w;
     w.tq = tab_i(base, l * F_STRIDE + F_TQ); w.am = tab_i(base, l * F_STRIDE + F_AM);
     w.wp = tab_i(base, l * F_STRIDE + F_WP); w.bias = tab_i(base, l * F_STRIDE + F_BIAS);
     w.slope = tab_f(base, l * F_STRIDE + F_SLOPE);
+    w.wpb = tab_i(base, l * F_STRIDE + F_WPB);
     return w;
 }
 
@@ -662,6 +663,62 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// OPT-IN (MCD_BF16X3=1, not the measured default): the same channel GEMM on the bf16 matrix path with both operands
+// split into bf16 pairs, x = hi + lo, and hi*hi + hi*lo + lo*hi accumulated in fp32 -- three v_mfma_f32_16x16x32_bf16
+// per K = 32 instead of eight v_mfma_f32_16x16x4_f32 (which run at the vector-FP32 rate and hold the SIMD's FP32 lanes).
+// Scores stay within ~1e-6 of the fp32 path (tests/studies/bf16x3_error.py).  Weights are split at pack time
+// ([m-tile][K/32][hi, lo][lane] x 8 bf16: lane (row, g) holds k = 32 ch + 8 g + i); activations are split here, as they
+// are read (lane (col j, g): channels 32 ch + 8 g + i, two ds_read_b128).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int MT, int CH>
+__device__ __forceinline__ void load_afrags_bf3(const float4* __restrict__ wp, int wave, int lane, float4 (&a)[2 * CH], int mi = 0) {
+    const float* wpl = reinterpret_cast<const float*>(wp + (((wave + mi * NWAVES) % MT) * CH * 2) * 64 + lane);
+#pragma unroll
+    for (int i = 0; i < 2 * CH; ++i) a[i] = load_global4(wpl + i * 256);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4& f) { return __builtin_bit_cast(bf16x8, f); }
+template <int MT, int NT, int CH1, int CH2, bool IDRES = false, class Epi>
+__device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)], const float* __restrict__ b1, int cs1,
+                                               const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0) {
+    constexpr int NG = Tiling<MT, NT>::NG;
+    constexpr int MAXN = Tiling<MT, NT>::MAXN;
+    const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
+    const int j = lane & 15, g = lane >> 4;
+    const int c0 = mt * 16 + 4 * g;
+    static_for<MAXN>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const int nt = ng + i * NG;
+        if (nt < NT) {
+            const int col = nt * 16 + j;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            if (IDRES) {
+                const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + c0);
+                c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
+            }
+            const float* p1 = b1 + col * cs1 + 8 * g;
+            const float* p2 = b2 + col * cs2 + 8 * g;
+            static_for<CH1 + CH2>([&](auto cc) {
+                constexpr int ch = decltype(cc)::value;
+                const float* p = ch < CH1 ? p1 + ch * 32 : p2 + (ch - CH1) * 32;
+                const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
+                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hi[e] = (__bf16)x[e];
+                    lo[e] = (__bf16)(x[e] - (float)hi[e]);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), hi, c, 0, 0, 0);       // hi_w * hi_x
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), lo, c, 0, 0, 0);       // hi_w * lo_x
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch + 1]), hi, c, 0, 0, 0);   // lo_w * hi_x
+            });
+            epi(ii, col, c0, c);
+        }
+    });
+}
+
 // one mix-first ST-GCN layer: LDS `in` -> `out`, with `z` as scratch; the three regions are disjoint.
 // generic mix-first ST-GCN layer (CIN -> COUT at V joints), used by the U-Net and by the condition encoder.
 // HASEMB = false: no embedding term (condition-encoder layers get t = None, components.py:56-63).
@@ -669,7 +726,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `mc`: this layer's mix coefficients (already loaded); `pre_gemm` runs between the mix barrier and the GEMM, `pre_barrier`
 // between the GEMM and the closing barrier -- the callers use them to issue the NEXT stage's coefficient loads.
-template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, int CSX = cs_of(CIN), class H1, class H2>
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, int CSX = cs_of(CIN), bool BF3 = false, class H1, class H2>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
                                               const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
                                               const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
@@ -681,7 +738,9 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     constexpr int CSI = cs_of(CIN), CSO = cs_of(COUT);
     constexpr int KQ1 = CIN / 16, KQ2 = RES ? CIN / 16 : 0;
     float4 afr[KQ1 + KQ2];
-    load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+    static_assert(!BF3 || KQ1 % 2 == 0, "split-bf16 path: K a multiple of 32 per operand buffer");
+    if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr);
+    else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     const float* bias = wb + lw.bias;
     mix_stage<CIN, V, T, NB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
@@ -717,12 +776,15 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
         }
     };
-    gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi);
+    if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES>(afr, z, CSI, in, CSX, wave, lane, epi);
+    else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi);
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
-        load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
+        if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, mi);
+        else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
         bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
-        gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
+        if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
+        else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
     }
     pre_barrier();
     __syncthreads();
@@ -741,11 +803,11 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 // U-Net layer L of the fixed channel plan
 template <int L, int T, int NB>
 using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
-template <int L, int T, int NB, bool FORCE = false, int CSX = cs_of(layer_desc(L).cin), class H1, class H2>
+template <int L, int T, int NB, bool FORCE = false, int CSX = cs_of(layer_desc(L).cin), bool BF3 = false, class H1, class H2>
 __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
                                           const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
     constexpr LDesc D = layer_desc(L);
-    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE, CSX>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE, CSX, BF3>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
                                                                prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
@@ -847,7 +909,7 @@ struct Plan {
 // The persistent scoring kernel.  mode 0: full reverse-diffusion trajectories + loss (mcd_score);
 // mode 1: one eps-prediction pass (mcd_unet_forward).
 // ------------------------------------------------------------------------------------------------
-template <int T, int NB, int MINW>
+template <int T, int NB, int MINW, bool BF3 = false>
 __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams P) {
     using PL = Plan<T, NB>;
     constexpr int TV17 = T * 17;
@@ -1036,7 +1098,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
         RsCoef<32, 17, 12, T, NB, true> rc1;
-        layer_std<2, T, NB, (MINW <= 2)>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
+        layer_std<2, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
         STAGE(4);
         LMix<3, T, NB> mc3;
@@ -1045,11 +1107,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         __syncthreads();
         STAGE(5);
         LMix<4, T, NB> mc4;
-        layer_std<3, T, NB, (MINW <= 2)>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
+        layer_std<3, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
         STAGE(6);
         RsCoef<64, 12, 10, T, NB, true> rc2;
-        layer_std<4, T, NB, (MINW <= 2)>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
+        layer_std<4, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
         STAGE(7);
         LMix<5, T, NB> mc5;
@@ -1065,8 +1127,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
-            layer_std<5, T, NB, (MINW <= 2)>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
-                                [&] { load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0); });  // sd3.0
+            layer_std<5, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
+                                [&] {
+                                    if constexpr (BF3) load_afrags_bf3<8, 4>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, 0);
+                                    else load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
+                                });  // sd3.0
             STAGE(9);
             float* Pb = RG + PL::L6_p;
             MixCoef<64, 10, T, NB> mc6;
@@ -1074,11 +1139,17 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
-            gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
+            if constexpr (BF3) gemm_tiles_bf3<8, NT, 4, 0>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
+            else gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
 #pragma unroll
             for (int mi = 1; mi < Tiling<8, NT>::MW; ++mi) {
-                load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
-                gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+                if constexpr (BF3) {
+                    load_afrags_bf3<8, 4>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, mi);
+                    gemm_tiles_bf3<8, NT, 4, 0>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+                } else {
+                    load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
+                    gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+                }
             }
             __syncthreads();
             STAGE(10);
@@ -1113,11 +1184,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         __syncthreads();
         STAGE(12);
         LMix<8, T, NB> mc8;
-        layer_std<7, T, NB, (MINW <= 2)>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
+        layer_std<7, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
         STAGE(13);
         RsCoef<32, 12, 17, T, NB, false> rc4;
-        layer_std<8, T, NB, (MINW <= 2)>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
+        layer_std<8, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
         STAGE(14);
         LMix<9, T, NB> mc9;
@@ -1134,7 +1205,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // conditionally loaded register struct costs ~35 VGPRs of phi copies here.
             EmbRow ef;
             auto ef_load = [&] { ef.load(wb, tid); };
-            layer_std<9, T, NB, (MINW <= 2)>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
+            layer_std<9, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
                                     mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
                                     ef_load();
@@ -1662,6 +1733,30 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
 // MFMA A-operand fragment order of a logical [M][K] matrix (M, K multiples of 16) with the K permutation that lets
 // one ds_read_b128 of the B operand feed four k-steps (see gemm_tiles): element e of lane (i, g) in group kq is
 // W[16 mt + i][16 kq + 4 g + e]  (k-step e of the group covers channels {16 kq + 4 g + e : g = 0..3}).
+// round-to-nearest-even float -> bf16 bits (what v_cvt_pk_bf16_f32 does for finite values)
+static inline unsigned short bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_to_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// split-bf16 fragments of gemm_tiles_bf3: [m-tile][K/32][hi, lo][lane] x 8 bf16 (4 floats), lane (row, g): k = 32 ch + 8 g + i
+template <class F>
+int pack_gemm_frags_bf3(Builder& B, int M, int K, F&& w) {
+    const int MTn = M / 16, CH = K / 32;
+    const int off = B.alloc((size_t)MTn * CH * 2 * 64 * 4);
+    for (int mt = 0; mt < MTn; ++mt) for (int ch = 0; ch < CH; ++ch) for (int lane = 0; lane < 64; ++lane) {
+        const int row = mt * 16 + (lane & 15), g = lane >> 4;
+        unsigned short hi[8], lo[8];
+        for (int i = 0; i < 8; ++i) {
+            const float v = (float)w(row, ch * 32 + 8 * g + i);
+            hi[i] = bf16_rne(v);
+            lo[i] = bf16_rne(v - bf16_to_f(hi[i]));
+        }
+        memcpy(&B.buf[off + ((size_t)((mt * CH + ch) * 2 + 0) * 64 + lane) * 4], hi, 16);
+        memcpy(&B.buf[off + ((size_t)((mt * CH + ch) * 2 + 1) * 64 + lane) * 4], lo, 16);
+    }
+    return off;
+}
 template <class F>
 int pack_gemm_frags(Builder& B, int M, int K, F&& w) {
     const int MTn = M / 16, KQ = K / 16;
@@ -1689,33 +1784,38 @@ struct mcd_weights {
 
 namespace {
 
-template <int T, int NB, int MINW>
+template <int T, int NB, int MINW, bool BF3 = false>
 int launch_score_t(const ScoreParams& P, hipStream_t st) {
     using PL = Plan<T, NB>;
     static bool attr_set[16] = {false};
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW, BF3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::BYTES));
         attr_set[dev] = true;
     }
     const int nblocks = (P.n_chains + NB - 1) / NB;
-    hipLaunchKernelGGL((score_kernel<T, NB, MINW>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
+    hipLaunchKernelGGL((score_kernel<T, NB, MINW, BF3>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
 
 int launch_score(int T, const ScoreParams& P, hipStream_t st) {
     static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
+    // opt-in split-bf16 channel GEMMs (layers 2..9) for the default shape (see gemm_tiles_bf3); everything measured and
+    // reported by bench.py uses the fp32 path
+    static const bool bf3 = getenv("MCD_BF16X3") && atoi(getenv("MCD_BF16X3")) != 0;
 #ifdef MCD_FAST_T6      // developer builds: one instantiation
     return launch_score_t<6, 1, 4>(P, st);
 #elif defined(MCD_FAST_BUILD)   // developer builds: only the two default-shape instantiations
+    if (T == 3 && bf3) return launch_score_t<3, 2, 4, true>(P, st);
     if (T == 3) return variant == 2 ? launch_score_t<3, 2, 2>(P, st) : launch_score_t<3, 2, 4>(P, st);
     return fail(MCD_EUNSUPPORTED, "fast build");
 #else
     switch (T) {
         case 3:
+            if (bf3) return launch_score_t<3, 2, 4, true>(P, st);
             if (variant == 0) return launch_score_t<3, 2, 4>(P, st);   // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
             if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st);   // 4 chains / WG, 1 WG per CU
             if (variant == 3) return launch_score_t<3, 1, 4>(P, st);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
@@ -1809,7 +1909,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
 
     Builder B;
-    struct HostLayer { int tq, am, wp, bias; float slope; };
+    struct HostLayer { int tq, am, wp, bias; float slope; int wpb; };
     struct { HostLayer L[NLAYERS]; int we, be, rs_w[4], rs_b[4]; } U;
     memset(&U, 0, sizeof(U));
     B.alloc(TAB_FLOATS);  // offset table lives at the start of the buffer
@@ -1855,6 +1955,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             for (int r = 0; r < 4; ++r) for (int k = 0; k < 32; ++k) B.buf[U.L[l].wp + r * 32 + k] = (float)wcat(r, k);
         } else {
             U.L[l].wp = pack_gemm_frags(B, M, Kc, wcat);
+            if (l >= 2 && l <= 9) U.L[l].wpb = pack_gemm_frags_bf3(B, M, Kc, wcat);
         }
     }
     static const char* rs_names[4] = {"down1", "down2", "up3", "up2"};
@@ -2000,6 +2101,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             tab[l * F_STRIDE + F_TQ] = U.L[l].tq; tab[l * F_STRIDE + F_AM] = U.L[l].am;
             tab[l * F_STRIDE + F_WP] = U.L[l].wp; tab[l * F_STRIDE + F_BIAS] = U.L[l].bias;
             memcpy(&tab[l * F_STRIDE + F_SLOPE], &U.L[l].slope, sizeof(float));
+            tab[l * F_STRIDE + F_WPB] = U.L[l].wpb;
         }
         tab[TAB_WE] = U.we; tab[TAB_BE] = U.be;
         if (cond_unet) for (int i = 0; i <= TABC_ULB; ++i) tab[TABC + i] = utab[i];

@@ -1,0 +1,46 @@
+"""GPU: the opt-in split-bf16 GEMM path (MCD_BF16X3=1; hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate)
+against the golden trajectories generated from the reference.  The library reads the switch once per process, so the check
+runs in a subprocess.  Same tolerance as the fp32 path: 1e-4 absolute on scores; the measured error is printed."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+import numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_golden
+from mocodad_amd.engine import HipScorer
+from oracle import mocodad_oracle as O
+worst = 0.0
+for ns, S in ((2, 1), (10, 5), (50, 8)):
+    w = load_golden("weights_inject.npz")
+    cfg = json.loads(bytes(w.pop("__cfg__")).decode())
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    ci, xi = O.split_indices(cfg["seg_len"], cfg["conditioning_indices"], "inject")
+    sc = HipScorer(sd, strategy="inject", seg_len=cfg["seg_len"], cond_idx=ci, corrupt_idx=xi,
+                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+    g = load_golden(f"traj_inject_ns{ns}_S{S}.npz")
+    loss, poses = sc.score(torch.from_numpy(g["data"]), n_samples=S, noise_steps=ns,
+                           noise=torch.from_numpy(g["noise"].astype(np.float32)), want_poses=True)
+    e = float(np.abs(loss.cpu().numpy() - g["loss_all"]).max())
+    p = float(np.abs(poses.cpu().numpy() - g["poses_all"]).max())
+    print(f"ns={ns} S={S}: max|score - golden| = {e:.3e}  max|pose - golden| = {p:.3e}")
+    worst = max(worst, e)
+print("WORST", worst)
+assert worst < 1e-4
+"""
+
+
+def test_split_bf16_gemms_vs_golden_trajectories():
+    env = dict(os.environ, MCD_BF16X3="1")
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True, text=True,
+                       timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "WORST" in r.stdout
