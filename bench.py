@@ -30,7 +30,7 @@ F_COND_T3 = 545_904
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 # HBM bytes per launch of the default workload from the rocprofv3 PMC passes (see profiles/)
 HBM_TRAFFIC_DEFAULT = 7.65e6   # (2 x 2706.0 + 80 + 2 x 1010.5 + 64 + 2 x 32.5 + 4) KB: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-HBM_TRAFFIC_SOURCE = "profiles/r01s_pmc.txt"
+HBM_TRAFFIC_SOURCE = "profiles/r01t_pmc.txt"
 PEAK_HBM_GBS = 8000.0
 
 
