@@ -108,6 +108,12 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
  * encoder also accept workspace == NULL. */
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
+/* Environment switches read once per process by the library (tuning / opt-in, none needed for normal use):
+ *   MCD_BF16X3=1   channel GEMMs of the default shape (3 U-Net frames) on the bf16 matrix path with both operands split
+ *                  into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate): scores within ~2e-6 of the fp32 path, ~35 %
+ *                  faster.  Off by default: the shipped, measured path computes in fp32.
+ *   MCD_VARIANT=n  alternative workgroup shapes of the trajectory kernel (tuning experiments only). */
+
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.
  *   data        (B,C,T,V) windows
  *   noise       NULL -> in-kernel Philox4x32-10 keyed by (seed, first_window_id+b, s, step, element or joint-pair group);
