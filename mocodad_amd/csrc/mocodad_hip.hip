@@ -679,7 +679,28 @@ __device__ __forceinline__ void load_afrags_bf3(const float4* __restrict__ wp, i
     for (int i = 0; i < 2 * CH; ++i) a[i] = load_global4(wpl + i * 256);
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const float4& f) { return __builtin_bit_cast(bf16x8, f); }
-template <int MT, int NT, int CH1, int CH2, bool IDRES = false, class Epi>
+// A tensor that only a split-bf16 GEMM reads (a layer's mix output z, layer 5's output) is stored already split, one
+// 32-bit word per element: bf16 hi in the upper half, bf16 lo in the lower -- the producer splits each element once, the
+// GEMM's m-tiles (up to 8 per element) only regroup the halves with v_perm_b32
+__device__ __forceinline__ float pack_hl(float x) {
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    const unsigned w = ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo);
+    return __uint_as_float(w);
+}
+__device__ __forceinline__ void unpack_hl(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
+    const unsigned w[8] = {__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z), __float_as_uint(x0.w),
+                           __float_as_uint(x1.x), __float_as_uint(x1.y), __float_as_uint(x1.z), __float_as_uint(x1.w)};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);   // upper halves of the pair
+        l[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);   // lower halves
+    }
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+template <int MT, int NT, int CH1, int CH2, bool IDRES = false, bool P1 = false, bool P2 = false, class Epi>
 __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)], const float* __restrict__ b1, int cs1,
                                                const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0) {
     constexpr int NG = Tiling<MT, NT>::NG;
@@ -703,12 +724,16 @@ __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)
                 constexpr int ch = decltype(cc)::value;
                 const float* p = ch < CH1 ? p1 + ch * 32 : p2 + (ch - CH1) * 32;
                 const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
-                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                 bf16x8 hi, lo;
+                if constexpr (ch < CH1 ? P1 : P2) {
+                    unpack_hl(x0, x1, hi, lo);
+                } else {
+                    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    hi[e] = (__bf16)x[e];
-                    lo[e] = (__bf16)(x[e] - (float)hi[e]);
+                    for (int e = 0; e < 8; ++e) {
+                        hi[e] = (__bf16)x[e];
+                        lo[e] = (__bf16)(x[e] - (float)hi[e]);
+                    }
                 }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), hi, c, 0, 0, 0);       // hi_w * hi_x
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), lo, c, 0, 0, 0);       // hi_w * lo_x
@@ -726,7 +751,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `mc`: this layer's mix coefficients (already loaded); `pre_gemm` runs between the mix barrier and the GEMM, `pre_barrier`
 // between the GEMM and the closing barrier -- the callers use them to issue the NEXT stage's coefficient loads.
-template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, int CSX = cs_of(CIN), bool BF3 = false, class H1, class H2>
+template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, int CSX = cs_of(CIN), bool BF3 = false, bool OUTP = false, class H1, class H2>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
                                               const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
                                               const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
@@ -751,9 +776,9 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                                  if constexpr (std::is_same_v<decltype(v), f32x4>) {
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)
-                                         if (w0 + r < V) zp[r * CSI] = v[r];
+                                         if (w0 + r < V) zp[r * CSI] = BF3 ? pack_hl(v[r]) : v[r];     // (z feeds the GEMM only)
                                  } else {
-                                     *zp = v;
+                                     *zp = BF3 ? pack_hl(v) : v;
                                  }
                              });
     __syncthreads();
@@ -773,17 +798,18 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             const f32x2 m0 = t0 * slope, m1 = t1 * slope;
             const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf)} + f32x2{e.x, e.y};
             const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf)} + f32x2{e.z, e.w};
-            *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
+            if constexpr (OUTP) *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(pack_hl(r0[0]), pack_hl(r0[1]), pack_hl(r1[0]), pack_hl(r1[1]));
+            else *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
         }
     };
-    if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES>(afr, z, CSI, in, CSX, wave, lane, epi);
+    if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi);
     else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi);
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
         if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, mi);
         else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
         bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
-        if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
+        if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
         else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
     }
     pre_barrier();
@@ -803,11 +829,11 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 // U-Net layer L of the fixed channel plan
 template <int L, int T, int NB>
 using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
-template <int L, int T, int NB, bool FORCE = false, int CSX = cs_of(layer_desc(L).cin), bool BF3 = false, class H1, class H2>
+template <int L, int T, int NB, bool FORCE = false, int CSX = cs_of(layer_desc(L).cin), bool BF3 = false, bool OUTP = false, class H1, class H2>
 __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
                                           const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
     constexpr LDesc D = layer_desc(L);
-    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE, CSX, BF3>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
+    layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE, CSX, BF3, OUTP>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
                                                                prof, 32 + 3 * L, pre_gemm, pre_barrier);
 }
 
@@ -1127,7 +1153,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
-            layer_std<5, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
+            layer_std<5, T, NB, (MINW <= 2), cs_of(64), BF3, BF3>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
                                 [&] {
                                     if constexpr (BF3) load_afrags_bf3<8, 4>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, 0);
                                     else load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
@@ -1139,13 +1165,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
-            if constexpr (BF3) gemm_tiles_bf3<8, NT, 4, 0>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
+            if constexpr (BF3) gemm_tiles_bf3<8, NT, 4, 0, false, true, true>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
             else gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
 #pragma unroll
             for (int mi = 1; mi < Tiling<8, NT>::MW; ++mi) {
                 if constexpr (BF3) {
                     load_afrags_bf3<8, 4>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, mi);
-                    gemm_tiles_bf3<8, NT, 4, 0>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+                    gemm_tiles_bf3<8, NT, 4, 0, false, true, true>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
                 } else {
                     load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
                     gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
