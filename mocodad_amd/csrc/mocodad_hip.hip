@@ -683,10 +683,10 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const float4& f) { return __builtin_
 // 32-bit word per element: bf16 hi in the upper half, bf16 lo in the lower -- the producer splits each element once, the
 // GEMM's m-tiles (up to 8 per element) only regroup the halves with v_perm_b32
 __device__ __forceinline__ float pack_hl(float x) {
-    const __bf16 hi = (__bf16)x;
-    const __bf16 lo = (__bf16)(x - (float)hi);
-    const unsigned w = ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo);
-    return __uint_as_float(w);
+    // hi = x truncated to bf16 (a mask, exact), lo = bf16(x - hi) rounded to nearest: |x - hi - lo| <= 2^-17 |x|
+    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+    const __bf16 lo = (__bf16)(x - __uint_as_float(hb));
+    return __uint_as_float(hb | (unsigned)__builtin_bit_cast(unsigned short, lo));
 }
 __device__ __forceinline__ void unpack_hl(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
     const unsigned w[8] = {__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z), __float_as_uint(x0.w),
@@ -729,11 +729,13 @@ __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)
                     unpack_hl(x0, x1, hi, lo);
                 } else {
                     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    unsigned h[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        hi[e] = (__bf16)x[e];
-                        lo[e] = (__bf16)(x[e] - (float)hi[e]);
-                    }
+                    for (int e = 0; e < 8; ++e) lo[e] = (__bf16)(x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)      // truncated hi halves of an element pair, one v_perm_b32 (see pack_hl)
+                        h[e] = __builtin_amdgcn_perm(__float_as_uint(x[2 * e + 1]), __float_as_uint(x[2 * e]), 0x07060302u);
+                    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
                 }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), hi, c, 0, 0, 0);       // hi_w * hi_x
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), lo, c, 0, 0, 0);       // hi_w * lo_x
