@@ -679,26 +679,29 @@ __device__ __forceinline__ void load_afrags_bf3(const float4* __restrict__ wp, i
     for (int i = 0; i < 2 * CH; ++i) a[i] = load_global4(wpl + i * 256);
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const float4& f) { return __builtin_bit_cast(bf16x8, f); }
-// A tensor that only a split-bf16 GEMM reads (a layer's mix output z, layer 5's output) is stored already split, one
-// 32-bit word per element: bf16 hi in the upper half, bf16 lo in the lower -- the producer splits each element once, the
-// GEMM's m-tiles (up to 8 per element) only regroup the halves with v_perm_b32
-__device__ __forceinline__ float pack_hl(float x) {
-    // hi = x truncated to bf16 (a mask, exact), lo = bf16(x - hi) rounded to nearest: |x - hi - lo| <= 2^-17 |x|
-    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-    const __bf16 lo = (__bf16)(x - __uint_as_float(hb));
-    return __uint_as_float(hb | (unsigned)__builtin_bit_cast(unsigned short, lo));
+// A tensor that only a split-bf16 GEMM reads (a layer's mix output z, layer 5's output) is stored already split, as two
+// bf16 planes inside its fp32-sized row: channels' hi halves in bytes [0, 2C), their lo halves in [2C, 4C).  The producer
+// splits each element once (hi = the element truncated to bf16 -- its upper 16 bits, stored as they are; lo = bf16 of the
+// exact remainder); the GEMM's m-tiles (up to 8 per element) read ready-made fragments with one ds_read_b128 per plane.
+__device__ __forceinline__ unsigned short bf16_lo_bits(float x) {
+    const __bf16 lo = (__bf16)(x - __uint_as_float(__float_as_uint(x) & 0xffff0000u));
+    return __builtin_bit_cast(unsigned short, lo);
 }
-__device__ __forceinline__ void unpack_hl(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
-    const unsigned w[8] = {__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z), __float_as_uint(x0.w),
-                           __float_as_uint(x1.x), __float_as_uint(x1.y), __float_as_uint(x1.z), __float_as_uint(x1.w)};
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);   // upper halves of the pair
-        l[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);   // lower halves
-    }
-    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
-    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+template <int C>
+__device__ __forceinline__ void store_split(float* row, int c, float x) {      // one element
+    unsigned short* h = reinterpret_cast<unsigned short*>(row) + c;
+    h[0] = (unsigned short)(__float_as_uint(x) >> 16);
+    h[C] = bf16_lo_bits(x);
+}
+template <int C>
+__device__ __forceinline__ void store_split4(float* row, int c0, float x0, float x1, float x2, float x3) {   // 4 channels
+    unsigned short* h = reinterpret_cast<unsigned short*>(row) + c0;
+    const uint2 hv = make_uint2(__builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u),
+                                __builtin_amdgcn_perm(__float_as_uint(x3), __float_as_uint(x2), 0x07060302u));
+    const uint2 lv = make_uint2((unsigned)bf16_lo_bits(x0) | ((unsigned)bf16_lo_bits(x1) << 16),
+                                (unsigned)bf16_lo_bits(x2) | ((unsigned)bf16_lo_bits(x3) << 16));
+    *reinterpret_cast<uint2*>(h) = hv;
+    *reinterpret_cast<uint2*>(h + C) = lv;
 }
 template <int MT, int NT, int CH1, int CH2, bool IDRES = false, bool P1 = false, bool P2 = false, class Epi>
 __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)], const float* __restrict__ b1, int cs1,
@@ -722,18 +725,22 @@ __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)
             const float* p2 = b2 + col * cs2 + 8 * g;
             static_for<CH1 + CH2>([&](auto cc) {
                 constexpr int ch = decltype(cc)::value;
-                const float* p = ch < CH1 ? p1 + ch * 32 : p2 + (ch - CH1) * 32;
-                const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
                 bf16x8 hi, lo;
                 if constexpr (ch < CH1 ? P1 : P2) {
-                    unpack_hl(x0, x1, hi, lo);
+                    // stored split (see store_split): the two planes of this buffer's row, 8 channels each
+                    constexpr int C = (ch < CH1 ? CH1 : CH2) * 32, cl = (ch < CH1 ? ch : ch - CH1) * 32;
+                    const unsigned short* rp = reinterpret_cast<const unsigned short*>(ch < CH1 ? b1 + col * cs1 : b2 + col * cs2) + cl + 8 * g;
+                    hi = *reinterpret_cast<const bf16x8*>(rp);
+                    lo = *reinterpret_cast<const bf16x8*>(rp + C);
                 } else {
+                    const float* p = ch < CH1 ? p1 + ch * 32 : p2 + (ch - CH1) * 32;
+                    const float4 x0 = *reinterpret_cast<const float4*>(p), x1 = *reinterpret_cast<const float4*>(p + 4);
                     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     unsigned h[4];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) lo[e] = (__bf16)(x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)      // truncated hi halves of an element pair, one v_perm_b32 (see pack_hl)
+                    for (int e = 0; e < 4; ++e)      // truncated hi halves of an element pair, one v_perm_b32 (see store_split)
                         h[e] = __builtin_amdgcn_perm(__float_as_uint(x[2 * e + 1]), __float_as_uint(x[2 * e]), 0x07060302u);
                     hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
                 }
@@ -778,9 +785,13 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                                  if constexpr (std::is_same_v<decltype(v), f32x4>) {
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)
-                                         if (w0 + r < V) zp[r * CSI] = BF3 ? pack_hl(v[r]) : v[r];     // (z feeds the GEMM only)
+                                         if (w0 + r < V) {
+                                             if constexpr (BF3) store_split<CIN>(zp - c + r * CSI, c, v[r]);    // (z feeds the GEMM only)
+                                             else zp[r * CSI] = v[r];
+                                         }
                                  } else {
-                                     *zp = BF3 ? pack_hl(v) : v;
+                                     if constexpr (BF3) store_split<CIN>(zp - c, c, v);
+                                     else *zp = v;
                                  }
                              });
     __syncthreads();
@@ -800,7 +811,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             const f32x2 m0 = t0 * slope, m1 = t1 * slope;
             const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf)} + f32x2{e.x, e.y};
             const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf)} + f32x2{e.z, e.w};
-            if constexpr (OUTP) *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(pack_hl(r0[0]), pack_hl(r0[1]), pack_hl(r1[0]), pack_hl(r1[1]));
+            if constexpr (OUTP) store_split4<COUT>(out + col * CSO, c0, r0[0], r0[1], r1[0], r1[1]);
             else *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
         }
     };
