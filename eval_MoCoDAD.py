@@ -30,10 +30,14 @@ def main():
     ap.add_argument("-c", "--config", type=str, required=True)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic clips instead of dataset files")
     ap.add_argument("--frames-per-clip", type=int, default=200)
+    ap.add_argument("--bf16x3", action="store_true", help="OPT-IN split-bf16 channel GEMMs (default shape only; scores within "
+                    "~2e-6 of the fp32 path, DESIGN.md 3.1); the default computes in fp32")
     ap.add_argument("--device-windows", action="store_true",
                     help="upload per-person trajectories once and let the kernels window + transform them on load "
                          "(instead of materialising seg_len x num_transform copies on the host)")
     cli = ap.parse_args()
+    if cli.bf16x3:
+        os.environ["MCD_BF16X3"] = "1"     # read once by the library, before its first launch
     args = load_config(cli.config)
     if hasattr(args, "diffusion_on_latent"):
         raise NotImplementedError("the latent-diffusion variant (MoCoDADlatent) is outside the accelerated path")

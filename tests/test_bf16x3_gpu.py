@@ -18,19 +18,20 @@ from conftest import load_golden
 from mocodad_amd.engine import HipScorer
 from oracle import mocodad_oracle as O
 worst = 0.0
-for ns, S in ((2, 1), (10, 5), (50, 8)):
-    w = load_golden("weights_inject.npz")
+for variant, ns, S in (("inject", 2, 1), ("inject", 10, 5), ("inject", 50, 8), ("concat", 10, 5)):   # 3 and 6 U-Net frames
+    w = load_golden(f"weights_{variant}.npz")
     cfg = json.loads(bytes(w.pop("__cfg__")).decode())
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
-    ci, xi = O.split_indices(cfg["seg_len"], cfg["conditioning_indices"], "inject")
-    sc = HipScorer(sd, strategy="inject", seg_len=cfg["seg_len"], cond_idx=ci, corrupt_idx=xi,
+    strat = cfg["conditioning_strategy"]
+    ci, xi = O.split_indices(cfg["seg_len"], cfg["conditioning_indices"], strat)
+    sc = HipScorer(sd, strategy=strat, seg_len=cfg["seg_len"], cond_idx=ci, corrupt_idx=xi,
                    cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
-    g = load_golden(f"traj_inject_ns{ns}_S{S}.npz")
+    g = load_golden(f"traj_{variant}_ns{ns}_S{S}.npz")
     loss, poses = sc.score(torch.from_numpy(g["data"]), n_samples=S, noise_steps=ns,
                            noise=torch.from_numpy(g["noise"].astype(np.float32)), want_poses=True)
     e = float(np.abs(loss.cpu().numpy() - g["loss_all"]).max())
     p = float(np.abs(poses.cpu().numpy() - g["poses_all"]).max())
-    print(f"ns={ns} S={S}: max|score - golden| = {e:.3e}  max|pose - golden| = {p:.3e}")
+    print(f"{variant} ns={ns} S={S}: max|score - golden| = {e:.3e}  max|pose - golden| = {p:.3e}")
     worst = max(worst, e)
 print("WORST", worst)
 assert worst < 1e-4
