@@ -109,7 +109,7 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* Environment switches read once per process by the library (tuning / opt-in, none needed for normal use):
- *   MCD_BF16X3=1   channel GEMMs (3 or 6 U-Net frames) on the bf16 matrix path with both operands split
+ *   MCD_BF16X3=1   channel GEMMs (3, 6 or 12 U-Net frames) on the bf16 matrix path with both operands split
  *                  into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate): scores within ~2e-6 of the fp32 path, ~45 %
  *                  faster.  Off by default: the shipped, measured path computes in fp32.
  *   MCD_VARIANT=n  alternative workgroup shapes of the trajectory kernel (tuning experiments only). */

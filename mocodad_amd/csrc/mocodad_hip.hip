@@ -1842,7 +1842,7 @@ int launch_score_t(const ScoreParams& P, hipStream_t st) {
 
 int launch_score(int T, const ScoreParams& P, hipStream_t st) {
     static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
-    // opt-in split-bf16 channel GEMMs (layers 2..9) for 3 and 6 U-Net frames (see gemm_tiles_bf3); everything measured and
+    // opt-in split-bf16 channel GEMMs (layers 2..9) for 3, 6 and 12 U-Net frames (see gemm_tiles_bf3); everything measured and
     // reported by bench.py uses the fp32 path
     static const bool bf3 = getenv("MCD_BF16X3") && atoi(getenv("MCD_BF16X3")) != 0;
 #ifdef MCD_FAST_T6      // developer builds: one instantiation
@@ -1863,7 +1863,7 @@ int launch_score(int T, const ScoreParams& P, hipStream_t st) {
             if (bf3) return launch_score_t<6, 1, 4, true>(P, st);
             if (variant == 1) return launch_score_t<6, 2, 2>(P, st);   // 2 chains / WG, 1 WG per CU (no register cap)
             return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
-        case 12: return launch_score_t<12, 1, 2>(P, st);
+        case 12: return bf3 ? launch_score_t<12, 1, 2, true>(P, st) : launch_score_t<12, 1, 2>(P, st);
         case 4: return launch_score_t<4, 1, 4>(P, st);                 // e.g. seg_len 8 split in halves
         case 8: return launch_score_t<8, 1, 2>(P, st);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 6, 8, 12)");

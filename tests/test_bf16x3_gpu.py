@@ -18,7 +18,7 @@ from conftest import load_golden
 from mocodad_amd.engine import HipScorer
 from oracle import mocodad_oracle as O
 worst = 0.0
-for variant, ns, S in (("inject", 2, 1), ("inject", 10, 5), ("inject", 50, 8), ("concat", 10, 5)):   # 3 and 6 U-Net frames
+for variant, ns, S in (("inject", 2, 1), ("inject", 10, 5), ("inject", 50, 8), ("concat", 10, 5), ("T12", 10, 2)):   # 3, 6 and 12 U-Net frames
     w = load_golden(f"weights_{variant}.npz")
     cfg = json.loads(bytes(w.pop("__cfg__")).decode())
     sd = {k: torch.from_numpy(v) for k, v in w.items()}
