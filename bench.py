@@ -3,17 +3,20 @@
 
 A "step" = one MoCoDAD.forward-equivalent call of the HIP path (condition encoder + S*(ns-1) U-Net
 passes + DDPM updates + per-sample loss + 'best' aggregation) over one batch of synthetic pose windows
-that is already resident in HBM.  Workload = BASELINE.json configs[1]: HR-Avenue-shaped windows
+that is already resident in HBM.  Default workload = BASELINE.json configs[1]: HR-Avenue-shaped windows
 (B=1024 per step as in config/Avenue/mocodad_test.yaml, seg_len 6 = 3 condition + 3 denoised frames,
 17 joints), noise_steps=10, 5 generated samples, inject conditioning, in-kernel Philox noise.
 
-  python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N --steps K --warmup W] [--config avenue|stc|ubnormal_concat|seq24] [--scaling weak|strong]
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (one per GPU,
+torch.distributed.run on 127.0.0.1 with a free port); started under torch.distributed.run it uses the ranks it is given.
 Rank 0 prints ONE JSON line (see the driver contract in the task description)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,26 +27,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic FLOP per window (BASELINE.md §3 / SURVEY.md §8d): P * F_unet(T_u=3) + F_cond(T_c=3)
-F_UNET_T3 = 4_290_352
-F_COND_T3 = 545_904
+# algorithmic FLOP per window (BASELINE.md §3 / SURVEY.md §8d): P * F_unet(T_u) + F_cond(T_c)
+F_UNET = {3: 4_290_352, 6: 8_799_400, 12: 18_524_464}
+F_COND = {3: 545_904, 12: 2_484_720}
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
-# HBM bytes per launch of the default workload from the rocprofv3 PMC passes (see profiles/)
-HBM_TRAFFIC_DEFAULT = 7.65e6   # (2 x 2706.0 + 80 + 2 x 1010.5 + 64 + 2 x 32.5 + 4) KB: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-HBM_TRAFFIC_SOURCE = "profiles/r01t_pmc.txt"
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per launch and matrix-pipe counters of the default workload from the rocprofv3 PMC passes committed under
+# profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); constants of a profile, not measured by this run
+PMC_DEFAULT = {"source": "profiles/r01t_pmc.txt", "hbm_bytes_per_launch": 7.65e6}
+
+# name -> (golden weights variant, windows per step, noise_steps, samples, description)
+CONFIGS = {
+    "avenue": ("inject", 1024, 10, 5, "BASELINE configs[1]: HR-Avenue-shaped windows (seg_len 6 = 3 cond + 3 denoised, 17 joints)"),
+    "stc": ("inject", 2048, 10, 5, "BASELINE configs[2]: HR-ShanghaiTech-shaped windows (seg_len 6 = 3 cond + 3 denoised), batch 2048"),
+    "ubnormal_concat": ("concat", 1024, 10, 5, "BASELINE configs[3]: HR-UBnormal-shaped windows, concat conditioning (U-Net on 6 frames, no encoder)"),
+    "seq24": ("T12", 4096, 50, 8, "BASELINE configs[4]: synthetic N(0,1) windows, seq_len 24 = 12 cond + 12 denoised frames"),
+}
 
 
-def load_weights():
-    d = np.load(os.path.join(ROOT, "tests", "golden", "weights_inject.npz"))
+def load_weights(variant="inject"):
+    d = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{variant}.npz"))
     w = {k: d[k] for k in d.files}
     cfg = json.loads(bytes(w.pop("__cfg__")).decode())
     return {k: torch.from_numpy(v) for k, v in w.items()}, cfg
 
 
-def synth_windows(n, seg_len, seed):
-    """HR-Avenue-shaped synthetic input: smooth per-joint random walks, robust-scaled-like, clipped to +-5."""
+def frame_split(seg_len, ci, strat):
+    if strat == "no_condition":
+        return [], list(range(seg_len))
+    if isinstance(ci, int):
+        n = seg_len // ci
+        return list(range(n)), list(range(n, seg_len))
+    return list(ci), [i for i in range(seg_len) if i not in ci]
+
+
+def synth_windows(n, seg_len, seed, iid=False):
+    """HR-Avenue-shaped synthetic input: smooth per-joint random walks, robust-scaled-like, clipped to +-5
+    (iid: i.i.d. N(0,1) as BASELINE configs[4] asks)."""
     g = torch.Generator().manual_seed(seed)
+    if iid:
+        return torch.randn(n, 2, seg_len, 17, generator=g).float().contiguous()
     base = torch.randn(n, 2, 1, 17, generator=g)
     steps = torch.randn(n, 2, seg_len, 17, generator=g) * 0.15
     return (base + torch.cumsum(steps, dim=2)).clamp_(-5, 5).float().contiguous()
@@ -67,44 +90,66 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(sd, ns, S, budget_s=15.0):
-    """The oracle (a PyTorch-CPU op-for-op port of the reference path) timed on this host's cores, on a
-    bounded sample: a 256-window probe sizes the timed sample to about `budget_s` seconds."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, cfg, ns, S, budget_s=15.0):
+    """The oracle (a PyTorch-CPU op-for-op port of the reference path) timed on this host's cores, on a bounded sample:
+    a small probe sizes the timed sample to about `budget_s` seconds; a 1-thread figure on a smaller sample beside it."""
     from oracle import mocodad_oracle as O
     threads = min(usable_cores(), 64)
-    torch.set_num_threads(threads)
+    seg_len, strat, ci = cfg["seg_len"], cfg["conditioning_strategy"], cfg["conditioning_indices"]
+    _, xi = frame_split(seg_len, ci, strat)
     g = torch.Generator().manual_seed(123)
 
     def run(n, seed):
-        data = synth_windows(n, 6, seed)
-        noise = torch.randn(S, ns - 1, n, 2, 3, 17, generator=g)
+        data = synth_windows(n, seg_len, seed)
+        noise = torch.randn(S, ns - 1, n, 2, len(xi), 17, generator=g)
         t0 = time.perf_counter()
         with torch.no_grad():
-            O.score(sd, data, noise, noise_steps=ns, aggregation="best")
+            O.score(sd, data, noise, noise_steps=ns, strategy=strat, conditioning_indices=ci, aggregation="best")
         return time.perf_counter() - t0
 
-    run(64, 1)                      # warm-up (thread pool, allocator)
-    probe = run(256, 2)
-    n = int(min(16384, max(256, 256 * budget_s / max(probe, 1e-3))))
-    n = max(256, n // 256 * 256)
+    torch.set_num_threads(threads)
+    run(8, 1)                       # warm-up (thread pool, allocator)
+    probe_n = 16
+    probe = run(probe_n, 2)
+    if probe < 0.5:                 # a light configuration: a larger probe sizes the sample more accurately
+        probe_n = 128
+        probe = run(probe_n, 2)
+    n = int(min(16384, max(16, probe_n * 0.8 * budget_s / max(probe, 1e-3))))
+    n = max(16, n // 16 * 16)
     dt = run(n, 3)
-    return {"value": round(n / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port",
+    torch.set_num_threads(1)
+    n1 = int(min(256, max(4, 0.2 * budget_s * 1.5 * (n / dt) / threads)))      # about 0.2 x budget on one thread
+    dt1 = run(n1, 4)
+    torch.set_num_threads(threads)
+    return {"value": round(n / dt, 2), "unit": "clips/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "one_thread": {"value": round(n1 / dt1, 2), "unit": "clips/s", "sample": f"{n1} windows, {dt1:.1f}s"},
             "sample": f"one batch of {n} windows, ns={ns}, S={S}, oracle/mocodad_oracle.py (PyTorch CPU, {threads} threads), {dt:.1f}s"}
 
 
-def opt_in_line(args):
-    """Run this benchmark once more with --bf16x3 in a child process and return its value / kernel time (or None)."""
-    import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--bf16x3", "--no-cpu-baseline", "--steps", str(args.steps),
-                            "--warmup", str(args.warmup), "--batch", str(args.batch), "--noise-steps", str(args.noise_steps),
-                            "--samples", str(args.samples)], capture_output=True, text=True, timeout=300)
-        d = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"value": d["value"], "unit": d["unit"], "kernel_ms_per_step": d["roofline"]["kernel_ms_per_step"],
-                "note": "OPT-IN, not the headline: channel GEMMs as hi*hi + hi*lo + lo*hi on the bf16 matrix path, f32 accumulate; "
-                        "scores within 2e-6 of the golden vectors (tests/test_bf16x3_gpu.py); DESIGN.md section 3"}
-    except Exception as e:  # noqa: BLE001 -- never let the informational field break the benchmark line
-        return {"value": None, "error": str(e)[:200]}
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay rank 0's line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -112,66 +157,102 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="windows per step per GPU")
-    ap.add_argument("--noise-steps", type=int, default=10)
-    ap.add_argument("--samples", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="avenue", help="workload shape (default: BASELINE configs[1])")
+    ap.add_argument("--batch", type=int, default=None, help="windows per step: per GPU (weak scaling) or in total (strong)")
+    ap.add_argument("--noise-steps", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=None)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every GPU scores --batch windows per step; strong: --batch windows per step are split over the GPUs")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams consecutive batches alternate over (2: the ramp of "
-                    "batch i+1 fills the tail of batch i, +2 %; per-launch durations then overlap, so the default keeps 1)")
+                    "batch i+1 fills the tail of batch i, +2 %%; per-launch durations then overlap, so the default keeps 1)")
     ap.add_argument("--bf16x3", action="store_true", help="OPT-IN, not the headline: channel GEMMs on the bf16 matrix path with both "
                     "operands split into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate; scores within ~1e-6 of the fp32 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational H2D-inclusive and opt-in legs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", help="'nccl' (= RCCL over xGMI, the default) or 'gloo' (tests that "
+                    "place several ranks on one GPU)")
     args = ap.parse_args()
-    if args.bf16x3:
-        os.environ["MCD_BF16X3"] = "1"     # read once by the library, before its first launch
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    # under torch.distributed.run (LOCAL_RANK set) the RCCL path is used even with one rank, so a 1-process launch
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
+    # under torch.distributed.run (LOCAL_RANK set) the collective path is used even with one rank, so a 1-process launch
     # exercises exactly what the N-GPU launches do
     use_dist = world > 1 or "LOCAL_RANK" in os.environ
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     from mocodad_amd.engine import HipScorer
-    sd, cfg = load_weights()
-    ns, S, B = args.noise_steps, args.samples, args.batch
-    sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5],
-                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev)
-    # weak scaling: every rank owns its own shard of B windows per step (global window ids keep the
-    # Philox streams distinct and independent of the number of GPUs)
-    data = synth_windows(B, 6, 1000 + rank).to(dev)
+    from mocodad_amd.parallel import shard_range
+    variant, B_cfg, ns_cfg, S_cfg, desc = CONFIGS[args.config]
+    sd, cfg = load_weights(variant)
+    ns = args.noise_steps or ns_cfg
+    S = args.samples or S_cfg
+    B_arg = args.batch or B_cfg
+    seg_len, strat = cfg["seg_len"], cfg["conditioning_strategy"]
+    ci, xi = frame_split(seg_len, cfg["conditioning_indices"], strat)
+    sc = HipScorer(sd, strategy=strat, seg_len=seg_len, cond_idx=ci, corrupt_idx=xi,
+                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev,
+                   options={"bf16x3": 1} if args.bf16x3 else None)
+    if args.scaling == "weak":
+        # every rank owns its own shard of B windows per step (global window ids keep the Philox streams distinct and
+        # independent of the number of GPUs)
+        lo, hi = rank * B_arg, (rank + 1) * B_arg
+        B_total = world * B_arg
+    else:
+        lo, hi = shard_range(B_arg, rank, world)
+        B_total = B_arg
+    B = hi - lo
+    per = -(-B_total // world)      # common (padded) shard length of the single all-gather
+    iid = args.config == "seq24"
+    data_host = synth_windows(B_total if args.scaling == "strong" else B, seg_len, 1000 + (0 if args.scaling == "strong" else rank), iid)
+    if args.scaling == "strong":
+        data_host = data_host[lo:hi].contiguous()
+    data = data_host.to(dev)
     # Window scores stay on their rank while the job runs; ONE all-gather after the last batch reassembles them before
     # the AUC (SURVEY.md 8e, and what eval_MoCoDAD.py does) -- it is inside the timed region.
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else []
+    gather_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
-    def run(n_steps, seed0, events=None):
+    def run(scorer, n_steps, seed0, events=None, src=None):
         # same buffer / collective size in the warm-up and in the timed run (no size-dependent lazy set-up inside the latter)
-        scores = torch.zeros(max(args.steps, n_steps), B, device=dev, dtype=torch.float32)
+        scores = torch.zeros(max(args.steps, n_steps), per, device=dev, dtype=torch.float32)
         main = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(main)
         for i in range(n_steps):
             with torch.cuda.stream(streams[i % len(streams)] if streams else main):
+                x = data if src is None else src.to(dev, non_blocking=True)      # src: host windows (PCIe-inclusive leg)
                 if events is not None:
                     events[i][0].record()
-                loss, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=seed0 + i, first_window_id=rank * B)
+                if B > 0:
+                    loss, _ = scorer.score(x, n_samples=S, noise_steps=ns, seed=seed0 + i, first_window_id=lo)
                 if events is not None:
                     events[i][1].record()   # brackets the scoring launches (cond encoder + persistent kernel) on this stream
-                sc.aggregate(data, loss, None, "best", noise_steps=ns, want_pose=False, out=scores[i])
+                if B > 0:
+                    scorer.aggregate(None, loss, None, "best", noise_steps=ns, want_pose=False, out=scores[i, :B])
         for st in streams:
             main.wait_stream(st)
         if use_dist:
-            gathered = torch.empty(world * scores.numel(), device=dev, dtype=torch.float32)
-            dist.all_gather_into_tensor(gathered, scores.view(-1))   # RCCL over xGMI
+            gather_ev[0].record()
+            flat = scores.view(-1) if coll_dev.type == "cuda" else scores.view(-1).cpu()
+            gathered = torch.empty(world * flat.numel(), device=coll_dev, dtype=torch.float32)
+            dist.all_gather_into_tensor(gathered, flat)   # RCCL over xGMI: the path's only exchange
+            gather_ev[1].record()
             return gathered
         return scores
 
@@ -181,18 +262,26 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup > 0:
-        run(args.warmup, 0)
+        run(sc, args.warmup, 0)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    best = run(args.steps, 100, ev)
+    best = run(sc, args.steps, 100, ev)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    step_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(step_ms)) if B > 0 else 0.0
+    rank_info = None
     if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        gms = gather_ev[0].elapsed_time(gather_ev[1])
+        mine = torch.tensor([dt_local, kern_ms, gms, float(B)], dtype=torch.float64, device=coll_dev)
+        allr = torch.empty(world * 4, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 4).cpu().numpy()
+        dt = float(allr[:, 0].max())          # the job's time = the slowest rank's
+        rank_info = {"kernel_ms": [round(float(v), 4) for v in allr[:, 1]], "wall_s": [round(float(v), 5) for v in allr[:, 0]],
+                     "all_gather_ms": [round(float(v), 4) for v in allr[:, 2]], "windows_per_step": [int(v) for v in allr[:, 3]]}
     if streams:
         # launches on different streams overlap, so a launch's own start-to-end time counts its neighbour's work too;
         # the roofline then uses the timed region's average time per launch instead
@@ -200,41 +289,69 @@ def main():
     assert torch.isfinite(best).all()
 
     if rank == 0:
-        total = world * B * args.steps
+        total = B_total * args.steps
         P = S * (ns - 1)
-        flop_per_window = P * F_UNET_T3 + F_COND_T3
+        flop_per_window = P * F_UNET[sc.t_unet] + (F_COND[sc.t_cond] if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
+        default_wl = (args.config, B, ns, S, args.bf16x3) == ("avenue", 1024, 10, 5, False)
+        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2"}[sc.t_unet]
         out = {
-            "metric": "pose-clips/sec (whole node) @ noise_steps=10, 5 samples",
+            "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
             "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "bf16x3 split operands, f32 accumulate (opt-in)" if args.bf16x3 else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: HR-Avenue-shaped windows (seg_len 6 = 3 cond + 3 denoised, 17 joints), "
-                                   f"noise_steps={ns}, {S} generated samples, inject conditioning, 'best' aggregation",
-                       "windows_per_step_per_gpu": B, "denoiser_passes_per_window": P, "weights": "seeded random init (tests/golden/weights_inject.npz)",
-                       "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), all-gather of scores",
+            "config": {"workload": f"{desc}, noise_steps={ns}, {S} generated samples, {strat} conditioning, 'best' aggregation",
+                       "name": args.config, "windows_per_step_per_gpu": B if args.scaling == "weak" else None,
+                       "windows_per_step_total": B_total, "denoiser_passes_per_window": P,
+                       "weights": f"seeded random init (tests/golden/weights_{variant}.npz)",
+                       "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), one all-gather of scores",
                        "streams": max(args.streams, 1)},
-            "roofline": {"bound": "mfma", "kernel": ("score_kernel<3,2,4,bf16x3>" if args.bf16x3 else "score_kernel<3,2,4>") + " (+ cond_fast_kernel<3,2>)", "achieved": round(achieved, 3),
+            "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
+            "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (f" (+ cond_fast_kernel<{sc.t_cond}>)" if strat == "inject" else ""),
+                         "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
-                         "hbm_algorithmic_bytes_per_window": 820,
+                         "hbm_algorithmic_bytes_per_window": 2 * seg_len * 17 * 4 + 4,
                          # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
-                         # measured for the default workload only
-                         "traffic": HBM_TRAFFIC_DEFAULT if (B, ns, S) == (1024, 10, 5) else None,
-                         "traffic_source": HBM_TRAFFIC_SOURCE,
+                         # a constant of the committed profile of the default workload, null elsewhere
+                         "traffic": PMC_DEFAULT["hbm_bytes_per_launch"] if default_wl else None,
+                         "traffic_source": PMC_DEFAULT["source"] if default_wl else None,
                          # the HBM roofline north_star asks to see beside it: measured bytes / launch time vs 8 TB/s
-                         "hbm": ({"achieved_GBps": round(HBM_TRAFFIC_DEFAULT / (kern_ms * 1e-3) / 1e9, 2), "peak_GBps": 8000.0,
-                                  "frac": round(HBM_TRAFFIC_DEFAULT / (kern_ms * 1e-3) / 8e12, 6)}
-                                 if (B, ns, S) == (1024, 10, 5) else None)},
+                         "hbm": ({"achieved_GBps": round(PMC_DEFAULT["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
+                                  "frac": round(PMC_DEFAULT["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 6)}
+                                 if default_wl else None)},
         }
+        if use_dist:
+            out["ranks"] = dict(rank_info, backend="rccl" if args.dist_backend == "nccl" else args.dist_backend)
+            out["rccl_ranks"] = world if args.dist_backend == "nccl" else 0
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, ns, S, args.cpu_budget)
-        if world == 1 and not args.bf16x3 and not args.no_cpu_baseline and not use_dist:
-            # informational only (never `value`): the opt-in split-bf16 GEMM path on the same box, in a child process
-            # because the library reads its switch once per process
-            out["opt_in_bf16x3"] = opt_in_line(args)
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, ns, S, args.cpu_budget)
+        if world == 1 and not use_dist and not args.no_extras and not args.bf16x3:
+            # informational only (never `value`): (1) the same steps fed from pinned HOST windows, the H2D copy inside the
+            # timed loop; (2) the opt-in split-bf16 GEMM path on the same box
+            n_x = min(args.steps, 10)
+            pinned = data_host.pin_memory()
+            run(sc, 2, 300, src=pinned)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(sc, n_x, 400, src=pinned)
+            torch.cuda.synchronize()
+            out["value_incl_h2d"] = {"value": round(B * n_x / (time.perf_counter() - t1), 1), "unit": "clips/s",
+                                     "note": "windows copied from pinned host memory inside the timed loop (PCIe-inclusive); informational"}
+            if sc.t_unet in (3, 6, 12):
+                sc2 = HipScorer(sd, strategy=strat, seg_len=seg_len, cond_idx=ci, corrupt_idx=xi,
+                                cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev, options={"bf16x3": 1})
+                run(sc2, 2, 500)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run(sc2, n_x, 600)
+                torch.cuda.synchronize()
+                out["opt_in_bf16x3"] = {"value": round(B * n_x / (time.perf_counter() - t1), 1), "unit": "clips/s",
+                                        "note": "OPT-IN, not the headline: channel GEMMs as hi*hi + hi*lo + lo*hi on the bf16 matrix "
+                                                "path, f32 accumulate (tests/test_bf16x3_gpu.py; DESIGN.md section 3.1)"}
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

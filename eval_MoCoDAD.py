@@ -35,9 +35,11 @@ def main():
     ap.add_argument("--device-windows", action="store_true",
                     help="upload per-person trajectories once and let the kernels window + transform them on load "
                          "(instead of materialising seg_len x num_transform copies on the host)")
+    ap.add_argument("--random-init", action="store_true", help="score with seeded random-init weights when the checkpoint "
+                    "is missing (otherwise a missing checkpoint is an error)")
+    ap.add_argument("--dist-backend", default="nccl", help="'nccl' (= RCCL over xGMI) or 'gloo' (tests with several ranks on one GPU)")
+    ap.add_argument("--dump-scores", type=str, default=None, help="rank 0 writes the gathered window scores + AUC to this .npz")
     cli = ap.parse_args()
-    if cli.bf16x3:
-        os.environ["MCD_BF16X3"] = "1"     # read once by the library, before its first launch
     args = load_config(cli.config)
     if hasattr(args, "diffusion_on_latent"):
         raise NotImplementedError("the latent-diffusion variant (MoCoDADlatent) is outside the accelerated path")
@@ -45,12 +47,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % torch.cuda.device_count()   # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     use_dist = world > 1 or "LOCAL_RANK" in os.environ     # under torch.distributed.run: RCCL path even with one rank
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if cli.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(cli.dist_backend)
 
     tw = None
     if cli.synthetic and cli.device_windows:
@@ -79,8 +85,8 @@ def main():
     ckpt = os.path.join(args.ckpt_dir, args.load_ckpt)
     if os.path.exists(ckpt):
         model.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"])
-    elif rank == 0:
-        print(f"[warn] checkpoint {ckpt} not found: scoring with random-init weights")
+    elif not cli.random_init:
+        raise SystemExit(f"checkpoint {ckpt} not found (pass --random-init to score with seeded random-init weights)")
 
     n = len(tw) if tw is not None else data.shape[0]
     shard = WindowShard(n, rank, world)
@@ -88,6 +94,8 @@ def main():
         shard.host_meta = (trans.numpy(), meta.numpy(), frames.numpy())
         model.shard = shard
     model.save_tensors = False
+    if cli.bf16x3:
+        model.hip_options = {"bf16x3": 1}
     t0 = time.perf_counter()
     model.on_test_epoch_start()
     with torch.no_grad():
@@ -101,6 +109,9 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print(f"windows: {n}  gpus: {world}  time: {dt:.3f}s  ({n / dt:.0f} clips/s)  AUC: {auc:.6f}")
+        if cli.dump_scores:
+            import numpy as np
+            np.savez(cli.dump_scores, scores=model.last_scores, auc=np.float64(auc))
     if use_dist:
         dist.destroy_process_group()
 

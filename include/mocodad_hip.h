@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MCD_ABI_VERSION 1
+#define MCD_ABI_VERSION 2
 
 enum {
     MCD_OK = 0,
@@ -104,15 +104,38 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
 int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table,
                      int32_t t, int32_t n_windows, float* eps_out, void* stream);
 
+/* TEST ENTRY.  One stage of the U-Net alone, run by the production stage functions inside the trajectory kernel's LDS plan:
+ * stage 0..10 = ST_GCNN_layer.forward of the 11 layers in execution order (stsgcn.py:94-116; st_gcnnsp1a.0, sd1.0, sd1.1,
+ * sd2.0, sd2.1, sd3.0, sd3.1, su4.0, su4.1, su3.0, su3.1), 11..14 = CNN_layer over the joint axis as called at
+ * stsae_unet.py:205,213,381,391 (down1, down2, up3, up2; without the skip add).
+ * x (B,Cin,t_unet,Vin), emb (B,emb_dim) = the layer's `t` argument (the layer adds Linear(SiLU(emb)); required),
+ * out (B,Cout,t_unet,Vout).  Instantiated for 3 and 6 U-Net frames. */
+int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* emb, int32_t n_windows,
+                      float* out, void* stream);
+
+/* The noise tensor the perf mode (noise == NULL) of mcd_score draws in-kernel, in mcd_score's `noise` layout
+ * (S, max(ns-1,1), B, C=2, Tx, V=17): mcd_score(noise = this tensor) reproduces mcd_score(noise = NULL, seed,
+ * first_window_id) bit for bit.  Replaces nothing in the reference (which draws torch.randn_like, mocodad.py:162,176);
+ * it exists so that the in-kernel generator's distribution can be tested and the perf mode can be replayed by an oracle. */
+int mcd_philox_noise(uint64_t seed, int64_t first_window_id, int32_t n_windows, int32_t n_samples, int32_t noise_steps,
+                     int32_t n_corrupt, float* noise_out, void* stream);
+
 /* Bytes of caller-provided device scratch mcd_score needs (condition embeddings).  Strategies without a condition
  * encoder also accept workspace == NULL. */
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
-/* Environment switches read once per process by the library (tuning / opt-in, none needed for normal use):
- *   MCD_BF16X3=1   channel GEMMs (3, 6 or 12 U-Net frames) on the bf16 matrix path with both operands split
- *                  into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate): scores within ~2e-6 of the fp32 path, ~45 %
- *                  faster.  Off by default: the shipped, measured path computes in fp32.
- *   MCD_VARIANT=n  alternative workgroup shapes of the trajectory kernel (tuning experiments only). */
+/* Per-handle options (no environment variables, no process-wide state).  Set them before the calls they affect, from the
+ * thread that owns the handle; none is needed for normal use.
+ *   MCD_OPT_BF16X3        1: channel GEMMs (3, 6 or 12 U-Net frames) on the bf16 matrix path with both operands split into
+ *                         bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate).  OPT-IN, off by default: the shipped, measured
+ *                         path computes in fp32.
+ *   MCD_OPT_VARIANT       alternative workgroup shapes of the trajectory kernel (tuning experiments only).
+ *   MCD_OPT_COND_GENERIC  1: run the condition encoder through the runtime-channel-list kernel even when the shipped
+ *                         architecture's MFMA kernel applies (used by the tests to cover both).
+ *   MCD_OPT_GENERIC_UNET  1: run the trajectory through the runtime-shape fallback kernel even when a specialised
+ *                         instantiation exists (used by the tests to cover both). */
+enum { MCD_OPT_BF16X3 = 0, MCD_OPT_VARIANT = 1, MCD_OPT_COND_GENERIC = 2, MCD_OPT_GENERIC_UNET = 3, MCD_OPT_COUNT = 4 };
+int mcd_set_option(mcd_weights_t* w, int32_t option, int32_t value);
 
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.
  *   data        (B,C,T,V) windows
@@ -162,6 +185,10 @@ int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_join
  * row (one per (transform, clip, person)), out (n_rows, n_frames) pre-zeroed by the callee. */
 int mcd_scatter_max(const float* scores, const int32_t* frames, const int32_t* row, int64_t n, int32_t seg_len,
                     int32_t n_rows, int32_t n_frames, float* out, void* stream);
+
+/* Profiling builds only (-DMCD_PROFILE, tools/stage_profile.py): device buffer of 96 uint64 per-stage cycle accumulators
+ * written by workgroup 0 of the trajectory kernel; NULL (the default) disables it.  A no-op in the shipped build. */
+void mcd_debug_set_prof(void* device_buffer);
 
 const char* mcd_last_error(void);
 int32_t mcd_abi_version(void);

@@ -13,6 +13,8 @@ STRATEGY = {"inject": 0, "concat": 1, "no_condition": 2, "inbetween_imp": 3, "ra
 LOSS = {"smooth_l1": 0, "l1": 1, "mse": 2}
 COND_UNET = -1  # MCD_COND_UNET
 AGGR = {"all": 0, "best": 1, "worst": 2, "mean": 3, "median": 4, "mean_pose": 5, "median_pose": 6, "quantile": 7}
+OPT = {"bf16x3": 0, "variant": 1, "cond_generic": 2, "generic_unet": 3}     # MCD_OPT_*
+ABI_VERSION = 2
 
 
 class Tensor(C.Structure):
@@ -39,6 +41,10 @@ class WindowView(C.Structure):
 _SIGS = {
     "mcd_pack_weights": (C.c_int, [C.POINTER(Tensor), C.c_int32, C.POINTER(ModelCfg), C.c_int32, C.POINTER(C.c_void_p)]),
     "mcd_free_weights": (None, [C.c_void_p]),
+    "mcd_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mcd_layer_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mcd_philox_noise": (C.c_int, [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mcd_debug_set_prof": (None, [C.c_void_p]),
     "mcd_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_score_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(ScoreCfg)]),

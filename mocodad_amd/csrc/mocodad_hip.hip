@@ -34,6 +34,7 @@
 #include <unordered_map>
 #include <utility>
 #include <type_traits>
+#include <atomic>
 
 #include "../../include/mocodad_hip.h"
 
@@ -166,6 +167,7 @@ struct ScoreParams {
     unsigned long long seed;
     long long first_window;
     int B, S, ns, seg_len, n_corrupt, loss_fn, mode, step_single, n_chains;
+    int upd_shift;            // some prediction updates a frame other than the one it is read at (element-wise tail: barrier between reads and writes)
     int fixed_mask;           // bit t: U-Net frame t is a condition frame copied from the window (concat / imputation)
     int src_frame[12];        // data frame feeding U-Net frame t (condition frame, or ground truth of a denoised one)
     int tx_of[12];            // denoised U-Net frame t -> its index among the corrupt frames
@@ -173,6 +175,11 @@ struct ScoreParams {
     int upd_of[12];           // U-Net frame t -> corrupt frame whose eps-prediction is read at t (-1: none)
     const int* win_mask;      // random_imp: (B,) per-window bitmask of the condition frames (frames in natural order;
                               // replaces fixed_mask and the four maps above, which are then derived from the mask)
+    // layer-test instantiation only (mcd_layer_forward): stage id (0..10 ST-GCN layer, 11 down1, 12 down2, 13 up3, 14 up2),
+    // its input (B,Cin,T,Vin) and output (B,Cout,T,Vout)
+    int lt_stage;
+    const float* lt_in;
+    float* lt_out;
 };
 // frame layout of one window: `fixed` = its condition-frame bitmask (P.fixed_mask, or the window's own for random_imp)
 __device__ __forceinline__ int fm_tx(const ScoreParams& P, int fixed, int t) {
@@ -948,7 +955,10 @@ struct Plan {
 // The persistent scoring kernel.  mode 0: full reverse-diffusion trajectories + loss (mcd_score);
 // mode 1: one eps-prediction pass (mcd_unet_forward).
 // ------------------------------------------------------------------------------------------------
-template <int T, int NB, int MINW, bool BF3 = false>
+// LT = true (layer test, mcd_layer_forward): a single-pass run in which stage P.lt_stage's input region is overwritten with
+// P.lt_in right before the stage and its output region is copied to P.lt_out right after it -- the stage functions and the
+// LDS plan under test are the production ones; the production instantiations (LT = false) contain none of this.
+template <int T, int NB, int MINW, bool BF3 = false, bool LT = false>
 __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams P) {
     using PL = Plan<T, NB>;
     constexpr int TV17 = T * 17;
@@ -991,12 +1001,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
         UPD[i] = k < 0 ? -1 : (n * T + (P.win_mask ? t : P.pos_of[k])) * 17;
     }
-    // the tail's thread -> (chain n, frame t, joint v) map, packed: n*T+t | n << 4 | t << 5 | v << 9 (the divisions by 17 and
+    // the tail's thread -> (chain n, frame t, joint v) map, packed: n*T+t | n << 4 | t << 6 | v << 10 (the divisions by 17 and
     // T*17 cost ~35 VALU instructions per thread and pass when done in place)
+    static_assert(NB <= 4 && T <= 16 && NB * T <= 16, "tail index packing: 4 bits (chain, frame) | 2 bits chain | 4 bits frame");
     int* const TT = reinterpret_cast<int*>(ZO + PL::ZO);
     for (int u = threadIdx.x; u < COLS17 * C0; u += NTHREADS) {
         const int col = u / C0, n = col / TV17, t = (col / 17) % T, v = col % 17;
-        TT[u] = (n * T + t) | (n << 4) | (t << 5) | (v << 9);
+        TT[u] = (n * T + t) | (n << 4) | (t << 6) | (v << 10);
     }
     if (threadIdx.x < 64) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 6 * F_STRIDE + F_BIAS) + threadIdx.x];
     else if (threadIdx.x < 64 + C0) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 10 * F_STRIDE + F_BIAS) + threadIdx.x - 64];
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
         for (int c = 0; c < C0; ++c) {
             if (P.mode == 1) {
-                xv[c] = P.x_in[((b * C0 + c) * T + t) * 17 + v];
+                xv[c] = P.x_in ? P.x_in[((b * C0 + c) * T + t) * 17 + v] : 0.f;
             } else if ((fixed >> t) & 1) {
                 xv[c] = load_coord(P.dv, b, c, fm_src(P, t), v, P.seg_len);
             } else {
@@ -1038,6 +1049,34 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
+    // layer test: (B,C,T,V) global tensor <-> LDS region [col = (n,t,v)][channel]
+    auto lt_inject = [&](int id, float* region, int cs, int C, int V) {
+        if constexpr (LT) {
+            if (P.lt_stage == id) {
+                __syncthreads();
+                for (int u = threadIdx.x; u < NB * C * T * V; u += NTHREADS) {
+                    const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % C, n = u / (V * T * C);
+                    int b = chain0 + n;
+                    if (b >= P.n_chains) b = P.n_chains - 1;
+                    region[((n * T + t) * V + v) * cs + c] = P.lt_in[(((size_t)b * C + c) * T + t) * V + v];
+                }
+                __syncthreads();
+            }
+        }
+    };
+    auto lt_dump = [&](int id, const float* region, int cs, int C, int V) {
+        if constexpr (LT) {
+            if (P.lt_stage == id) {
+                __syncthreads();
+                for (int u = threadIdx.x; u < NB * C * T * V; u += NTHREADS) {
+                    const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % C, n = u / (V * T * C);
+                    const int b = chain0 + n;
+                    if (b < P.n_chains) P.lt_out[(((size_t)b * C + c) * T + t) * V + v] = region[((n * T + t) * V + v) * cs + c];
+                }
+                __syncthreads();
+            }
+        }
+    };
     // U-Net skip tensors d1 / d2, register-resident between the down- and the up-samplers
     using RS1 = RsCfg<32, 17, 12, T, NB, true>;
     using RS2 = RsCfg<64, 12, 10, T, NB, true>;
@@ -1128,6 +1167,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         layer_std<0, T, NB, (MINW <= 2), 4>(wb, mc0, XT, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc1, 1); }, nohook);                                           // sp1a (2 -> 16)
         STAGE(2);
+        lt_dump(0, RG + PL::L0_out, 20, 16, 17);
+        lt_inject(1, RG + PL::L1_in, 20, 16, 17);
         // ---- down path
         LMix<2, T, NB> mc2;
         // SiLU(pe + cond) for the NEXT pass's embeddings (consumed in this pass's last layer): two global loads and an
@@ -1136,23 +1177,33 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         layer_std<1, T, NB, (MINW <= 2)>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
         STAGE(3);
+        lt_dump(1, RG + PL::L1_out, 36, 32, 17);
+        lt_inject(2, RG + PL::L2_in, 36, 32, 17);
         RsCoef<32, 17, 12, T, NB, true> rc1;
         layer_std<2, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
         STAGE(4);
+        lt_dump(2, RG + PL::L2_out, 36, 32, 17);
+        lt_inject(11, RG + PL::L2_out, 36, 32, 17);
         LMix<3, T, NB> mc3;
         mix_early(mc3, 3);
         resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         __syncthreads();
         STAGE(5);
+        lt_dump(11, RG + PL::DN1_out, 36, 32, 12);
+        lt_inject(3, RG + PL::L3_in, 36, 32, 12);
         LMix<4, T, NB> mc4;
         layer_std<3, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
         STAGE(6);
+        lt_dump(3, RG + PL::L3_out, 68, 64, 12);
+        lt_inject(4, RG + PL::L4_in, 68, 64, 12);
         RsCoef<64, 12, 10, T, NB, true> rc2;
         layer_std<4, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
         STAGE(7);
+        lt_dump(4, RG + PL::L4_out, 68, 64, 12);
+        lt_inject(12, RG + PL::L4_out, 68, 64, 12);
         LMix<5, T, NB> mc5;
         mix_early(mc5, 5);
         resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
@@ -1160,6 +1211,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
         if constexpr (!FUSE64) __syncthreads();
         STAGE(8);
+        lt_dump(12, RG + PL::DN2_out, 68, 64, 10);
+        lt_inject(5, RG + PL::L5_in, 68, 64, 10);
         // ---- sd3.0, then sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G, then out = PReLU(mix(P_t) + P_r + b) + e in place of P_r
         {
             constexpr int NT = PL::P10 / 16;
@@ -1172,6 +1225,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                     else load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
                                 });  // sd3.0
             STAGE(9);
+            lt_dump(5, RG + PL::L5_out, 132, 128, 10);
+            lt_inject(6, RG + PL::L6_in, 132, 128, 10);
             float* Pb = RG + PL::L6_p;
             MixCoef<64, 10, T, NB> mc6;
             mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
@@ -1216,25 +1271,39 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         rs_early(rc3, 2);
         if constexpr (!FUSE64) __syncthreads();     // aligned: up3 reads only this wave's own layer-6 output block
         STAGE(11);
+        lt_dump(6, RG + PL::L6_p + 64, 132, 64, 10);
+        lt_inject(13, RG + PL::L6_p + 64, 132, 64, 10);
+        if constexpr (LT) {       // the resampler alone: no skip tensor added
+            if (P.lt_stage == 13) for (float& f : skip2) f = 0.f;
+            if (P.lt_stage == 14) for (float& f : skip1) f = 0.f;
+        }
         // ---- up path
         LMix<7, T, NB> mc7;
         mix_early(mc7, 7);
         resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         __syncthreads();
         STAGE(12);
+        lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
+        lt_inject(7, RG + PL::L7_in, 68, 64, 12);
         LMix<8, T, NB> mc8;
         layer_std<7, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
         STAGE(13);
+        lt_dump(7, RG + PL::L7_out, 68, 64, 12);
+        lt_inject(8, RG + PL::L8_in, 68, 64, 12);
         RsCoef<32, 12, 17, T, NB, false> rc4;
         layer_std<8, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
         STAGE(14);
+        lt_dump(8, RG + PL::L8_out, 36, 32, 12);
+        lt_inject(14, RG + PL::L8_out, 36, 32, 12);
         LMix<9, T, NB> mc9;
         mix_early(mc9, 9);
         resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         __syncthreads();
         STAGE(15);
+        lt_dump(14, RG + PL::UP2_out, 36, 32, 17);
+        lt_inject(9, RG + PL::L9_in, 36, 32, 17);
         // ---- su3.0, then su3.1 (32 -> 2) W-first: P = [W_t; W_r] M32 (4 useful rows), then the 2-channel mix with the PReLU,
         //      embedding, U-Net residual (+X) and the DDPM update fused into its store
         {
@@ -1250,6 +1319,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                     ef_load();
                                 }, nohook);                                                              // su3.0
             STAGE(16);
+            lt_dump(9, RG + PL::L9_out, 36, 32, 17);
+            lt_inject(10, RG + PL::L10_in, 36, 32, 17);
             const float ca = srow[0], cb = srow[1], csg = srow[2];     // DDPM coefficients of this step (used two stages on)
             EmbRow ef2;                                   // the 20 rows beyond the first NTHREADS: fetched here, used after
             ef2.load(wb, emb_row2(tid));                  // the FMA product below
@@ -1295,25 +1366,46 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // element-wise tail of the pass, one (column, coordinate) per thread: eps = PReLU(mix(P_t) + P_r + b) + e + x
             // (layer 10 + the U-Net's residual), then the DDPM update of the frame this prediction drives and the next
             // pass's input block.  (Inside the mix's store functor this ran on 2 of every 16 lanes of 6 waves.)
-            for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
-                const int c = u % C0, col = u / C0;
-                const int tt = TT[u];
-                const int n = (tt >> 4) & 1, t = (tt >> 5) & 15, v = tt >> 9;
-                const float x = XT[col * 4 + c];
-                const float eps = prelu(ZO[u] + Pb[col * 20 + C0 + c] + BIA[64 + c], slope10) + E10[e10_off + n * 4 + c] + x;
-                if (single) {
-                    const int chain = chain0 + n;
-                    if (chain < P.n_chains) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v] = eps;
-                } else {
-                    const int cbase = UPD[tt & 15];
-                    if (cbase >= 0) {
-                        const int colp = cbase + v;
-                        const float z = zadd ? ZN[colp * C0 + c] : 0.f;
-                        const float xn = ca * (XT[colp * 4 + c] - cb * eps) + csg * z;
-                        XT[colp * 4 + c] = xn;
+            // Reads first, then (behind a barrier when a prediction drives a DIFFERENT frame than the one it was made at:
+            // 'concat' with the condition at the end of the window) the writes: the frame a thread updates is then another
+            // thread's U-Net residual input x.
+            constexpr int TAIL_IT = (COLS17 * C0 + NTHREADS - 1) / NTHREADS;
+            float xn_t[TAIL_IT];
+            int dst_t[TAIL_IT];
+#pragma unroll
+            for (int it = 0; it < TAIL_IT; ++it) {
+                const int u = tid + it * NTHREADS;
+                dst_t[it] = -1;
+                xn_t[it] = 0.f;
+                if (u < COLS17 * C0) {
+                    const int c = u % C0, col = u / C0;
+                    const int tt = TT[u];
+                    const int n = (tt >> 4) & 3, t = (tt >> 6) & 15, v = tt >> 10;
+                    const float x = XT[col * 4 + c];
+                    const float l10 = prelu(ZO[u] + Pb[col * 20 + C0 + c] + BIA[64 + c], slope10) + E10[e10_off + n * 4 + c];
+                    const float eps = l10 + x;
+                    if constexpr (LT) {      // layer 10 alone: without the U-Net's residual (+ x)
+                        const int chain = chain0 + n;
+                        if (P.lt_stage == 10 && chain < P.n_chains) P.lt_out[(((size_t)chain * C0 + c) * T + t) * 17 + v] = l10;
+                    }
+                    if (single) {
+                        const int chain = chain0 + n;
+                        if (chain < P.n_chains && P.eps_out) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v] = eps;
+                    } else {
+                        const int cbase = UPD[tt & 15];
+                        if (cbase >= 0) {
+                            const int colp = cbase + v;
+                            const float z = zadd ? ZN[colp * C0 + c] : 0.f;
+                            xn_t[it] = ca * (XT[colp * 4 + c] - cb * eps) + csg * z;
+                            dst_t[it] = colp * 4 + c;
+                        }
                     }
                 }
             }
+            if (P.upd_shift) __syncthreads();
+#pragma unroll
+            for (int it = 0; it < TAIL_IT; ++it)
+                if (dst_t[it] >= 0) XT[dst_t[it]] = xn_t[it];
             mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);      // for the next pass
             STAGE(21);
             __syncthreads();
@@ -1819,32 +1911,40 @@ struct mcd_weights {
     bool has_cond;
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
     bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
+    int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
+    int opt[MCD_OPT_COUNT];   // mcd_set_option values (plain ints: set before the calls they affect, like any other argument)
 };
 
 namespace {
 
-template <int T, int NB, int MINW, bool BF3 = false>
-int launch_score_t(const ScoreParams& P, hipStream_t st) {
-    using PL = Plan<T, NB>;
-    static bool attr_set[16] = {false};
+// Raise a kernel's dynamic-LDS limit once per device.  `done` is the kernel's own device bitmask; two host threads racing
+// here both make the (idempotent) call, nobody launches before it has been made on its device.
+int ensure_lds_limit(const void* fn, size_t bytes, std::atomic<unsigned long long>& done) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW, BF3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::BYTES));
-        attr_set[dev] = true;
-    }
+    if (dev < 64 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return MCD_OK;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    return MCD_OK;
+}
+#define LDS_LIMIT(kernel_expr, bytes) do { static std::atomic<unsigned long long> done_{0}; \
+    int rc_ = ensure_lds_limit(reinterpret_cast<const void*>(kernel_expr), (bytes), done_); if (rc_ != MCD_OK) return rc_; } while (0)
+
+template <int T, int NB, int MINW, bool BF3 = false, bool LT = false>
+int launch_score_t(const ScoreParams& P, hipStream_t st) {
+    using PL = Plan<T, NB>;
+    LDS_LIMIT((&score_kernel<T, NB, MINW, BF3, LT>), PL::BYTES);
     const int nblocks = (P.n_chains + NB - 1) / NB;
-    hipLaunchKernelGGL((score_kernel<T, NB, MINW, BF3>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
+    hipLaunchKernelGGL((score_kernel<T, NB, MINW, BF3, LT>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
 
-int launch_score(int T, const ScoreParams& P, hipStream_t st) {
-    static const int variant = getenv("MCD_VARIANT") ? atoi(getenv("MCD_VARIANT")) : 0;  // tuning experiments only
+int launch_score(const mcd_weights* w, int T, const ScoreParams& P, hipStream_t st) {
+    const int variant = w->opt[MCD_OPT_VARIANT];          // tuning experiments only
     // opt-in split-bf16 channel GEMMs (layers 2..9) for 3, 6 and 12 U-Net frames (see gemm_tiles_bf3); everything measured and
     // reported by bench.py uses the fp32 path
-    static const bool bf3 = getenv("MCD_BF16X3") && atoi(getenv("MCD_BF16X3")) != 0;
+    const bool bf3 = w->opt[MCD_OPT_BF16X3] != 0;
 #ifdef MCD_FAST_T6      // developer builds: one instantiation
     return launch_score_t<6, 1, 4>(P, st);
 #elif defined(MCD_FAST_BUILD)   // developer builds: only the two default-shape instantiations
@@ -1878,14 +1978,7 @@ template <int T, int NB>
 int launch_cond_fast_t(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     constexpr int P17 = ceil16(NB * T * 17);
     constexpr size_t bytes = (size_t)P17 * (2 * 20 + 2 * 36) * 4;
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_fast_kernel<T, NB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set[dev] = true;
-    }
+    LDS_LIMIT((&cond_fast_kernel<T, NB>), bytes);
     hipLaunchKernelGGL((cond_fast_kernel<T, NB>), dim3((B + NB - 1) / NB), dim3(NTHREADS), bytes, st, w->dbuf, data, fi, seg_len, emb, B);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
@@ -1901,14 +1994,7 @@ int launch_cond_fast(const mcd_weights* w, const DataView& data, const FrameIdx&
 template <int T, int NB>
 int launch_cond_unet_t(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     constexpr size_t lds = (size_t)CondUnetLds<T, NB>::FLOATS * 4;
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_unet_kernel<T, NB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
-    }
+    LDS_LIMIT((&cond_unet_kernel<T, NB>), lds);
     hipLaunchKernelGGL((cond_unet_kernel<T, NB>), dim3((B + NB - 1) / NB), dim3(NTHREADS), lds, st, w->dbuf, data, fi, seg_len, emb, B);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
@@ -2151,8 +2237,15 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         }
         for (int r = 0; r < 4; ++r) { tab[TAB_RSW + r] = U.rs_w[r]; tab[TAB_RSB + r] = U.rs_b[r]; }
     }
+    const int zero_row = B.alloc(32);
+    // upload on `device`, leaving the calling thread's current device as it was
+    int prev_dev = 0;
+    HIP_TRY(hipGetDevice(&prev_dev));
     HIP_TRY(hipSetDevice(device));
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev_dev};
     mcd_weights* w = new mcd_weights();
+    memset(w->opt, 0, sizeof(w->opt));
+    w->zero_row = zero_row;
     w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast; w->cond_unet = cond_unet;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -2161,6 +2254,13 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     Cw.base = w->dbuf;
     w->cond = Cw;
     *out = w;
+    return MCD_OK;
+}
+
+int mcd_set_option(mcd_weights_t* w, int32_t option, int32_t value) {
+    if (!w) return fail(MCD_EINVAL, "null argument");
+    if (option < 0 || option >= MCD_OPT_COUNT) return fail(MCD_EINVAL, "unknown option " + std::to_string(option));
+    w->opt[option] = value;
     return MCD_OK;
 }
 
@@ -2175,7 +2275,7 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
     if (!w->has_cond) return fail(MCD_EINVAL, "model has no condition encoder");
     if (n_windows <= 0) return MCD_OK;
     if (!cond_data || !emb_out) return fail(MCD_EINVAL, "null argument");
-    if (w->cond_unet || (w->cond_fast && !getenv("MCD_COND_GENERIC"))) {
+    if (w->cond_unet || (w->cond_fast && !w->opt[MCD_OPT_COND_GENERIC])) {
         FrameIdx fi;
         for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = k;
         DataView dv;
@@ -2184,13 +2284,7 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
         return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
     }
     const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 16 && !attr_set[dev]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cond_encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[dev] = true;
-    }
+    LDS_LIMIT(&cond_encode_kernel, (size_t)160 * 1024);
     hipLaunchKernelGGL(cond_encode_kernel, dim3(n_windows), dim3(256), lds, (hipStream_t)stream, w->cond, cond_data, emb_out, n_windows);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
@@ -2206,7 +2300,69 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     P.wbuf = w->dbuf; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
     P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.fixed_mask = 0;
     P.mode = 1; P.step_single = t; P.n_chains = n_windows;
-    return launch_score(w->cfg.t_unet, P, (hipStream_t)stream);
+    return launch_score(w, w->cfg.t_unet, P, (hipStream_t)stream);
+}
+
+int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* emb, int32_t n_windows, float* out,
+                      void* stream) {
+    if (!w) return fail(MCD_EINVAL, "null argument");
+    if (stage < 0 || stage > 14) return fail(MCD_EINVAL, "stage must be 0..10 (ST-GCN layers) or 11..14 (down1, down2, up3, up2)");
+    if (n_windows <= 0) return MCD_OK;
+    if (!x || !out || !emb) return fail(MCD_EINVAL, "null argument");
+    ScoreParams P;
+    memset(&P, 0, sizeof(P));
+    P.wbuf = w->dbuf; P.cond_emb = emb; P.step_table = w->dbuf + w->zero_row;   // pe = 0: the layers see SiLU(emb)
+    P.B = n_windows; P.S = 1; P.ns = 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet;
+    P.mode = 1; P.step_single = 0; P.n_chains = n_windows;
+    P.lt_stage = stage; P.lt_in = x; P.lt_out = out;
+    P.x_in = stage == 0 ? x : nullptr;     // layer 0 reads the chain state itself; the other stages start from x = 0
+#ifdef MCD_FAST_BUILD
+    return fail(MCD_EUNSUPPORTED, "fast build");
+#else
+    switch (w->cfg.t_unet) {
+        case 3: return launch_score_t<3, 2, 4, false, true>(P, (hipStream_t)stream);
+        case 6: return launch_score_t<6, 1, 4, false, true>(P, (hipStream_t)stream);
+        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3 and 6 U-Net frames (the fixtures' shapes)");
+    }
+#endif
+}
+
+__global__ void philox_noise_kernel(unsigned long long seed, long long first_window, int B, int S, int K, int Tx, float* __restrict__ out) {
+    // one thread per (s, k, b, tx, joint pair): exactly the draws of score_kernel (x_T: one call per element keyed
+    // (element, 0, s, window); step k >= 1: one call per joint pair keyed (tx * 9 + pair, k, s, window))
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)S * K * B * Tx * 9;
+    if (u >= total) return;
+    const int jp = (int)(u % 9), tx = (int)((u / 9) % Tx);
+    const int b = (int)((u / (9 * Tx)) % B), k = (int)((u / ((long long)9 * Tx * B)) % K), s = (int)(u / ((long long)9 * Tx * B * K));
+    const int v0 = 2 * jp, CTV = C0 * Tx * 17;
+    float* o = out + ((size_t)(s * K + k) * B + b) * CTV;
+    float z[4];
+    if (k == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = i & 1, v = v0 + (i >> 1);
+            z[i] = v < 17 ? philox_normal(seed, (unsigned)((c * Tx + tx) * 17 + v), 0u, (unsigned)s, (unsigned)(first_window + b)) : 0.f;
+        }
+    } else {
+        philox_normal4(seed, (unsigned)(tx * 9 + jp), (unsigned)k, (unsigned)s, (unsigned)(first_window + b), z);
+    }
+    o[tx * 17 + v0] = z[0];
+    o[Tx * 17 + tx * 17 + v0] = z[1];
+    if (v0 + 1 < 17) { o[tx * 17 + v0 + 1] = z[2]; o[Tx * 17 + tx * 17 + v0 + 1] = z[3]; }
+}
+
+int mcd_philox_noise(uint64_t seed, int64_t first_window_id, int32_t n_windows, int32_t n_samples, int32_t noise_steps,
+                     int32_t n_corrupt, float* noise_out, void* stream) {
+    if (n_windows <= 0) return MCD_OK;
+    if (!noise_out) return fail(MCD_EINVAL, "null argument");
+    if (n_samples < 1 || noise_steps < 2 || n_corrupt < 1 || n_corrupt > MCD_MAX_FRAMES) return fail(MCD_EINVAL, "bad sizes");
+    const int K = noise_steps > 2 ? noise_steps - 1 : 1;
+    const long long total = (long long)n_samples * K * n_windows * n_corrupt * 9;
+    hipLaunchKernelGGL(philox_noise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)seed, (long long)first_window_id, n_windows, n_samples, K, n_corrupt, noise_out);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
 }
 
 static int64_t ws_cond_bytes(const mcd_weights* w, int64_t B) {
@@ -2286,19 +2442,20 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         const int t = keeps_cond ? cfg->corrupt_idx[k] : k;     // mocodad.py:829-838: mask built from corrupt_idxs
         if (t < 0 || t >= Tu || P.upd_of[t] >= 0) return fail(MCD_EINVAL, "bad corrupt_idx");
         P.upd_of[t] = k;
+        if (P.pos_of[k] != t) P.upd_shift = 1;
     }
     if (strat == MCD_STRATEGY_INJECT) {
         if (!workspace) return fail(MCD_EINVAL, "workspace required for the inject strategy");
         float* emb = reinterpret_cast<float*>(workspace);
         float* cbuf = emb + (size_t)B * EDIM + 16;
         const int Tc = cfg->n_cond;
-        if (w->cond_unet || (w->cond_fast && !getenv("MCD_COND_GENERIC"))) {
+        if (w->cond_unet || (w->cond_fast && !w->opt[MCD_OPT_COND_GENERIC])) {
             FrameIdx fi;
             for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
             int rc = launch_cond_mfma(w, P.dv, fi, cfg->seg_len, emb, B, st);
             if (rc != MCD_OK) return rc;
             P.cond_emb = emb;
-            return launch_score(Tu, P, st);
+            return launch_score(w, Tu, P, st);
         }
         const int total = B * C0 * Tc * 17;
         FrameIdx fi;
@@ -2310,7 +2467,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (rc != MCD_OK) return rc;
         P.cond_emb = emb;
     }
-    return launch_score(Tu, P, st);
+    return launch_score(w, Tu, P, st);
 }
 
 int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,

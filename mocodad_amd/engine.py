@@ -33,7 +33,8 @@ class HipScorer:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, strategy: str, seg_len: int, cond_idx: Sequence[int],
                  corrupt_idx: Sequence[int], cond_channels: Sequence[int] = (), cond_unet: bool = False,
-                 num_coords: int = 2, n_joints: int = 17, emb_dim: int = 16, device=None):
+                 num_coords: int = 2, n_joints: int = 17, emb_dim: int = 16, device=None,
+                 options: Optional[Dict[str, int]] = None):
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("mocodad_amd needs an MI355X (gfx950) GPU: the scoring path has no CPU fallback")
@@ -72,8 +73,18 @@ class HipScorer:
             n += 1
         handle = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _lib.check(self.L.mcd_pack_weights(arr, n, C.byref(cfg), idx, C.byref(handle)))
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_pack_weights(arr, n, C.byref(cfg), idx, C.byref(handle)))
         self._h = handle
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name: str, value: int) -> None:
+        """Per-handle switch of the library (include/mocodad_hip.h MCD_OPT_*): 'bf16x3', 'variant', 'cond_generic',
+        'generic_unet'."""
+        if name not in _lib.OPT:
+            raise ValueError(f"unknown option {name!r} (known: {sorted(_lib.OPT)})")
+        _lib.check(self.L.mcd_set_option(self._h, _lib.OPT[name], int(value)))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -104,7 +115,14 @@ class HipScorer:
         return c
 
     # ------------------------------------------------------------------ entry points
+    def _check_shape(self, what: str, t: torch.Tensor, tail: Tuple[int, ...]) -> None:
+        if t.dim() != len(tail) + 1 or tuple(t.shape[1:]) != tuple(tail):
+            raise ValueError(f"{what} must have shape (B, {', '.join(map(str, tail))}), got {tuple(t.shape)}")
+
     def cond_encode(self, cond_data: torch.Tensor) -> torch.Tensor:
+        if self.strategy != "inject":
+            raise ValueError("this model has no condition encoder")
+        self._check_shape("cond_data", cond_data, (self.num_coords, self.t_cond, self.n_joints))
         x = _f32c(cond_data, self.device)
         out = torch.empty(x.shape[0], self.emb_dim, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
@@ -112,6 +130,11 @@ class HipScorer:
         return out
 
     def unet_forward(self, x: torch.Tensor, t: int, cond: Optional[torch.Tensor], noise_steps: Optional[int] = None) -> torch.Tensor:
+        self._check_shape("x", x, (self.num_coords, self.t_unet, self.n_joints))
+        if cond is not None:
+            self._check_shape("cond", cond, (self.emb_dim,))
+            if cond.shape[0] != x.shape[0]:
+                raise ValueError(f"cond has {cond.shape[0]} rows, x has {x.shape[0]} windows")
         x = _f32c(x, self.device)
         cond = None if cond is None else _f32c(cond, self.device)
         tab = self.table(noise_steps if noise_steps is not None else max(int(t) + 1, 2))
@@ -145,6 +168,7 @@ class HipScorer:
             if wb.seg_len != self.seg_len:
                 raise ValueError(f"window view has seg_len {wb.seg_len}, model expects {self.seg_len}")
         else:
+            self._check_shape("data", data, (self.num_coords, self.seg_len, self.n_joints))
             data = _f32c(data, self.device)
             B = data.shape[0]
             if cond_mask is not None:     # dense windows + per-window condition sets
@@ -172,6 +196,32 @@ class HipScorer:
                                              _ptr(self.table(noise_steps)), _ptr(ws), _ptr(loss), _ptr(poses), _stream()))
         del keep
         return loss, poses
+
+    # stage ids of mcd_layer_forward: (Cin, Vin, Cout, Vout)
+    _STAGES = {0: (2, 17, 16, 17), 1: (16, 17, 32, 17), 2: (32, 17, 32, 17), 3: (32, 12, 64, 12), 4: (64, 12, 64, 12),
+               5: (64, 10, 128, 10), 6: (128, 10, 64, 10), 7: (64, 12, 64, 12), 8: (64, 12, 32, 12), 9: (32, 17, 32, 17),
+               10: (32, 17, 2, 17), 11: (32, 17, 32, 12), 12: (64, 12, 64, 10), 13: (64, 10, 64, 12), 14: (32, 12, 32, 17)}
+
+    def layer_forward(self, stage: int, x: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+        """TEST ENTRY: one U-Net stage alone (0..10 ST-GCN layers, 11..14 down1/down2/up3/up2), x (B,Cin,T,Vin),
+        emb (B,emb_dim) -> (B,Cout,T,Vout)."""
+        cin, vin, cout, vout = self._STAGES[int(stage)]
+        self._check_shape("x", x, (cin, self.t_unet, vin))
+        self._check_shape("emb", emb, (self.emb_dim,))
+        x, emb = _f32c(x, self.device), _f32c(emb, self.device)
+        out = torch.empty(x.shape[0], cout, self.t_unet, vout, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_layer_forward(self._h, int(stage), _ptr(x), _ptr(emb), x.shape[0], _ptr(out), _stream()))
+        return out
+
+    def philox_noise(self, n_windows: int, *, n_samples: int, noise_steps: int, seed: int = 0, first_window_id: int = 0) -> torch.Tensor:
+        """The noise tensor (S, max(ns-1,1), B, C, Tx, V) the perf mode of `score` draws in-kernel for these keys."""
+        S, K, Tx = int(n_samples), max(int(noise_steps) - 1, 1), len(self.corrupt_idx)
+        out = torch.empty(S, K, int(n_windows), self.num_coords, Tx, self.n_joints, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.mcd_philox_noise(C.c_uint64(seed & (2**64 - 1)), C.c_int64(first_window_id), int(n_windows), S,
+                                               int(noise_steps), Tx, _ptr(out), _stream()))
+        return out
 
     def aggregate(self, data: torch.Tensor, loss_all: torch.Tensor, poses_all: Optional[torch.Tensor], strategy: str,
                   *, noise_steps: int, loss_fn: str = "smooth_l1", want_pose: bool = True,

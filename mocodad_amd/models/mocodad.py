@@ -194,6 +194,7 @@ class MoCoDAD(_Base):
         self._scorer_key = None
         self._calls = 0
         self.shard = None  # optional mocodad_amd.parallel.WindowShard set by the multi-GPU driver
+        self.hip_options: Dict[str, int] = {}   # per-handle library switches (engine.HipScorer.set_option), e.g. {"bf16x3": 1}
 
     # -------------------------------------------------------------- construction
     def build_model(self) -> None:
@@ -287,7 +288,8 @@ class MoCoDAD(_Base):
             chans = list(self.condition_encoder.channels) if self.condition_encoder is not None and not unet_enc else []
             self._scorer = HipScorer(self.state_dict(), strategy=self.conditioning_strategy, seg_len=self.n_frames,
                                      cond_idx=ci, corrupt_idx=xi, cond_channels=chans, cond_unet=unet_enc,
-                                     num_coords=self.num_coords, n_joints=self.n_joints, emb_dim=self.embedding_dim, device=dev)
+                                     num_coords=self.num_coords, n_joints=self.n_joints, emb_dim=self.embedding_dim, device=dev,
+                                     options=self.hip_options)
             self._scorer_key = key
         return self._scorer
 
@@ -391,9 +393,22 @@ class MoCoDAD(_Base):
     def _epoch_end(self, attr: str) -> float:
         outs = getattr(self, attr)
         delattr(self, attr)
-        out, gt_data, trans, meta, frames = processing_data(outs)
-        if self.shard is not None:  # multi-GPU: reassemble the per-window scores with ONE all-gather
-            out, trans, meta, frames = self.shard.gather(out, trans, meta, frames, device=self.device)
+        if self.shard is not None:
+            # multi-GPU: every rank scored its contiguous window shard (possibly an empty one); ONE all-gather reassembles
+            # the per-window scores, then rank 0 alone runs the post-processing and the AUC (the other ranks return nan)
+            if self.aggregation_strategy == "all" or self.model_return_value != "loss":
+                raise ValueError("sharded evaluation exchanges one score per window: use model_return_value='loss' and an "
+                                 "aggregation strategy other than 'all'")
+            local = torch.cat([o[0].reshape(-1) for o in outs]) if outs else torch.empty(0, dtype=torch.float32, device=self.device)
+            out, trans, meta, frames = self.shard.gather(local, None, None, None, device=self.device)
+            gt_data = None      # windows stay on their ranks (post_processing does not use them)
+            if self.shard.rank != 0:
+                return float("nan")
+        else:
+            if not outs:
+                raise ValueError("no batches were scored")
+            out, gt_data, trans, meta, frames = processing_data(outs)
+        self.last_scores = np.asarray(out)     # the (gathered) per-window scores of this epoch, in dataset order
         if self.save_tensors:
             self._save_tensors({"prediction": out, "gt_data": gt_data, "trans": trans, "metadata": meta, "frames": frames},
                                split_name=self.split, aggr_strategy=self.aggregation_strategy, n_gen=self.n_generated_samples)

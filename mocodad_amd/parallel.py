@@ -42,11 +42,15 @@ class WindowShard:
             dist.all_gather_into_tensor(full, pad, group=self.group)
         return full[: self.n_total]
 
-    def gather(self, out: np.ndarray, trans, meta, frames, device=None):
-        """Used by MoCoDAD._epoch_end: scores are exchanged; trans/meta/frames are index-deterministic host data that
-        every rank can rebuild, so they are taken from `self.host_meta` (the full arrays) when provided."""
+    def gather(self, out, trans, meta, frames, device=None):
+        """Used by MoCoDAD._epoch_end: the local shard's scores (tensor or array, possibly empty) are exchanged;
+        trans/meta/frames are index-deterministic host data that every rank can rebuild, so they are taken from
+        `self.host_meta` (the full arrays) set by the driver."""
         dev = device if device is not None and (dist.get_backend(self.group) == "nccl") else "cpu"
-        full = self.all_gather_scores(torch.as_tensor(out, dtype=torch.float32, device=dev)).cpu().numpy()
+        local = out if torch.is_tensor(out) else torch.as_tensor(np.asarray(out))
+        if local.numel() != len(self):
+            raise ValueError(f"rank {self.rank} scored {local.numel()} windows, its shard has {len(self)}")
+        full = self.all_gather_scores(local.reshape(-1).to(device=dev, dtype=torch.float32)).cpu().numpy()
         hm = getattr(self, "host_meta", None)
         if hm is None:
             raise RuntimeError("WindowShard.host_meta = (trans, meta, frames) of the FULL dataset must be set by the driver")

@@ -158,6 +158,13 @@ EXTRA3_CASES = {
     # a random set of 2 condition frames per window (mocodad.py:719-724); the drawn sets are recorded as bitmasks
     "rndimp": (dict(conditioning_strategy="random_imp", conditioning_indices=2), 4, 2, 5),
 }
+# `--extra4` (round 2): the long chains where error amplifies (cumulative gain 1014x at ns = 50) for the 12- and 6-frame
+# U-Nets, from the ALREADY COMMITTED weights_T12 / weights_concat; and concat with a SHORT condition at the end of the window
+# (2 condition + 4 denoised frames: a prediction then drives a frame that is another prediction's U-Net input)
+EXTRA4_LONG = {"T12": (50, 8, 2), "concat": (50, 2, 4)}      # variant: (ns, S, B)
+EXTRA4_CASES = {
+    "cattail2": (dict(conditioning_strategy="concat", conditioning_indices=[4, 5]), 4, 2, 4),
+}
 RNDIMP_SEED = 1234
 
 
@@ -212,6 +219,48 @@ def extra(MoCoDAD, cases=None):
         save(f"traj_{name}_ns{ns}_S{S}.npz", data=data, noise=noise.half(), **out)
 
 
+def extra4(MoCoDAD):
+    extra(MoCoDAD, EXTRA4_CASES)
+    for vname, (ns, S, B) in EXTRA4_LONG.items():
+        d = np.load(os.path.join(HERE, f"weights_{vname}.npz"))
+        cfg = json.loads(bytes(d["__cfg__"]).decode())
+        args, _ = make_args(strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"], cond_idx=cfg["conditioning_indices"],
+                            noise_steps=ns, n_gen=S, aggr="all", ret="all")
+        m = MoCoDAD(args).eval()
+        m.load_state_dict({k: torch.from_numpy(d[k]) for k in d.files if k != "__cfg__"})
+        gen = torch.Generator().manual_seed(777 + len(vname))
+        seg_len = cfg["seg_len"]
+        data = synth_windows(B, seg_len, gen)
+        Tx = m.n_frames_corrupt
+        noise = fp16_round(torch.randn(S, ns - 1, B, 2, Tx, 17, generator=gen))
+        trans = torch.arange(B) % 5
+        meta = torch.stack([torch.ones(B), torch.arange(B) // 4 + 1, torch.arange(B) % 3 + 1, torch.arange(B) * 2 + 1], 1).long()
+        frames = (meta[:, 3:4] + torch.arange(seg_len)[None]).int()
+        batch = [data, trans, meta, frames]
+        tr = dict(data=data, noise=noise.half(), trans=trans, meta=meta, frames=frames)
+        orig = torch.randn_like
+        for aggr in ("all", "best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3"):
+            feeder = NoiseFeeder(noise)
+            torch.randn_like = feeder
+            try:
+                o = m.forward(batch, aggr_strategy=aggr, return_="all")
+            finally:
+                torch.randn_like = orig
+            assert feeder.calls == S * (ns - 1)
+            key = aggr.replace(":", "_").replace(".", "p")
+            if aggr == "all":
+                tr["loss_all"], tr["poses_all"] = o[0], o[1]
+            else:
+                tr[f"loss_{key}"] = o[0]
+                if o[1] is not None:
+                    tr[f"pose_{key}"] = o[1]
+        if m.condition_encoder is not None:
+            cd, _, _ = m._select_frames(data)
+            tr["cond_emb"] = m.condition_encoder(cd, t=None)[0]
+        print(vname, "max |pose|", float(tr["poses_all"].abs().max()), "loss range", float(tr["loss_all"].min()), float(tr["loss_all"].max()))
+        save(f"traj_{vname}_ns{ns}_S{S}.npz", **tr)
+
+
 def extra2():
     """Test-time affine transforms of the reference's dataset (utils/dataset_utils.py:255-310; applied in
     utils/dataset.py:67-76): `python tests/golden/gen_golden.py --extra2`."""
@@ -242,6 +291,9 @@ def main():
         return
     if "--extra3" in sys.argv:
         extra(MoCoDAD, EXTRA3_CASES)
+        return
+    if "--extra4" in sys.argv:
+        extra4(MoCoDAD)
         return
 
     # ---------------------------------------------------------------- 5. schedules

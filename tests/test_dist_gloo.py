@@ -60,3 +60,61 @@ def test_all_gather_scores_world2(n_total):
     assert all(r[1] for r in res), res
     spans = sorted((r[2], r[3]) for r in res)
     assert spans[0][0] == 0 and spans[-1][1] == n_total
+
+
+def _tiny_dataset():
+    """One clip, one person, 9 windows: with 4 ranks the shards are 3 + 3 + 3 + 0 (ceil-divided), with 2 ranks 5 + 4."""
+    from mocodad_amd.data import synthetic
+    data, trans, meta, frames, gts = synthetic.make_dataset(n_clips=1, frames_per_clip=40, persons_per_clip=1, num_transform=1)
+    return data[:9], trans[:9], meta[:9], frames[:9], gts
+
+
+def _epoch_worker(rank, world, port, gt_dir, q):
+    """MoCoDAD._epoch_end with a WindowShard: every rank contributes its (possibly EMPTY) shard of window scores, rank 0
+    alone post-processes.  The scores are injected (no GPU here); the exchange and the host side are the real ones."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import golden_weights, make_args
+        from mocodad_amd.models.mocodad import MoCoDAD
+        data, trans, meta, frames, gts = _tiny_dataset()
+        n = data.shape[0]
+        _, cfg = golden_weights("inject")
+        m = MoCoDAD(make_args(cfg, gt_path=gt_dir, num_transform=1, dataset_choice="HR-STC", pad_size=-1, filter_kernel_size=3,
+                              frames_shift=2, save_tensors=False))
+        scores = torch.linspace(0.1, 2.0, n)
+        shard = WindowShard(n)
+        shard.host_meta = (trans.numpy(), meta.numpy(), frames.numpy())
+        m.shard = shard
+        m.on_test_epoch_start()
+        for lo in range(shard.lo, shard.hi, 2):
+            hi = min(lo + 2, shard.hi)
+            m._test_output_list.append([scores[lo:hi], data[lo:hi], trans[lo:hi], meta[lo:hi], frames[lo:hi]])
+        auc = m.on_test_epoch_end()
+        q.put((rank, float(auc), len(shard)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_epoch_end_rank0_auc(tmp_path, world):
+    from mocodad_amd.data import synthetic
+    from oracle import mocodad_oracle as O
+    data, trans, meta, frames, gts = _tiny_dataset()
+    synthetic.write_gt(str(tmp_path), gts)
+    n = data.shape[0]
+    ref, _, _ = O.post_processing(torch.linspace(0.1, 2.0, n).numpy(), trans.numpy(), meta.numpy(), frames.numpy(), gts,
+                                  num_transform=1, pad_size=-1, filter_kernel_size=3, frames_shift=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert abs(res[0][1] - ref) < 1e-9, (res, ref)
+    assert all(np.isnan(r[1]) for r in res[1:])
+    assert [r[2] for r in res] == ([5, 4] if world == 2 else [3, 3, 3, 0])

@@ -50,7 +50,8 @@ def test_cond_encoder_vs_golden(variant):
         np.testing.assert_allclose(emb, gl["cond_emb"], atol=2e-5, rtol=1e-5)
 
 
-CASES = [("inject", 2, 1), ("inject", 10, 5), ("inject", 50, 8), ("concat", 10, 5), ("T12", 10, 2), ("injtail", 10, 2)]
+CASES = [("inject", 2, 1), ("inject", 10, 5), ("inject", 50, 8), ("concat", 10, 5), ("T12", 10, 2), ("injtail", 10, 2),
+         ("T12", 50, 8), ("concat", 50, 2)]      # the last two: the long chains (gain 1014x) of the 12- and 6-frame U-Nets
 
 
 @pytest.mark.parametrize("variant,ns,S", CASES)

@@ -145,7 +145,7 @@ def test_full_size_properties_other_configs(variant, B, ns, S, seg_len):
     assert (best <= mean + 1e-6).all() and (mean <= worst + 1e-6).all()
 
 
-@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse", "imp2", "implist", "cattail", "encU", "rndimp"])
+@pytest.mark.parametrize("name", ["nocond", "encE", "l1", "mse", "imp2", "implist", "cattail", "encU", "rndimp", "cattail2"])
 def test_extra_variants_vs_reference(name):
     """no_condition strategy (U-Net on all 6 frames), 'E' encoder with channels [24,40]+8 (generic condition-encoder
     kernel), l1 / mse losses, in-between imputation (every 2nd frame / an explicit list conditions), concat with the

@@ -1,0 +1,71 @@
+"""GPU (one device is enough): the multi-process path end to end.  Two ranks share cuda:0 (RCCL refuses two ranks on one
+GPU, so the collective runs on gloo here; on a node every rank has its own GPU and the backend is nccl = RCCL over xGMI):
+  - eval_MoCoDAD.py with WORLD_SIZE=2 gives the single-process scores and AUC bit for bit (noise keyed by global window id,
+    contiguous shards, one all-gather, AUC on rank 0);
+  - `python bench.py --gpus 2` launches its own ranks and prints ONE JSON line for the 2-rank job, weak and strong scaling."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e["OMP_NUM_THREADS"] = "4"
+    return e
+
+
+@pytest.mark.parametrize("extra", [[], ["--device-windows"]])
+def test_eval_two_ranks_equals_one_process(tmp_path, extra):
+    cfg = os.path.join(ROOT, "configs", "hr_avenue_test.yaml")
+    common = ["-c", cfg, "--synthetic", "3", "--frames-per-clip", "90", "--random-init"] + extra
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "eval_MoCoDAD.py")] + common + ["--dump-scores", one],
+                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_port()), os.path.join(ROOT, "eval_MoCoDAD.py")] + common +
+                        ["--dist-backend", "gloo", "--dump-scores", two], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    a, b = np.load(one), np.load(two)
+    assert a["scores"].shape == b["scores"].shape and a["scores"].size > 1000
+    assert np.array_equal(a["scores"], b["scores"])
+    assert float(a["auc"]) == float(b["auc"])
+    assert r2.stdout.count("AUC:") == 1          # rank 0 alone computes and prints it
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_self_launches_two_ranks(scaling):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256",
+                        "--dist-backend", "gloo", "--scaling", scaling], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
+    assert len(d["ranks"]["kernel_ms"]) == 2 and len(d["ranks"]["all_gather_ms"]) == 2
+    total = 512 if scaling == "weak" else 256
+    assert d["config"]["windows_per_step_total"] == total
+    assert sum(d["ranks"]["windows_per_step"]) == total
+    assert "roofline" in d and "cpu_baseline" not in d
+
+
+def test_missing_checkpoint_is_an_error():
+    cfg = os.path.join(ROOT, "configs", "hr_avenue_test.yaml")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "eval_MoCoDAD.py"), "-c", cfg, "--synthetic", "1"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode != 0 and "--random-init" in (r.stdout + r.stderr)

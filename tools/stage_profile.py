@@ -12,8 +12,7 @@ so = os.path.join(ROOT, "mocodad_amd", "libmocodad_hip_prof.so")
 if not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMCD_PROFILE",
                            "-o", so, os.path.join(ROOT, "mocodad_amd", "csrc", "mocodad_hip.hip")])
-if len(sys.argv) > 1:
-    os.environ["MCD_VARIANT"] = sys.argv[1]
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 import torch
 from mocodad_amd import _lib
 _lib.LIB_PATH = so
@@ -22,9 +21,8 @@ from mocodad_amd.engine import HipScorer
 
 sd, cfg = bench.load_weights()
 sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5],
-               cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+               cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0", options={"variant": VARIANT})
 L = _lib.lib()
-L.mcd_debug_set_prof.argtypes = [C.c_void_p]
 prof = torch.zeros(96, dtype=torch.int64, device="cuda:0")
 data = bench.synth_windows(1024, 6, 1).cuda()
 sc.score(data, n_samples=5, noise_steps=10, seed=1)
@@ -43,7 +41,7 @@ for l in range(11):
 sub10 = p[18:22].copy()        # layer 10: FMA product | x-block zeroing + next pass's embeddings | barrier | mix + DDPM store (then barrier = p[17])
 p[17] += sub10.sum()
 tot = p[:18].sum()
-print(f"variant={os.environ.get('MCD_VARIANT','0')}  cycles per pass (9 passes): total {tot/9:.0f}")
+print(f"variant={VARIANT}  cycles per pass (9 passes): total {tot/9:.0f}")
 lay = {2: 0, 3: 1, 4: 2, 6: 3, 7: 4, 9: 5, 13: 7, 14: 8, 16: 9}
 for i, (n, v) in enumerate(zip(names, p)):
     extra = ""
