@@ -186,6 +186,33 @@ int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_join
 int mcd_scatter_max(const float* scores, const int32_t* frames, const int32_t* row, int64_t n, int32_t seg_len,
                     int32_t n_rows, int32_t n_frames, float* out, void* stream);
 
+/* Frame-score assembly after the path, whole: replaces the (transform, clip, person) loops of
+ * MoCoDAD.post_processing (mocodad.py:362-425) with compute_var_matrix + np.nanmax (eval_utils.py:27-34, mocodad.py:392-393),
+ * pad_scores (eval_utils.py:133-149), the person aggregation mean + (max - min of log1p) (mocodad.py:401-403), the HR frame
+ * masks (:405-413), score_process = shift + scipy gaussian_filter1d(sigma = filter_kernel_size; truncate 4, 'reflect')
+ * (eval_utils.py:100-106) and the mean over the transforms (:422); float64 like the NumPy code.  What is left for the host is
+ * roc_auc_score.  All table pointers are DEVICE memory built once per dataset by the caller. */
+typedef struct {
+    int32_t n_clips;              /* ground-truth files, in sorted file-name order */
+    int32_t num_transform;
+    int32_t n_persons;            /* dense person-id range: ids 0 .. n_persons-1 (max id + 1) */
+    int32_t max_frames;           /* row stride: max over the clips of len(gt) */
+    int32_t pad_size;             /* anomaly_score_pad_size, -1 = no padding */
+    int32_t frames_shift;         /* anomaly_score_frames_shift (>= 1) */
+    int32_t gauss_radius;         /* int(4 * sigma + 0.5) */
+    const int64_t* clip_keys;     /* (n_clips,) ascending (scene << 32 | clip) */
+    const int32_t* clip_n_frames; /* (n_clips,) len(gt) */
+    const int32_t* frame_dst;     /* (n_clips, max_frames) position of the frame in the clip's output after the HR masks, -1 = dropped */
+    const int32_t* clip_out_len;  /* (n_clips,) frames kept */
+    const int64_t* clip_out_off;  /* (n_clips,) offset of the clip's scores in `out` (sorted file-name order, concatenated) */
+    const double* gauss_weights;  /* (2 * gauss_radius + 1,) scipy's normalised kernel */
+} mcd_frame_cfg_t;
+int64_t mcd_frame_scores_workspace_bytes(const mcd_frame_cfg_t* cfg);
+/* scores (N,) f32, trans (N,) i64, meta (N,4) i64 = [scene, clip, person, first_frame], frames (N,seg_len) i32 1-based
+ * (the arrays MoCoDAD.post_processing receives, on the device) -> out (sum clip_out_len,) f64 = `pds` of mocodad.py:422. */
+int mcd_frame_scores(const mcd_frame_cfg_t* cfg, const float* scores, const int64_t* trans, const int64_t* meta,
+                     const int32_t* frames, int64_t n_windows, int32_t seg_len, void* workspace, double* out, void* stream);
+
 /* Profiling builds only (-DMCD_PROFILE, tools/stage_profile.py): device buffer of 96 uint64 per-stage cycle accumulators
  * written by workgroup 0 of the trajectory kernel; NULL (the default) disables it.  A no-op in the shipped build. */
 void mcd_debug_set_prof(void* device_buffer);

@@ -38,6 +38,13 @@ class WindowView(C.Structure):
                 ("affine", C.c_void_p), ("cond_mask", C.c_void_p)]
 
 
+class FrameCfg(C.Structure):
+    _fields_ = [("n_clips", C.c_int32), ("num_transform", C.c_int32), ("n_persons", C.c_int32), ("max_frames", C.c_int32),
+                ("pad_size", C.c_int32), ("frames_shift", C.c_int32), ("gauss_radius", C.c_int32),
+                ("clip_keys", C.c_void_p), ("clip_n_frames", C.c_void_p), ("frame_dst", C.c_void_p), ("clip_out_len", C.c_void_p),
+                ("clip_out_off", C.c_void_p), ("gauss_weights", C.c_void_p)]
+
+
 _SIGS = {
     "mcd_pack_weights": (C.c_int, [C.POINTER(Tensor), C.c_int32, C.POINTER(ModelCfg), C.c_int32, C.POINTER(C.c_void_p)]),
     "mcd_free_weights": (None, [C.c_void_p]),
@@ -56,6 +63,9 @@ _SIGS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_scatter_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p]),
+    "mcd_frame_scores_workspace_bytes": (C.c_int64, [C.POINTER(FrameCfg)]),
+    "mcd_frame_scores": (C.c_int, [C.POINTER(FrameCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_last_error": (C.c_char_p, []),
     "mcd_abi_version": (C.c_int32, []),
 }

@@ -1775,6 +1775,113 @@ __global__ void scatter_max_kernel(const float* __restrict__ scores, const int* 
     atomicMax(reinterpret_cast<int*>(out + (size_t)row[i] * n_frames + f), __float_as_int(fmaxf(scores[i], 0.f)));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Frame-score assembly after the path (mocodad.py:362-425; eval_utils.py:27-34,100-106,133-149), on device, in float64
+// like the reference's NumPy code.
+//   frame_scatter_kernel: window score -> max over the windows covering each frame of its (transform, clip, person) row.
+//   frame_scores_kernel : one workgroup per clip; for every transform: per person pad_scores, then
+//                         mean_p + (max_p - min_p) of log1p over the persons present, HR-mask compaction, shift,
+//                         gaussian_filter1d (scipy defaults: truncate 4 sigma, 'reflect'), accumulated over the transforms
+//                         and divided by their number.
+// Rows are dense: row = (transform * n_clips + clip) * P + person id; `used[row]` marks persons that have windows.
+// ------------------------------------------------------------------------------------------------
+struct FrameParams {
+    const float* scores; const long long* trans; const long long* meta; const int* frames;
+    const long long* clip_keys;     // (n_clips,) sorted (scene << 32 | clip)
+    const int* clip_n;              // (n_clips,) frames of the clip = len(gt)
+    const int* dst;                 // per clip F entries: position of the frame after the HR masks, -1 = dropped
+    const int* out_len;             // (n_clips,) frames kept
+    const long long* out_off;       // (n_clips,) offset of the clip in the concatenated output
+    const double* gauss;            // (2 radius + 1,) normalised weights
+    float* mat; int* used; double* out;
+    long long n;
+    int seg_len, n_clips, num_transform, P, F, pad, shift, radius;
+};
+
+__global__ void frame_scatter_kernel(const FrameParams Q) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= Q.n * Q.seg_len) return;
+    const long long i = u / Q.seg_len;
+    const long long tr = Q.trans[i];
+    if (tr < 0 || tr >= Q.num_transform) return;
+    const long long key = (Q.meta[i * 4 + 0] << 32) | (Q.meta[i * 4 + 1] & 0xffffffffll);
+    int lo = 0, hi = Q.n_clips;                     // lower bound in the sorted clip keys
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (Q.clip_keys[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo >= Q.n_clips || Q.clip_keys[lo] != key) return;        // a clip without a ground-truth file is not evaluated
+    const long long person = Q.meta[i * 4 + 2];
+    if (person < 0 || person >= Q.P) return;
+    const int f = Q.frames[u] - 1;
+    if (f < 0 || f >= Q.clip_n[lo]) return;
+    const long long row = ((long long)tr * Q.n_clips + lo) * Q.P + person;
+    Q.used[row] = 1;
+    // non-negative floats order like their bit patterns (np.nanmax over the windows covering the frame; 0 = absent)
+    atomicMax(reinterpret_cast<int*>(Q.mat + row * Q.F + f), __float_as_int(fmaxf(Q.scores[i], 0.f)));
+}
+
+__global__ __launch_bounds__(256) void frame_scores_kernel(const FrameParams Q) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    const int ci = blockIdx.x, n = Q.clip_n[ci], m = Q.out_len[ci];
+    double* cs = fsm;                 // [m] compacted clip score of the current transform
+    double* acc = fsm + Q.F;          // [m] sum over the transforms
+    const int* dst = Q.dst + (size_t)ci * Q.F;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) acc[j] = 0.0;
+    for (int tr = 0; tr < Q.num_transform; ++tr) {
+        const size_t row0 = ((size_t)tr * Q.n_clips + ci) * Q.P;
+        __syncthreads();
+        for (int f = threadIdx.x; f < n; f += blockDim.x) {
+            double sum = 0.0, lmax = 0.0, lmin = 0.0;
+            int cnt = 0;
+            for (int p = 0; p < Q.P; ++p) {
+                if (!Q.used[row0 + p]) continue;
+                const float* r = Q.mat + (row0 + p) * Q.F;
+                float v = r[f];
+                if (Q.pad >= 0 && v != 0.f) {
+                    // pad_scores (eval_utils.py:133-149): zero `pad` frames before and pad-1 frames after every interval of
+                    // absence inside frames [0, n-2]; an interval touching frame 0 / frame n-2 is not extended on that side
+                    bool z = false;
+                    for (int d = 1; d <= Q.pad && !z; ++d) z = (f + d <= n - 2) && r[f + d] == 0.f;
+                    if (!z) {
+                        // backwards: for the last frame, the run of absence that ends at frame n-2 does not count
+                        bool in_tail = (f == n - 1);
+                        for (int d = 1; d <= Q.pad - 1 && f - d >= 0 && !z; ++d) {
+                            const bool zero = r[f - d] == 0.f;
+                            if (in_tail) { if (!zero) in_tail = false; }
+                            else z = zero;
+                        }
+                    }
+                    if (z) v = 0.f;
+                }
+                const double dv = (double)v, lg = log1p(dv);
+                sum += dv;
+                if (cnt == 0) { lmax = lg; lmin = lg; } else { lmax = fmax(lmax, lg); lmin = fmin(lmin, lg); }
+                ++cnt;
+            }
+            const int j = dst[f];
+            // a (transform, clip) block without any person: NaN (the reference fails on np.stack of an empty list; the host
+            // wrapper turns the NaN into that error)
+            if (j >= 0) cs[j] = cnt > 0 ? sum / (double)cnt + (lmax - lmin) : (double)NAN;
+        }
+        __syncthreads();
+        // score_process (eval_utils.py:100-106): shift by `shift` frames (zeros enter), then correlate with the Gaussian
+        // in scipy's symmetric form: in[c] w[c] + sum_{i=1..radius} (in[c-i] + in[c+i]) w[c-i], outermost pair first
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            auto at = [&](int k) -> double {          // shifted, 'reflect'-extended (d c b a | a b c d | d c b a)
+                const int per = 2 * m;
+                k %= per; if (k < 0) k += per;
+                if (k >= m) k = per - 1 - k;
+                return k >= Q.shift ? cs[k - Q.shift] : 0.0;
+            };
+            double t = at(j) * Q.gauss[Q.radius];
+            for (int i = Q.radius; i >= 1; --i) t += (at(j - i) + at(j + i)) * Q.gauss[Q.radius - i];
+            acc[j] += t;
+        }
+    }
+    __syncthreads();
+    double* o = Q.out + Q.out_off[ci];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) o[j] = acc[j] / (double)Q.num_transform;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -2502,6 +2609,48 @@ int mcd_scatter_max(const float* scores, const int32_t* frames, const int32_t* r
     const long long total = (long long)n * seg_len;
     hipLaunchKernelGGL(scatter_max_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scores, frames, row,
                        (long long)n, seg_len, n_frames, out);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+
+
+int64_t mcd_frame_scores_workspace_bytes(const mcd_frame_cfg_t* c) {
+    if (!c || c->n_clips <= 0 || c->num_transform <= 0 || c->n_persons <= 0 || c->max_frames <= 0) return 0;
+    const int64_t rows = (int64_t)c->num_transform * c->n_clips * c->n_persons;
+    return rows * c->max_frames * 4 + (rows * 4 + 255) / 256 * 256;
+}
+
+int mcd_frame_scores(const mcd_frame_cfg_t* c, const float* scores, const int64_t* trans, const int64_t* meta,
+                     const int32_t* frames, int64_t n_windows, int32_t seg_len, void* workspace, double* out, void* stream) {
+    if (!c || !workspace || !out) return fail(MCD_EINVAL, "null argument");
+    if (c->n_clips <= 0 || c->num_transform <= 0 || c->n_persons <= 0 || c->max_frames <= 0) return fail(MCD_EINVAL, "bad sizes");
+    if (!c->clip_keys || !c->clip_n_frames || !c->frame_dst || !c->clip_out_len || !c->clip_out_off || !c->gauss_weights)
+        return fail(MCD_EINVAL, "null table");
+    if (n_windows > 0 && (!scores || !trans || !meta || !frames)) return fail(MCD_EINVAL, "null argument");
+    if (c->frames_shift < 1) return fail(MCD_EINVAL, "frames_shift must be >= 1 (the reference's score[:-shift] is empty for 0)");
+    if (c->gauss_radius < 0) return fail(MCD_EINVAL, "bad gauss_radius");
+    const size_t lds = (size_t)2 * c->max_frames * sizeof(double);
+    if (lds > 150 * 1024) return fail(MCD_EUNSUPPORTED, "clips longer than 9600 frames");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)c->num_transform * c->n_clips * c->n_persons;
+    FrameParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.scores = scores; Q.trans = reinterpret_cast<const long long*>(trans); Q.meta = reinterpret_cast<const long long*>(meta);
+    Q.frames = frames; Q.clip_keys = reinterpret_cast<const long long*>(c->clip_keys); Q.clip_n = c->clip_n_frames;
+    Q.dst = c->frame_dst; Q.out_len = c->clip_out_len; Q.out_off = reinterpret_cast<const long long*>(c->clip_out_off);
+    Q.gauss = c->gauss_weights;
+    Q.mat = reinterpret_cast<float*>(workspace);
+    Q.used = reinterpret_cast<int*>(Q.mat + rows * c->max_frames);
+    Q.out = out; Q.n = n_windows; Q.seg_len = seg_len; Q.n_clips = c->n_clips; Q.num_transform = c->num_transform;
+    Q.P = c->n_persons; Q.F = c->max_frames; Q.pad = c->pad_size; Q.shift = c->frames_shift; Q.radius = c->gauss_radius;
+    HIP_TRY(hipMemsetAsync(workspace, 0, (size_t)(rows * c->max_frames * 4 + rows * 4), st));
+    if (n_windows > 0) {
+        const long long total = (long long)n_windows * seg_len;
+        hipLaunchKernelGGL(frame_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Q);
+        HIP_TRY(hipGetLastError());
+    }
+    LDS_LIMIT(&frame_scores_kernel, (size_t)150 * 1024);
+    hipLaunchKernelGGL(frame_scores_kernel, dim3(c->n_clips), dim3(256), lds, st, Q);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }

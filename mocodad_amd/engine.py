@@ -266,3 +266,57 @@ class HipScorer:
             _lib.check(self.L.mcd_scatter_max(_ptr(scores), _ptr(frames), _ptr(row), scores.numel(), frames.shape[1],
                                               n_rows, n_frames, _ptr(out), _stream()))
         return out
+
+
+class FrameScoreAssembler:
+    """Window scores -> per-frame anomaly scores on the device (mcd_frame_scores): the whole of the reference's
+    post_processing loops (mocodad.py:362-425) except roc_auc_score.  Built once per dataset from the ground-truth masks."""
+
+    MAX_WORKSPACE = 8 << 30
+
+    def __init__(self, gts, masks, *, num_transform: int, pad_size: int, filter_kernel_size: float, frames_shift: int, device):
+        from .utils.eval_utils import frame_tables, gaussian_kernel1d
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        t = frame_tables(gts, masks)
+        self.gt, self.total, self.F = t["gt"], int(t["total"]), int(t["max_frames"])
+        w = gaussian_kernel1d(filter_kernel_size)
+        self._dev = {k: torch.from_numpy(np.ascontiguousarray(t[k])).to(self.device)
+                     for k in ("clip_keys", "clip_n_frames", "frame_dst", "clip_out_len", "clip_out_off")}
+        self._dev["gauss"] = torch.from_numpy(w).to(self.device)
+        self.n_clips, self.num_transform = len(t["clip_keys"]), int(num_transform)
+        self.pad_size, self.frames_shift, self.radius = int(pad_size), int(frames_shift), (len(w) - 1) // 2
+        self._ws = None
+
+    def _cfg(self, n_persons: int) -> "_lib.FrameCfg":
+        d = self._dev
+        return _lib.FrameCfg(n_clips=self.n_clips, num_transform=self.num_transform, n_persons=n_persons, max_frames=self.F,
+                             pad_size=self.pad_size, frames_shift=self.frames_shift, gauss_radius=self.radius,
+                             clip_keys=d["clip_keys"].data_ptr(), clip_n_frames=d["clip_n_frames"].data_ptr(),
+                             frame_dst=d["frame_dst"].data_ptr(), clip_out_len=d["clip_out_len"].data_ptr(),
+                             clip_out_off=d["clip_out_off"].data_ptr(), gauss_weights=d["gauss"].data_ptr())
+
+    def __call__(self, scores, trans, meta, frames) -> Optional[np.ndarray]:
+        """scores (N,), trans (N,), meta (N,4), frames (N,seg_len): arrays or tensors, host or device -> pds (total,) float64
+        (None if the dense (transform, clip, person) table would not fit the workspace cap: the caller falls back to the host)."""
+        dev = self.device
+        as_t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, dt).contiguous()
+        scores, trans, meta, frames = as_t(scores, torch.float32), as_t(trans, torch.int64), as_t(meta, torch.int64), as_t(frames, torch.int32)
+        n = int(scores.numel())
+        if meta.shape != (n, 4) or trans.numel() != n or frames.shape[0] != n:
+            raise ValueError("scores / trans / meta / frames disagree on the number of windows")
+        n_persons = int(meta[:, 2].max().item()) + 1 if n else 1
+        cfg = self._cfg(max(n_persons, 1))
+        need = int(self.L.mcd_frame_scores_workspace_bytes(C.byref(cfg)))
+        if need > self.MAX_WORKSPACE:
+            return None
+        with torch.cuda.device(dev):
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            out = torch.empty(self.total, device=dev, dtype=torch.float64)
+            _lib.check(self.L.mcd_frame_scores(C.byref(cfg), _ptr(scores), _ptr(trans), _ptr(meta), _ptr(frames), n,
+                                               int(frames.shape[1]) if n else 1, _ptr(self._ws), _ptr(out), _stream()))
+        pds = out.cpu().numpy()
+        if np.isnan(pds).any():
+            raise ValueError("a (transform, clip) block has no pose windows (need at least one array to stack)")
+        return pds

@@ -417,9 +417,7 @@ class MoCoDAD(_Base):
         return auc
 
     # -------------------------------------------------------------- after the path: scores -> AUC
-    def post_processing(self, out: np.ndarray, gt_data: np.ndarray, trans: np.ndarray, meta: np.ndarray,
-                        frames: np.ndarray) -> float:
-        from sklearn.metrics import roc_auc_score
+    def _gt_and_masks(self):
         from ..utils.eval_utils import get_avenue_mask, get_hr_ubnormal_mask
         names = sorted(f for f in os.listdir(self.gt_path) if f.endswith(".npy"))
         gts = {(int(f.split("_")[0]), int(f.split("_")[1].split(".")[0])): np.load(os.path.join(self.gt_path, f)) for f in names}
@@ -428,13 +426,38 @@ class MoCoDAD(_Base):
             masks = dict(get_hr_ubnormal_mask(self.split))
         if self.dataset_name == "HR-Avenue":
             masks.update({("clip", k): v for k, v in get_avenue_mask().items()})
-        scatter = None
-        if self._scorer is not None:
-            scatter = self._scorer.scatter_max
-        pds, gt = post_process_scores(np.asarray(out), np.asarray(trans), np.asarray(meta), np.asarray(frames), gts,
+        return gts, masks
+
+    def _frame_assembler(self):
+        """Device frame-score assembly for the current dataset settings (tables built once, rebuilt when a setting changes)."""
+        key = (self.gt_path, self.dataset_name, self.use_hr, self.split, self.num_transforms, self.anomaly_score_pad_size,
+               self.anomaly_score_filter_kernel_size, self.anomaly_score_frames_shift, str(self.device))
+        if getattr(self, "_asm_key", None) != key:
+            from ..engine import FrameScoreAssembler
+            gts, masks = self._gt_and_masks()
+            self._asm = FrameScoreAssembler(gts, masks, num_transform=self.num_transforms, pad_size=self.anomaly_score_pad_size,
+                                            filter_kernel_size=self.anomaly_score_filter_kernel_size,
+                                            frames_shift=self.anomaly_score_frames_shift, device=self.device)
+            self._asm_key = key
+        return self._asm
+
+    def post_processing(self, out, gt_data, trans, meta, frames) -> float:
+        """Window scores -> AUC (mocodad.py:337-430).  On a GPU the whole frame-score assembly runs in mcd_frame_scores and
+        the host keeps roc_auc_score; without one (saved tensors evaluated offline) the NumPy path below does it.
+        out / trans / meta / frames: NumPy arrays (the reference's signature) or tensors; gt_data is unused, as in the reference."""
+        from sklearn.metrics import roc_auc_score
+        if self.device.type == "cuda" and self.anomaly_score_frames_shift >= 1:
+            asm = self._frame_assembler()
+            pds = asm(out, trans, meta, frames)
+            if pds is not None:
+                return float(roc_auc_score(asm.gt, pds))
+        gts, masks = self._gt_and_masks()
+        _np = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        pds, gt = post_process_scores(_np(out), _np(trans), _np(meta), _np(frames), gts,
                                       num_transform=self.num_transforms, pad_size=self.anomaly_score_pad_size,
                                       filter_kernel_size=self.anomaly_score_filter_kernel_size,
-                                      frames_shift=self.anomaly_score_frames_shift, masks=masks, scatter_max=scatter)
+                                      frames_shift=self.anomaly_score_frames_shift, masks=masks,
+                                      scatter_max=self._scorer.scatter_max if self._scorer is not None else None)
         return float(roc_auc_score(gt, pds))
 
     def test_on_saved_tensors(self, split_name: str) -> float:

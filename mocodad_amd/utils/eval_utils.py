@@ -131,3 +131,50 @@ def post_process_scores(out, trans, meta, frames, gts: Dict[Tuple[int, int], np.
         if gt_cat is None:
             gt_cat = np.concatenate(gcat)
     return np.mean(np.stack(per_transform, 0), 0), gt_cat
+
+
+# ------------------------------------------------------------------ device path (mcd_frame_scores)
+def gaussian_kernel1d(sigma: float, truncate: float = 4.0) -> np.ndarray:
+    """The weights scipy.ndimage.gaussian_filter1d(x, sigma) correlates with (order 0): radius int(truncate*sigma + 0.5)."""
+    sd = float(sigma)
+    radius = int(truncate * sd + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return phi / phi.sum()
+
+
+def frame_tables(gts: Dict[Tuple[int, int], np.ndarray], masks: Optional[Dict] = None):
+    """Per-dataset tables of the device frame-score assembly: clips in ascending (scene, clip) key order (what the kernel
+    binary-searches), their output offsets in sorted file-name order (the order the reference concatenates in), the
+    position of every frame after the HR masks, and the concatenated ground truth."""
+    masks = masks or {}
+    by_name = sorted(gts.keys(), key=lambda k: f"{k[0]:02d}_{k[1]:04d}")
+    slots = sorted(gts.keys(), key=lambda k: (int(k[0]) << 32) | (int(k[1]) & 0xffffffff))
+    F = max(len(g) for g in gts.values())
+    kept, gt_kept = {}, {}
+    for (sc, cl) in by_name:
+        g = np.asarray(gts[(sc, cl)])
+        idx = np.arange(len(g))
+        if (sc, cl) in masks:
+            keep = np.asarray(masks[(sc, cl)]).astype(bool)
+            idx, g = idx[keep], g[keep]
+        if ("clip", cl) in masks:
+            keep = np.asarray(masks[("clip", cl)]) == 1
+            idx, g = idx[keep], g[keep]
+        kept[(sc, cl)], gt_kept[(sc, cl)] = idx, g
+    off, o = {}, 0
+    for k in by_name:
+        off[k] = o
+        o += len(kept[k])
+    dst = np.full((len(slots), F), -1, dtype=np.int32)
+    for i, k in enumerate(slots):
+        dst[i, kept[k]] = np.arange(len(kept[k]), dtype=np.int32)
+    return {
+        "clip_keys": np.array([(int(k[0]) << 32) | (int(k[1]) & 0xffffffff) for k in slots], dtype=np.int64),
+        "clip_n_frames": np.array([len(gts[k]) for k in slots], dtype=np.int32),
+        "frame_dst": dst,
+        "clip_out_len": np.array([len(kept[k]) for k in slots], dtype=np.int32),
+        "clip_out_off": np.array([off[k] for k in slots], dtype=np.int64),
+        "total": o, "max_frames": F,
+        "gt": np.concatenate([gt_kept[k] for k in by_name]) if by_name else np.zeros(0),
+    }

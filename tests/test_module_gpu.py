@@ -86,7 +86,9 @@ def test_test_loop_end_to_end_auc_vs_oracle(tmp_path):
     assert m.logged["AUC"] == auc
 
 
-def test_device_scatter_max_matches_numpy():
+def test_device_scatter_max_vs_the_reference_loop():
+    """mcd_scatter_max against compute_var_matrix + np.nanmax restated here as the reference writes it (one zero matrix per
+    (transform, clip, person), rows = windows, max over rows: eval_utils.py:27-34, mocodad.py:392-393)."""
     from mocodad_amd.utils import eval_utils as EU
     m, _, _ = _model("inject")
     sc = m.scorer()
@@ -96,10 +98,16 @@ def test_device_scatter_max_matches_numpy():
         if k.startswith("gt_"):
             s_, c_ = k[3:].split("_")
             gts[(int(s_), int(c_))] = g[k]
-    a, ka = EU.frame_score_rows(g["out"], g["trans"], g["meta"], g["frames"], gts, 5, scatter_max=None)
-    b, kb = EU.frame_score_rows(g["out"], g["trans"], g["meta"], g["frames"], gts, 5, scatter_max=sc.scatter_max)
-    assert np.array_equal(ka, kb)
-    np.testing.assert_allclose(a, b, rtol=1e-7, atol=0)
+    mat, keys = EU.frame_score_rows(g["out"], g["trans"], g["meta"], g["frames"], gts, 5, scatter_max=sc.scatter_max)
+    assert len(keys) == 5 * 2 * 3
+    for r, (tr, scn, cl, person) in enumerate(keys):
+        sel = (g["trans"] == tr) & (g["meta"][:, 0] == scn) & (g["meta"][:, 1] == cl) & (g["meta"][:, 2] == person)
+        n = len(gts[(scn, cl)])
+        var = np.zeros((int(sel.sum()), n))
+        for w, (val, fr) in enumerate(zip(g["out"][sel], g["frames"][sel])):
+            var[w, fr - 1] = val
+        np.testing.assert_array_equal(mat[r, :n], np.nanmax(var, axis=0).astype(np.float32).astype(np.float64))
+        assert (mat[r, n:] == 0).all()
 
 
 def test_full_size_properties():
