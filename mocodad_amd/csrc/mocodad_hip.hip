@@ -1762,6 +1762,256 @@ __global__ void aggregate_kernel(const AggrParams P) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Runtime-shape fallback of the trajectory kernel: ANY U-Net frame count 1..MCD_MAX_FRAMES (the reference is generic in
+// n_frames, mocodad.py:780-796, stsgcn.py:134-141), every strategy.  Plain fp32 FMAs, one 256-thread workgroup per chain
+// at a time (persistent grid), activations [channel][frame][joint] in a per-workgroup global scratch slab (they do not fit
+// LDS beyond ~12 frames).  Correct, not fast: the specialised score_kernel<T,...> instantiations are the product path for
+// 3, 4, 6, 8 and 12 frames; this one removes MCD_EUNSUPPORTED for everything else and cross-checks them in the tests.
+// Same noise keys, same update, same loss as score_kernel.
+// ------------------------------------------------------------------------------------------------
+struct GLayer { int cin, cout, V, tq, am, wt, wr, bias, embo; float slope; };    // wr < 0: identity residual; embo < 0: no embedding
+struct GenNet { GLayer L[NLAYERS]; int rs_w[4], rs_b[4], we, be; };
+struct FrameMaps { int src_frame[MCD_MAX_FRAMES], tx_of[MCD_MAX_FRAMES], pos_of[MCD_MAX_FRAMES], upd_of[MCD_MAX_FRAMES]; };
+constexpr int GEN_THREADS = 256;
+constexpr int GEN_BUF = 1280;        // floats per frame of the three rotating buffers: 128 ch x 10 joints (>= 32 x 17, 64 x 12)
+constexpr int GEN_D1 = 32 * 17, GEN_D2 = 64 * 12;
+constexpr int GEN_SLAB = 3 * GEN_BUF + GEN_D1 + GEN_D2;      // per frame and workgroup
+
+// one ST-GCN layer (stsgcn.py:94-116, BatchNorm folded): X [cin][T][V] -> O [cout][T][V]; Y (>= cin T V floats, may be O) and
+// Z are scratch.  emb: the pass's embedding outputs (LDS) or null.
+__device__ void g_layer(const float* wb, const GLayer& L, int T, const float* X, float* Y, float* Z, float* O, const float* emb) {
+    const int V = L.V, TV = T * V, tid = threadIdx.x;
+    const float* Tq = wb + L.tq;      // [q][v][t]
+    const float* Am = wb + L.am;      // [q][v][w]
+    for (int u = tid; u < L.cin * TV; u += GEN_THREADS) {
+        const int c = u / TV, q = (u % TV) / V, v = u % V;
+        const float* x = X + c * TV + v;
+        const float* tq = Tq + (q * V + v) * T;
+        float y = 0.f;
+        for (int t = 0; t < T; ++t) y = fmaf(x[t * V], tq[t], y);
+        Y[u] = y;
+    }
+    __syncthreads();
+    for (int u = tid; u < L.cin * TV; u += GEN_THREADS) {
+        const int c = u / TV, q = (u % TV) / V, w = u % V;
+        const float* y = Y + c * TV + q * V;
+        const float* a = Am + q * V * V + w;
+        float z = 0.f;
+        for (int v = 0; v < V; ++v) z = fmaf(y[v], a[v * V], z);
+        Z[u] = z;
+    }
+    __syncthreads();
+    const float* wt = wb + L.wt;
+    const float* wr = L.wr >= 0 ? wb + L.wr : nullptr;
+    const float* bias = wb + L.bias;
+    for (int u = tid; u < L.cout * TV; u += GEN_THREADS) {
+        const int co = u / TV, p = u % TV;
+        float a = bias[co];
+        for (int c = 0; c < L.cin; ++c) a = fmaf(wt[co * L.cin + c], Z[c * TV + p], a);
+        if (wr) { for (int c = 0; c < L.cin; ++c) a = fmaf(wr[co * L.cin + c], X[c * TV + p], a); }
+        else a += X[co * TV + p];
+        a = prelu(a, L.slope);
+        if (emb && L.embo >= 0) a += emb[L.embo + co];
+        O[u] = a;
+    }
+    __syncthreads();
+}
+// joint resampler (stsgcn.py:187-199 over the joint axis): X [C][T][vin] -> O [C][T][vout] (+ skip)
+__device__ void g_resample(const float* wb, int wo, int bo, int C, int T, int vin, int vout, const float* X, float* O, const float* skip) {
+    const float* W = wb + wo;
+    const float* bb = wb + bo;
+    for (int u = threadIdx.x; u < C * T * vout; u += GEN_THREADS) {
+        const int vo = u % vout, ct = u / vout;
+        float a = bb[vo];
+        for (int v = 0; v < vin; ++v) a = fmaf(W[vo * vin + v], X[ct * vin + v], a);
+        if (skip) a += skip[u];
+        O[u] = a;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GEN_THREADS) void score_generic_kernel(const ScoreParams P, const FrameMaps M, const GenNet N, int T,
+                                                                    float* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int TV = T * 17, CTV = C0 * TV, tid = threadIdx.x;
+    float* XT = gsm;                  // chain state [c][t][v] over the U-Net frames
+    float* EPS = XT + CTV;            // layer 10's output (+ x)
+    float* ZN = EPS + CTV;            // this step's noise at the U-Net frames
+    float* EMB = ZN + CTV;            // [EMB_TOTAL + 4]
+    float* SE = EMB + EMB_TOTAL + 4;  // [16]
+    float* RED = SE + EDIM;           // [GEN_THREADS]
+    float* slab = scratch + (size_t)blockIdx.x * GEN_SLAB * T;
+    float* A = slab;
+    float* Bb = A + GEN_BUF * T;
+    float* Zb = Bb + GEN_BUF * T;
+    float* D1 = Zb + GEN_BUF * T;
+    float* D2 = D1 + GEN_D1 * T;
+    const float* wb = P.wbuf;
+    const int Tx = P.n_corrupt;
+    const int K = P.ns > 2 ? P.ns - 1 : 1;
+    const int per = C0 * Tx * 17;
+    for (long long chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
+        const int b = (int)(chain / P.S), s = (int)(chain % P.S);
+        const unsigned fixed = (unsigned)(P.win_mask ? P.win_mask[b] : P.fixed_mask);
+        auto tx_of = [&](int t) { return P.win_mask ? __popc(~fixed & ((1u << t) - 1u)) : M.tx_of[t]; };
+        auto src_of = [&](int t) { return P.win_mask ? t : M.src_frame[t]; };
+        __syncthreads();
+        for (int u = tid; u < CTV; u += GEN_THREADS) {
+            const int c = u / TV, t = (u % TV) / 17, v = u % 17;
+            float x;
+            if (P.mode == 1) x = P.x_in[((size_t)b * C0 + c) * TV + t * 17 + v];
+            else if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
+            else {
+                const int e = (c * Tx + tx_of(t)) * 17 + v;
+                x = P.noise ? P.noise[((size_t)(s * K + 0) * P.B + b) * per + e]
+                            : philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
+            }
+            XT[u] = x;
+        }
+        const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
+        const int i_last = P.mode == 1 ? P.step_single : 1;
+        for (int sidx = i_first; sidx >= i_last; --sidx) {
+            const float* srow = P.step_table + sidx * (4 + EDIM);
+            __syncthreads();
+            if (tid < EDIM) {
+                float e = srow[4 + tid];
+                if (P.cond_emb) e += P.cond_emb[(size_t)b * EDIM + tid];
+                SE[tid] = e / (1.f + expf(-e));
+            }
+            // this step's noise, one thread per (frame, joint pair) like score_kernel (same Philox keys)
+            if (P.mode == 0 && sidx > 1) {
+                const int k = P.ns - sidx;
+                for (int gi = tid; gi < T * 9; gi += GEN_THREADS) {
+                    const int t = gi / 9, v0 = (gi % 9) * 2;
+                    float z[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (!((fixed >> t) & 1u)) {
+                        const int tx = tx_of(t);
+                        if (P.noise) {
+                            const float* zp = P.noise + ((size_t)(s * K + k) * P.B + b) * per + tx * 17 + v0;
+                            z[0] = zp[0]; z[1] = zp[Tx * 17];
+                            if (v0 + 1 < 17) { z[2] = zp[1]; z[3] = zp[Tx * 17 + 1]; }
+                        } else {
+                            philox_normal4(P.seed, (unsigned)(tx * 9 + (v0 >> 1)), (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b), z);
+                        }
+                    }
+                    ZN[t * 17 + v0] = z[0]; ZN[TV + t * 17 + v0] = z[1];
+                    if (v0 + 1 < 17) { ZN[t * 17 + v0 + 1] = z[2]; ZN[TV + t * 17 + v0 + 1] = z[3]; }
+                }
+            }
+            __syncthreads();
+            for (int o = tid; o < EMB_TOTAL; o += GEN_THREADS) {
+                const float* we = wb + N.we + o * EDIM;
+                float a = wb[N.be + o];
+                for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[k], a);
+                EMB[o] = a;
+            }
+            __syncthreads();
+            // ---- the U-Net (stsae_unet.py:406-438)
+            g_layer(wb, N.L[0], T, XT, A, Zb, A, EMB);
+            g_layer(wb, N.L[1], T, A, Bb, Zb, Bb, EMB);
+            g_layer(wb, N.L[2], T, Bb, D1, Zb, D1, EMB);                                         // d1
+            g_resample(wb, N.rs_w[0], N.rs_b[0], 32, T, 17, 12, D1, A, nullptr);                  // down1
+            g_layer(wb, N.L[3], T, A, Bb, Zb, Bb, EMB);
+            g_layer(wb, N.L[4], T, Bb, D2, Zb, D2, EMB);                                         // d2
+            g_resample(wb, N.rs_w[1], N.rs_b[1], 64, T, 12, 10, D2, A, nullptr);                  // down2
+            g_layer(wb, N.L[5], T, A, Bb, Zb, Bb, EMB);
+            g_layer(wb, N.L[6], T, Bb, A, Zb, A, EMB);
+            g_resample(wb, N.rs_w[2], N.rs_b[2], 64, T, 10, 12, A, Bb, D2);                       // up3 + d2
+            g_layer(wb, N.L[7], T, Bb, A, Zb, A, EMB);
+            g_layer(wb, N.L[8], T, A, Bb, Zb, Bb, EMB);
+            g_resample(wb, N.rs_w[3], N.rs_b[3], 32, T, 12, 17, Bb, A, D1);                       // up2 + d1
+            g_layer(wb, N.L[9], T, A, Bb, Zb, Bb, EMB);
+            g_layer(wb, N.L[10], T, Bb, A, Zb, EPS, EMB);
+            // ---- eps = U-Net output + its input; DDPM update of the frame each prediction drives (mocodad.py:172-178,829-838)
+            const float ca = srow[0], cb = srow[1], csg = srow[2];
+            const bool zadd = sidx > 1;
+            float xn[(C0 * MCD_MAX_FRAMES * 17 + GEN_THREADS - 1) / GEN_THREADS];
+            int dst[(C0 * MCD_MAX_FRAMES * 17 + GEN_THREADS - 1) / GEN_THREADS];
+            int it = 0;
+            for (int u = tid; u < CTV; u += GEN_THREADS, ++it) {
+                const int c = u / TV, t = (u % TV) / 17, v = u % 17;
+                const float eps = EPS[u] + XT[u];
+                dst[it] = -1; xn[it] = 0.f;
+                if (P.mode == 1) {
+                    P.eps_out[((size_t)b * C0 + c) * TV + t * 17 + v] = eps;
+                } else {
+                    const int k = P.win_mask ? (((fixed >> t) & 1u) ? -1 : 0) : M.upd_of[t];
+                    if (k >= 0) {
+                        const int tp = P.win_mask ? t : M.pos_of[k];
+                        const int up = c * TV + tp * 17 + v;
+                        xn[it] = ca * (XT[up] - cb * eps) + csg * (zadd ? ZN[up] : 0.f);
+                        dst[it] = up;
+                    }
+                }
+            }
+            __syncthreads();
+            it = 0;
+            for (int u = tid; u < CTV; u += GEN_THREADS, ++it)
+                if (dst[it] >= 0) XT[dst[it]] = xn[it];
+        }
+        if (P.mode == 1) continue;
+        __syncthreads();
+        // ---- loss over the corrupt frames (mocodad.py:484)
+        float part = 0.f;
+        for (int e = tid; e < per; e += GEN_THREADS) {
+            const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
+            int tu = M.pos_of[tx];
+            if (P.win_mask) { int cnt = 0; for (int t = 0; t < T; ++t) if (!((fixed >> t) & 1u)) { if (cnt == tx) tu = t; ++cnt; } }
+            const float x0 = XT[c * TV + tu * 17 + v];
+            const float gt = load_coord(P.dv, b, c, src_of(tu), v, P.seg_len);
+            part += loss_elem(x0, gt, P.loss_fn);
+            if (P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
+        }
+        RED[tid] = part;
+        __syncthreads();
+        for (int o = GEN_THREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
+        if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
+    }
+}
+
+// 'E_unet' condition encoder at any frame count (the U-Net's down path without embeddings + to_time_dim), same scratch scheme
+struct GenCond { GLayer L[7]; int rs_w[2], rs_b[2], lw, lb; };
+__global__ __launch_bounds__(GEN_THREADS) void cond_unet_generic_kernel(const float* wb, const GenCond N, const DataView dv, const FrameIdx fi,
+                                                                        int seg_len, int T, int B, float* __restrict__ emb_out,
+                                                                        float* __restrict__ scratch) {
+    __shared__ float RED[GEN_THREADS];
+    const int TV = T * 17, tid = threadIdx.x;
+    float* slab = scratch + (size_t)blockIdx.x * GEN_SLAB * T;
+    float* A = slab;
+    float* Bb = A + GEN_BUF * T;
+    float* Zb = Bb + GEN_BUF * T;
+    float* D1 = Zb + GEN_BUF * T;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int u = tid; u < C0 * TV; u += GEN_THREADS) {
+            const int c = u / TV, t = (u % TV) / 17, v = u % 17;
+            D1[u] = load_coord(dv, b, c, fi.idx[t], v, seg_len);
+        }
+        __syncthreads();
+        g_layer(wb, N.L[0], T, D1, A, Zb, A, nullptr);
+        g_layer(wb, N.L[1], T, A, Bb, Zb, Bb, nullptr);
+        g_layer(wb, N.L[2], T, Bb, A, Zb, A, nullptr);
+        g_resample(wb, N.rs_w[0], N.rs_b[0], 32, T, 17, 12, A, Bb, nullptr);
+        g_layer(wb, N.L[3], T, Bb, A, Zb, A, nullptr);
+        g_layer(wb, N.L[4], T, A, Bb, Zb, Bb, nullptr);
+        g_resample(wb, N.rs_w[1], N.rs_b[1], 64, T, 12, 10, Bb, A, nullptr);
+        g_layer(wb, N.L[5], T, A, Bb, Zb, Bb, nullptr);
+        g_layer(wb, N.L[6], T, Bb, A, Zb, A, nullptr);            // -> A [6][T][10]
+        const int F = CU_OUT * T * 10;
+        for (int jo = 0; jo < EDIM; ++jo) {
+            float a = 0.f;
+            for (int k = tid; k < F; k += GEN_THREADS) a = fmaf(wb[N.lw + (size_t)jo * F + k], A[k], a);
+            RED[tid] = a;
+            __syncthreads();
+            for (int o = GEN_THREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
+            if (tid == 0) emb_out[(size_t)b * EDIM + jo] = RED[0] + wb[N.lb + jo];
+            __syncthreads();
+        }
+    }
+}
+
 // scatter-max of window scores to frames (mocodad.py:392-393 + eval_utils.py:27-34); scores >= 0
 __global__ void scatter_max_kernel(const float* __restrict__ scores, const int* __restrict__ frames,
                                    const int* __restrict__ row, long long n, int seg_len, int n_frames,
@@ -2018,6 +2268,9 @@ struct mcd_weights {
     bool has_cond;
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
     bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
+    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3, 4, 6, 8, 12); otherwise the runtime-shape kernel
+    GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
+    GenCond gcond;    // ... and of the 'E_unet' condition encoder
     int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
     int opt[MCD_OPT_COUNT];   // mcd_set_option values (plain ints: set before the calls they affect, like any other argument)
 };
@@ -2114,9 +2367,31 @@ int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx&
         default: return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated (supported: 3, 6, 12)");
     }
 }
-// the MFMA condition encoders read the condition frames straight from the window view
-int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
-    return w->cond_unet ? launch_cond_unet(w, data, fi, seg_len, emb, B, st) : launch_cond_fast(w, data, fi, seg_len, emb, B, st);
+constexpr int GEN_MAX_WGS = 2048;       // persistent grid of the runtime-shape kernels (8 workgroups of 4 waves per CU)
+int64_t gen_scratch_bytes(int64_t units, int T) {
+    const int64_t wgs = units < GEN_MAX_WGS ? units : GEN_MAX_WGS;
+    return wgs * (int64_t)GEN_SLAB * T * 4;
+}
+int launch_score_generic(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st) {
+    const int T = w->cfg.t_unet;
+    const int wgs = P.n_chains < GEN_MAX_WGS ? P.n_chains : GEN_MAX_WGS;
+    const size_t lds = ((size_t)3 * C0 * T * 17 + EMB_TOTAL + 4 + EDIM + GEN_THREADS) * 4;
+    hipLaunchKernelGGL(score_generic_kernel, dim3(wgs), dim3(GEN_THREADS), lds, st, P, M, w->gen, T, scratch);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+// the condition encoders that read the condition frames straight from the window view: the MFMA kernels for the frame
+// counts they are instantiated for, the runtime-shape 'E_unet' kernel otherwise (scratch: gen_scratch_bytes(B, Tc))
+int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, float* scratch,
+                     hipStream_t st) {
+    if (!w->cond_unet) return launch_cond_fast(w, data, fi, seg_len, emb, B, st);
+    const int Tc = w->cond.Tc;
+    if ((Tc == 3 || Tc == 6 || Tc == 12) && !w->opt[MCD_OPT_COND_GENERIC]) return launch_cond_unet(w, data, fi, seg_len, emb, B, st);
+    if (!scratch) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape condition encoder");
+    const int wgs = B < GEN_MAX_WGS ? B : GEN_MAX_WGS;
+    hipLaunchKernelGGL(cond_unet_generic_kernel, dim3(wgs), dim3(GEN_THREADS), 0, st, w->dbuf, w->gcond, data, fi, seg_len, Tc, B, emb, scratch);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
 }
 }  // namespace
 
@@ -2136,8 +2411,12 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (cfg->n_joints != 17) return fail(MCD_EUNSUPPORTED, "n_joints must be 17 (the reference U-Net hard-wires 17/12/10 joints)");
     if (cfg->emb_dim != EDIM) return fail(MCD_EUNSUPPORTED, "embedding_dim must be 16");
     const int T = cfg->t_unet;
-    if (T != 3 && T != 4 && T != 6 && T != 8 && T != 12)
-        return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 6, 8, 12)");
+    if (T < 1 || T > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "U-Net frame count must be in 1.." + std::to_string(MCD_MAX_FRAMES));
+    const bool fast_unet = T == 3 || T == 4 || T == 6 || T == 8 || T == 12;     // the instantiated score_kernel<T,...>
+    GenNet G;
+    memset(&G, 0, sizeof(G));
+    GenCond GC;
+    memset(&GC, 0, sizeof(GC));
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
 
@@ -2166,6 +2445,17 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         U.L[l].slope = sl[0];
         memcpy(&B.buf[U.we + (size_t)emb_off(l) * EDIM], we, sizeof(float) * D.cout * EDIM);
         memcpy(&B.buf[U.be + emb_off(l)], be, sizeof(float) * D.cout);
+        {   // plain layout for the runtime-shape kernel
+            GLayer& g = G.L[l];
+            g.cin = cin; g.cout = D.cout; g.V = D.V; g.slope = sl[0]; g.embo = emb_off(l);
+            if (!pack_mix(tm, p, T, D.V, B, g.tq, g.am)) return fail(MCD_EMISSING, tm.missing);
+            g.wt = B.alloc(ft.w.size());
+            for (size_t i = 0; i < ft.w.size(); ++i) B.buf[g.wt + i] = (float)ft.w[i];
+            g.wr = -1;
+            if (D.res) { g.wr = B.alloc(fr.w.size()); for (size_t i = 0; i < fr.w.size(); ++i) B.buf[g.wr + i] = (float)fr.w[i]; }
+            g.bias = B.alloc(D.cout);
+            for (int o = 0; o < D.cout; ++o) B.buf[g.bias + o] = (float)(ft.b[o] + (D.res ? fr.b[o] : 0.0));
+        }
         const int mpad = ceil16(D.cout);
         U.L[l].bias = B.alloc(mpad);
         for (int o = 0; o < D.cout; ++o) B.buf[U.L[l].bias + o] = (float)(ft.b[o] + (D.res ? fr.b[o] : 0.0));
@@ -2208,7 +2498,12 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             B.buf[U.rs_w[r] + (mt * KS + ks) * 64 + lane] = (vo < vout && v < vin) ? (float)f.w[(size_t)vo * vin + v] : 0.f;
         }
         for (int vo = 0; vo < vout; ++vo) B.buf[U.rs_b[r] + vo] = (float)f.b[vo];
+        G.rs_w[r] = B.alloc((size_t)vout * vin);
+        for (size_t i = 0; i < f.w.size(); ++i) B.buf[G.rs_w[r] + i] = (float)f.w[i];
+        G.rs_b[r] = B.alloc(vout);
+        for (int vo = 0; vo < vout; ++vo) B.buf[G.rs_b[r] + vo] = (float)f.b[vo];
     }
+    G.we = U.we; G.be = U.be;
     // condition encoder
     CondW Cw;
     memset(&Cw, 0, sizeof(Cw));
@@ -2219,7 +2514,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     int utab[TABC_ULB + 1] = {0};   // cond table of the 'E_unet' encoder: 7 layers, 2 resamplers, Linear
     if (cond_unet) {
         const int Tc = cfg->t_cond;
-        if (Tc != 3 && Tc != 6 && Tc != 12) return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated (supported: 3, 6, 12)");
+        if (Tc < 1 || Tc > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1.." + std::to_string(MCD_MAX_FRAMES));
         Cw.Tc = Tc; Cw.latent = EDIM;
         static const char* unames[7] = {"st_gcnnsp1a.0", "st_gcnnsd1.0", "st_gcnnsd1.1", "st_gcnnsd2.0", "st_gcnnsd2.1", "st_gcnnsd3.0", "st_gcnnsd3.1"};
         static const int ucin[7] = {C0, 16, 32, 32, 64, 64, 128}, ucout[7] = {16, 32, 32, 64, 64, 128, CU_OUT}, uv[7] = {17, 17, 17, 12, 12, 10, 10};
@@ -2244,6 +2539,17 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             for (int o = 0; o < cout; ++o) B.buf[bias + o] = (float)(ft.b[o] + (res ? fr.b[o] : 0.0));
             utab[l * F_STRIDE + F_TQ] = tq; utab[l * F_STRIDE + F_AM] = am; utab[l * F_STRIDE + F_WP] = wp; utab[l * F_STRIDE + F_BIAS] = bias;
             memcpy(&utab[l * F_STRIDE + F_SLOPE], &sl[0], sizeof(float));
+            {   // plain layout for cond_unet_generic_kernel
+                GLayer& g = GC.L[l];
+                g.cin = cinr; g.cout = cout; g.V = uv[l]; g.slope = sl[0]; g.embo = -1;
+                if (!pack_mix(tm, p, Tc, uv[l], B, g.tq, g.am)) return fail(MCD_EMISSING, tm.missing);
+                g.wt = B.alloc(ft.w.size());
+                for (size_t i = 0; i < ft.w.size(); ++i) B.buf[g.wt + i] = (float)ft.w[i];
+                g.wr = -1;
+                if (res) { g.wr = B.alloc(fr.w.size()); for (size_t i = 0; i < fr.w.size(); ++i) B.buf[g.wr + i] = (float)fr.w[i]; }
+                g.bias = B.alloc(cout);
+                for (int o = 0; o < cout; ++o) B.buf[g.bias + o] = (float)(ft.b[o] + (res ? fr.b[o] : 0.0));
+            }
         }
         static const char* urs[2] = {"down1", "down2"};
         static const int urin[2] = {17, 12}, urout[2] = {12, 10};
@@ -2259,6 +2565,10 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             }
             for (int vo = 0; vo < vout; ++vo) B.buf[bo + vo] = (float)f.b[vo];
             utab[TABC_URS + 2 * r] = wf; utab[TABC_URS + 2 * r + 1] = bo;
+            GC.rs_w[r] = B.alloc((size_t)vout * vin);
+            for (size_t i = 0; i < f.w.size(); ++i) B.buf[GC.rs_w[r] + i] = (float)f.w[i];
+            GC.rs_b[r] = B.alloc(vout);
+            for (int vo = 0; vo < vout; ++vo) B.buf[GC.rs_b[r] + vo] = (float)f.b[vo];
         }
         const int64_t F = (int64_t)CU_OUT * Tc * 10;
         const float* lw = tm.get("condition_encoder.to_time_dim.weight", F * EDIM);
@@ -2266,9 +2576,10 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         if (!lw || !lb) return fail(MCD_EMISSING, tm.missing);
         utab[TABC_ULW] = B.alloc(F * EDIM); memcpy(&B.buf[utab[TABC_ULW]], lw, sizeof(float) * F * EDIM);
         utab[TABC_ULB] = B.alloc(EDIM); memcpy(&B.buf[utab[TABC_ULB]], lb, sizeof(float) * EDIM);
+        GC.lw = utab[TABC_ULW]; GC.lb = utab[TABC_ULB];
     } else if (has_cond) {
         if (cfg->cond_layers < 1 || cfg->cond_layers > MCD_MAX_COND_LAYERS) return fail(MCD_EINVAL, "bad cond_layers");
-        if (cfg->t_cond < 1 || cfg->t_cond > 12) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1..12");
+        if (cfg->t_cond < 1 || cfg->t_cond > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1.." + std::to_string(MCD_MAX_FRAMES));
         Cw.n_layers = cfg->cond_layers; Cw.Tc = cfg->t_cond; Cw.latent = EDIM; Cw.cmax = C0;
         int cin = C0;
         for (int l = 0; l < Cw.n_layers; ++l) {
@@ -2352,7 +2663,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev_dev};
     mcd_weights* w = new mcd_weights();
     memset(w->opt, 0, sizeof(w->opt));
-    w->zero_row = zero_row;
+    w->zero_row = zero_row; w->fast_unet = fast_unet; w->gen = G; w->gcond = GC;
     w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast; w->cond_unet = cond_unet;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -2388,7 +2699,9 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
         DataView dv;
         memset(&dv, 0, sizeof(dv));
         dv.data = cond_data;
-        return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, (hipStream_t)stream);
+        if (w->cond_unet && !(w->cond.Tc == 3 || w->cond.Tc == 6 || w->cond.Tc == 12))
+            return fail(MCD_EUNSUPPORTED, "mcd_cond_encode: the 'E_unet' encoder at this frame count needs scratch memory; use mcd_score");
+        return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, nullptr, (hipStream_t)stream);
     }
     const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
     LDS_LIMIT(&cond_encode_kernel, (size_t)160 * 1024);
@@ -2407,7 +2720,16 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     P.wbuf = w->dbuf; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
     P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.fixed_mask = 0;
     P.mode = 1; P.step_single = t; P.n_chains = n_windows;
-    return launch_score(w, w->cfg.t_unet, P, (hipStream_t)stream);
+    if (w->fast_unet && !w->opt[MCD_OPT_GENERIC_UNET]) return launch_score(w, w->cfg.t_unet, P, (hipStream_t)stream);
+    // runtime-shape kernel (a test entry here): its scratch slabs come from the stream-ordered allocator
+    hipStream_t st = (hipStream_t)stream;
+    float* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)gen_scratch_bytes(n_windows, w->cfg.t_unet), st));
+    FrameMaps M;
+    memset(&M, 0, sizeof(M));
+    const int rc = launch_score_generic(w, P, M, scratch, st);
+    HIP_TRY(hipFreeAsync(scratch, st));
+    return rc;
 }
 
 int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* emb, int32_t n_windows, float* out,
@@ -2478,8 +2800,12 @@ static int64_t ws_cond_bytes(const mcd_weights* w, int64_t B) {
 }
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg) {
     if (!w || !cfg) return 0;
-    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V)
-    return ws_cond_bytes(w, cfg->n_windows);
+    // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V); then the scratch slabs of the runtime-shape kernels
+    // (frame counts without a specialised instantiation, or MCD_OPT_GENERIC_UNET / MCD_OPT_COND_GENERIC)
+    int64_t gen = 0;
+    if (!w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET]) gen = gen_scratch_bytes((int64_t)cfg->n_windows * cfg->n_samples, w->cfg.t_unet);
+    if (w->cond_unet) { const int64_t g2 = gen_scratch_bytes(cfg->n_windows, w->cond.Tc); if (g2 > gen) gen = g2; }
+    return ws_cond_bytes(w, cfg->n_windows) + gen;
 }
 
 __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out, int B, int C, int T, int V, int n,
@@ -2513,7 +2839,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
     if (rnd && !(view && view->cond_mask)) return fail(MCD_EINVAL, "random_imp needs mcd_window_view_t.cond_mask");
     const int tf = keeps_cond ? cfg->n_cond : 0;
     if (tf + cfg->n_corrupt != Tu) return fail(MCD_EINVAL, "frame split does not match the packed U-Net (t_unet)");
-    if (Tu > 12) return fail(MCD_EUNSUPPORTED, "more than 12 U-Net frames");
+    const bool generic = !w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET] != 0;      // runtime-shape kernel
     if (strat == MCD_STRATEGY_INJECT && cfg->n_cond != w->cfg.t_cond) return fail(MCD_EINVAL, "n_cond does not match the packed condition encoder");
     hipStream_t st = (hipStream_t)stream;
     ScoreParams P;
@@ -2531,26 +2857,38 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
     P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
     // U-Net frame layout: concat = condition frames first (mocodad.py:668), imputation = natural frame order
     // (mocodad.py:672-683), inject / no_condition = the corrupt frames only
+    FrameMaps M;
+    memset(&M, 0, sizeof(M));
     for (int k = 0; k < tf && !rnd; ++k) {
         const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->cond_idx[k] : k;
         if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad cond_idx");
         P.fixed_mask |= 1 << t;
-        P.src_frame[t] = cfg->cond_idx[k];
+        M.src_frame[t] = cfg->cond_idx[k];
     }
     for (int k = 0; k < cfg->n_corrupt && !rnd; ++k) {
         const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->corrupt_idx[k] : tf + k;
         if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad corrupt_idx");
-        P.src_frame[t] = cfg->corrupt_idx[k];
-        P.tx_of[t] = k;
-        P.pos_of[k] = t;
+        M.src_frame[t] = cfg->corrupt_idx[k];
+        M.tx_of[t] = k;
+        M.pos_of[k] = t;
     }
-    for (int t = 0; t < 12; ++t) P.upd_of[t] = -1;
+    for (int t = 0; t < MCD_MAX_FRAMES; ++t) M.upd_of[t] = -1;
     for (int k = 0; k < cfg->n_corrupt && !rnd; ++k) {
         const int t = keeps_cond ? cfg->corrupt_idx[k] : k;     // mocodad.py:829-838: mask built from corrupt_idxs
-        if (t < 0 || t >= Tu || P.upd_of[t] >= 0) return fail(MCD_EINVAL, "bad corrupt_idx");
-        P.upd_of[t] = k;
-        if (P.pos_of[k] != t) P.upd_shift = 1;
+        if (t < 0 || t >= Tu || M.upd_of[t] >= 0) return fail(MCD_EINVAL, "bad corrupt_idx");
+        M.upd_of[t] = k;
+        if (M.pos_of[k] != t) P.upd_shift = 1;
     }
+    for (int t = 0; t < 12; ++t) {      // the specialised kernels (<= 12 frames) carry the maps in their parameter block
+        P.src_frame[t] = M.src_frame[t]; P.tx_of[t] = M.tx_of[t]; P.pos_of[t] = M.pos_of[t]; P.upd_of[t] = M.upd_of[t];
+    }
+    // workspace: [condition embeddings | gathered condition frames][scratch slabs of the runtime-shape kernels]
+    float* gen_scratch = workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_cond_bytes(w, B)) : nullptr;
+    auto score = [&]() -> int {
+        if (!generic) return launch_score(w, Tu, P, st);
+        if (!workspace) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape kernel");
+        return launch_score_generic(w, P, M, gen_scratch, st);
+    };
     if (strat == MCD_STRATEGY_INJECT) {
         if (!workspace) return fail(MCD_EINVAL, "workspace required for the inject strategy");
         float* emb = reinterpret_cast<float*>(workspace);
@@ -2559,10 +2897,10 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (w->cond_unet || (w->cond_fast && !w->opt[MCD_OPT_COND_GENERIC])) {
             FrameIdx fi;
             for (int k = 0; k < MCD_MAX_FRAMES; ++k) fi.idx[k] = cfg->cond_idx[k];
-            int rc = launch_cond_mfma(w, P.dv, fi, cfg->seg_len, emb, B, st);
+            int rc = launch_cond_mfma(w, P.dv, fi, cfg->seg_len, emb, B, gen_scratch, st);
             if (rc != MCD_OK) return rc;
             P.cond_emb = emb;
-            return launch_score(w, Tu, P, st);
+            return score();
         }
         const int total = B * C0 * Tc * 17;
         FrameIdx fi;
@@ -2574,7 +2912,7 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         if (rc != MCD_OK) return rc;
         P.cond_emb = emb;
     }
-    return launch_score(w, Tu, P, st);
+    return score();
 }
 
 int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,

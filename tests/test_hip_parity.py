@@ -88,17 +88,14 @@ def test_ragged_batch_vs_oracle(B):
     np.testing.assert_allclose(loss.cpu().numpy(), l_ref.t().numpy(), atol=ATOL, rtol=0)
 
 
-@pytest.mark.parametrize("strategy,seg_len,ci", [("inject", 8, 2), ("concat", 8, [0, 1, 2, 3]), ("inject", 12, 3)])
-def test_other_frame_counts_vs_oracle(strategy, seg_len, ci):
-    """U-Net frame counts 4 and 8 (seg_len 8 split in halves / concatenated; seg_len 12 with 4 condition frames), which no
-    reference-generated fixture covers: a randomly initialised model with perturbed BatchNorm statistics, HIP vs. oracle."""
+def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
+    """A randomly initialised model with perturbed BatchNorm statistics (no reference-generated fixture covers these shapes)."""
     from helpers import golden_weights, make_args
     from mocodad_amd.models.mocodad import MoCoDAD
-    from oracle import mocodad_oracle as O
     _, cfg = golden_weights("inject")
-    torch.manual_seed(5)
+    torch.manual_seed(seed)
     m = MoCoDAD(make_args(cfg, conditioning_strategy=strategy, seg_len=seg_len, conditioning_indices=ci, noise_steps=4,
-                          n_generated_samples=2))
+                          n_generated_samples=2, conditioning_architecture=arch))
     gen = torch.Generator().manual_seed(17)
     with torch.no_grad():
         for mod in m.modules():
@@ -111,6 +108,20 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci):
         last.tcn[0].weight.mul_(0.25)
         last.residual[0].weight.mul_(0.25)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m, sd, gen
+
+
+@pytest.mark.parametrize("strategy,seg_len,ci,arch", [
+    ("inject", 8, 2, "AE"), ("concat", 8, [0, 1, 2, 3], "AE"), ("inject", 12, 3, "AE"),          # 4 and 8 U-Net frames: specialised kernels
+    # frame counts WITHOUT a specialised instantiation -> the runtime-shape kernel (the reference is generic in n_frames)
+    ("inject", 10, 2, "AE"), ("concat", 7, [0, 1, 2], "AE"), ("no_condition", 5, None, "AE"), ("inject", 10, 2, "E_unet"),
+    ("inbetween_imp", 10, 2, "AE"), ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE")])
+def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
+    """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 4 / 8 frames on the specialised
+    kernels; 5, 7, 10, 16 and 24 frames (seg_len 10 split 5 + 5, concat over 7 or 24 frames, the longest window the ABI
+    takes: 32 = 16 + 16, ...) on the runtime-shape fallback, including the 'E_unet' encoder."""
+    from oracle import mocodad_oracle as O
+    m, sd, gen = _random_model(strategy, seg_len, ci, arch)
     m = m.to("cuda:0")
     B, S, ns = 5, 2, 4
     data = torch.randn(B, 2, seg_len, 17, generator=gen).clamp_(-3, 3)
@@ -123,6 +134,56 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci):
         l_ref = O.window_losses(p_ref, corrupt)
     np.testing.assert_allclose(out[1].cpu().numpy(), p_ref.transpose(0, 1).numpy(), atol=ATOL, rtol=1e-5)
     np.testing.assert_allclose(out[0].cpu().numpy(), l_ref.t().numpy(), atol=ATOL, rtol=0)
+    # perf mode (in-kernel Philox) == the same kernel fed with the exported draws
+    sc = m.scorer()
+    a, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
+    z = sc.philox_noise(B, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
+    b, _ = sc.score(data, n_samples=S, noise_steps=ns, noise=z)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant,ns,S", [("inject", 10, 5), ("concat", 10, 5), ("T12", 10, 2), ("injtail", 10, 2)])
+def test_runtime_shape_kernel_vs_golden_and_specialised(variant, ns, S):
+    """The runtime-shape fallback forced (option 'generic_unet') on shapes the specialised kernels serve: it reproduces the
+    reference-generated trajectories, and agrees with the specialised kernel in perf mode (same Philox keys) to rounding."""
+    sc, _, _ = _scorer(variant)
+    g = load_golden(f"traj_{variant}_ns{ns}_S{S}.npz")
+    data = torch.from_numpy(g["data"])
+    noise = torch.from_numpy(g["noise"].astype(np.float32))
+    fast, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=9)
+    sc.set_option("generic_unet", 1)
+    loss, poses = sc.score(data, n_samples=S, noise_steps=ns, noise=noise, want_poses=True)
+    np.testing.assert_allclose(poses.cpu().numpy(), g["poses_all"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss_all"], atol=ATOL, rtol=0)
+    slow, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=9)
+    np.testing.assert_allclose(slow.cpu().numpy(), fast.cpu().numpy(), atol=ATOL, rtol=0)
+    gp = load_golden(f"pass_{variant}.npz")
+    cond = torch.from_numpy(gp["cond"]) if "cond" in gp else None
+    eps = sc.unet_forward(torch.from_numpy(gp["x"]), 9, cond, noise_steps=10).cpu().numpy()
+    np.testing.assert_allclose(eps, gp["eps_t9"], atol=ATOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["cattail", "cattail2", "imp2", "nocond", "encU"])
+def test_runtime_shape_kernel_vs_extra_goldens(name):
+    """The fallback forced on the reference-generated vectors of the frame layouts with index quirks: concat with the
+    condition at the END (predictions read at the corrupt frames' original indices; with 2 + 4 frames a prediction drives a
+    frame that is another prediction's input), in-between imputation, no condition, and the 'E_unet' encoder through
+    cond_unet_generic_kernel (option 'cond_generic')."""
+    from oracle import mocodad_oracle as O
+    sc, _, cfg = _scorer(name) if name != "encU" else (None, None, None)
+    if name == "encU":
+        from mocodad_amd.engine import HipScorer
+        w = load_golden("weights_encU.npz")
+        cfg = json.loads(bytes(w.pop("__cfg__")).decode())
+        sd = {k: torch.from_numpy(v) for k, v in w.items()}
+        sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5], cond_unet=True, device="cuda:0")
+        sc.set_option("cond_generic", 1)
+    sc.set_option("generic_unet", 1)
+    g = load_golden(f"traj_{name}_ns4_S2.npz")
+    loss, poses = sc.score(torch.from_numpy(g["data"]), n_samples=2, noise_steps=4,
+                           noise=torch.from_numpy(g["noise"].astype(np.float32)), want_poses=True)
+    np.testing.assert_allclose(poses.cpu().numpy(), g["pose_all"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy(), g["loss_all"], atol=ATOL, rtol=0)
 
 
 def test_empty_batch():

@@ -207,13 +207,13 @@ def test_window_views_score_like_materialised_windows(tmp_path):
 
 def test_c_abi_error_paths():
     """Argument / capability errors come back as negative codes + a message (raised as RuntimeError by the ctypes layer),
-    never as a crash: unsupported frame count, random_imp without its per-window masks, a wrong frame split, S > 64."""
+    never as a crash: too many frames, random_imp without its per-window masks, a wrong frame split, S > 64."""
     from mocodad_amd.engine import HipScorer
     from mocodad_amd.models.mocodad import MoCoDAD
     sd, cfg = golden_weights("inject")
-    # seg_len 10 split 5 + 5: U-Net frame count 5 is not instantiated -> MCD_EUNSUPPORTED at pack time
-    m = MoCoDAD(make_args(cfg, seg_len=10, conditioning_indices=2)).to("cuda:0")
-    with pytest.raises(RuntimeError, match="not instantiated"):
+    # more frames than MCD_MAX_FRAMES -> MCD_EUNSUPPORTED at pack time (every count up to 32 is served)
+    m = MoCoDAD(make_args(cfg, seg_len=40, conditioning_strategy="concat", conditioning_indices=[0, 1, 2])).to("cuda:0")
+    with pytest.raises(RuntimeError, match="must be in 1..32"):
         m.scorer()
     # random_imp needs the per-window condition-frame masks
     sdr, cfgr = golden_weights("rndimp")
