@@ -120,8 +120,9 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
 int mcd_philox_noise(uint64_t seed, int64_t first_window_id, int32_t n_windows, int32_t n_samples, int32_t noise_steps,
                      int32_t n_corrupt, float* noise_out, void* stream);
 
-/* Bytes of caller-provided device scratch mcd_score needs (condition embeddings).  Strategies without a condition
- * encoder also accept workspace == NULL. */
+/* Bytes of caller-provided device scratch a scoring call may need: condition embeddings when the condition encoder runs
+ * as its own launch, (B,S) losses when an aggregation cannot be fused, scratch slabs of the runtime-shape kernels.  With
+ * the shipped architecture on a specialised frame count none of it is touched and workspace == NULL is accepted. */
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* Per-handle options (no environment variables, no process-wide state).  Set them before the calls they affect, from the
@@ -133,8 +134,13 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
  *   MCD_OPT_COND_GENERIC  1: run the condition encoder through the runtime-channel-list kernel even when the shipped
  *                         architecture's MFMA kernel applies (used by the tests to cover both).
  *   MCD_OPT_GENERIC_UNET  1: run the trajectory through the runtime-shape fallback kernel even when a specialised
- *                         instantiation exists (used by the tests to cover both). */
-enum { MCD_OPT_BF16X3 = 0, MCD_OPT_VARIANT = 1, MCD_OPT_COND_GENERIC = 2, MCD_OPT_GENERIC_UNET = 3, MCD_OPT_COUNT = 4 };
+ *                         instantiation exists (used by the tests to cover both).
+ *   MCD_OPT_SPLIT         0 (default): the library chooses how many workgroups share a window's samples (1 = a workgroup
+ *                         runs all samples of its windows: condition encoder and aggregation fused into the ONE launch;
+ *                         n_samples = one trajectory per workgroup, better fill for odd batch sizes); n > 0 forces it
+ *                         (tests). */
+enum { MCD_OPT_BF16X3 = 0, MCD_OPT_VARIANT = 1, MCD_OPT_COND_GENERIC = 2, MCD_OPT_GENERIC_UNET = 3, MCD_OPT_SPLIT = 4,
+       MCD_OPT_COUNT = 5 };
 int mcd_set_option(mcd_weights_t* w, int32_t option, int32_t value);
 
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.
@@ -172,6 +178,15 @@ typedef struct {
 int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
                    const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
                    float* loss_out, float* pose_out, void* stream);
+
+/* mcd_score_view + the loss-based aggregation over the samples (mocodad.py:489-492,504-516: MCD_AGGR_BEST / WORST / MEAN /
+ * MEDIAN / QUANTILE) in ONE call -- and, whenever the workgroups own whole windows, in ONE kernel launch: the condition
+ * encoder runs in the workgroup that owns the window, the per-sample losses stay in its LDS, loss_agg (B,) is all that
+ * is written.  loss_all (B,S) and pose_out are optional extra outputs (NULL = not wanted).  The *_pose strategies need the
+ * generated poses of all samples: mcd_score + mcd_aggregate. */
+int mcd_score_fused(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
+                    const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+                    int32_t aggregation, float quantile, float* loss_agg, float* loss_all, float* pose_out, void* stream);
 
 /* Replaces: MoCoDAD._aggregation_strategy (mocodad.py:454-520) on the (B,S) losses / (B,S,C,Tx,V) poses.
  * data/cfg give the ground-truth corrupt frames for the *_pose strategies.  loss_agg (B,), pose_agg

@@ -13,7 +13,7 @@ STRATEGY = {"inject": 0, "concat": 1, "no_condition": 2, "inbetween_imp": 3, "ra
 LOSS = {"smooth_l1": 0, "l1": 1, "mse": 2}
 COND_UNET = -1  # MCD_COND_UNET
 AGGR = {"all": 0, "best": 1, "worst": 2, "mean": 3, "median": 4, "mean_pose": 5, "median_pose": 6, "quantile": 7}
-OPT = {"bf16x3": 0, "variant": 1, "cond_generic": 2, "generic_unet": 3}     # MCD_OPT_*
+OPT = {"bf16x3": 0, "variant": 1, "cond_generic": 2, "generic_unet": 3, "split": 4}     # MCD_OPT_*
 ABI_VERSION = 2
 
 
@@ -59,6 +59,8 @@ _SIGS = {
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_score_view": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.POINTER(WindowView), C.c_void_p, C.c_uint64,
                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcd_score_fused": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.POINTER(WindowView), C.c_void_p, C.c_uint64,
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_aggregate": (C.c_int, [C.POINTER(ScoreCfg), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_scatter_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

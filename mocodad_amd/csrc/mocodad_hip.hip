@@ -167,6 +167,16 @@ struct ScoreParams {
     unsigned long long seed;
     long long first_window;
     int B, S, ns, seg_len, n_corrupt, loss_fn, mode, step_single, n_chains;
+    // A workgroup owns NB WINDOWS (group g = blockIdx / split) and runs the samples s = part, part + split, ... of both
+    // (part = blockIdx % split) one trajectory after the other.  split = 1: it sees every sample of its windows, so the
+    // condition encoder runs once per workgroup in its own LDS (cond_inkernel) and the aggregation over the samples
+    // (loss_agg, aggr, aggr_q) happens here too: ONE launch per scoring call.
+    int split, aggr, cond_inkernel;
+    int force_split;          // host only (MCD_OPT_SPLIT): 0 = choose
+    int loss_out_optional;    // host only: loss_out is the library's own scratch, not wanted when the aggregation is fused
+    float aggr_q;
+    float* loss_agg;          // (B,) aggregated loss, or null
+    int cond_idx[12];         // cond_inkernel: data frames the condition encoder reads
     int upd_shift;            // some prediction updates a frame other than the one it is read at (element-wise tail: barrier between reads and writes)
     int fixed_mask;           // bit t: U-Net frame t is a condition frame copied from the window (concat / imputation)
     int src_frame[12];        // data frame feeding U-Net frame t (condition frame, or ground truth of a denoised one)
@@ -244,6 +254,36 @@ __device__ __forceinline__ float prelu_bound(float a) {
     return __int_as_float(__float_as_int(a) <= 0x3f800000 ? 0x7f800000 : (int)0xff800000);
 }
 __device__ __forceinline__ float prelu(float x, float a) { return __builtin_amdgcn_fmed3f(x, a * x, prelu_bound(a)); }
+
+// aggregation of one window's S per-sample losses (mocodad.py:504-512 best / worst with strict comparisons from 1e10 / -1,
+// :489-492 mean / median, :513-516 quantile): torch's conventions -- median = lower middle, quantile = linear interpolation
+// (torch.lerp).  Sorts L in place for the order statistics.
+__device__ __forceinline__ float aggregate_losses(float* L, int S, int strategy, float q) {
+    if (strategy == MCD_AGGR_BEST || strategy == MCD_AGGR_WORST) {
+        const bool best = strategy == MCD_AGGR_BEST;
+        float cur = best ? 1e10f : -1.f;
+        for (int s = 0; s < S; ++s) if (best ? (L[s] < cur) : (L[s] > cur)) cur = L[s];
+        return cur;
+    }
+    if (strategy == MCD_AGGR_MEAN) {
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum += L[s];
+        return sum / (float)S;
+    }
+    for (int i = 1; i < S; ++i) {          // insertion sort (S <= 64)
+        const float x = L[i];
+        int k = i - 1;
+        while (k >= 0 && L[k] > x) { L[k + 1] = L[k]; --k; }
+        L[k + 1] = x;
+    }
+    if (strategy == MCD_AGGR_MEDIAN) return L[(S - 1) / 2];
+    const float pos = q * (float)(S - 1);
+    const int lo = (int)floorf(pos);
+    const int hi = lo + 1 < S ? lo + 1 : S - 1;
+    const float wgt = pos - (float)lo;
+    const float a = L[lo], c = L[hi];
+    return wgt < 0.5f ? a + wgt * (c - a) : c - (c - a) * (1.f - wgt);
+}
 
 // ------------------------------------------------------------------------------------------------
 // DPP helpers.  A coefficient row (<= 16 values) lives in ONE VGPR, value i in lane i of every 16-lane row
@@ -942,14 +982,93 @@ struct Plan {
     static constexpr int UPD = 16;              // per (chain, U-Net frame): first column of the frame its prediction updates, or -1
     static constexpr int ZO = P17 * 2;          // layer 10's mixed output Z[col][c] between its mix and the element-wise tail
     static constexpr int TT = P17 * 2;          // per (column, coordinate) of the element-wise tail: packed (chain, frame, joint) indices
+    static constexpr int CE = 4 * EDIM;         // condition embeddings of the workgroup's windows [NB <= 4][16]
+    static constexpr int LOSS = NB * 64;        // per-sample losses of the workgroup's windows [NB][S <= 64] (in-kernel aggregation)
 #ifdef MCD_PROFILE
     static constexpr int PROF = PROF_SLOTS;
 #else
     static constexpr int PROF = 0;
 #endif
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + PROF;
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + PROF;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
+
+// ------------------------------------------------------------------------------------------------
+// condition encoder, fast path for the shipped architecture (channels [32,16,32] + h_dim 32, latent 16):
+// the same MFMA mix / GEMM stages as the U-Net, NB windows per 512-thread workgroup, followed by the
+// bottleneck Linear over the (c,t,v) flattening (stsae.py:73-89).  Reads the condition frames straight from the
+// window tensor (no gather pass).  Other channel lists use cond_encode_kernel below.
+// ------------------------------------------------------------------------------------------------
+constexpr int TABC = 128;                  // cond table: second 128 words of the weight buffer
+constexpr int TABC_LW = 40, TABC_LB = 41;  // bottleneck Linear weight [16][32*T*17] / bias
+struct FrameIdx { int idx[MCD_MAX_FRAMES]; };
+
+// body shared by cond_fast_kernel and by the trajectory kernel's prologue (P.cond_inkernel): windows b0 .. b0 + NB - 1,
+// frame_of(t) = data frame of condition frame t; the embeddings go to emb_lds[n][16] (LDS) and / or emb_out (B,16).
+// smem: P17 * (2 * 20 + 2 * 36) floats, zeroed by the caller.
+template <int T, int NB, class FrameOf>
+__device__ __forceinline__ void cond_fast_body(const float* wbuf, const DataView& dv, FrameOf&& frame_of, int seg_len, float* smem,
+                                               int b0, int B, float* emb_lds, float* __restrict__ emb_out) {
+    constexpr int P17 = ceil16(NB * T * 17);
+    constexpr int s16 = P17 * 20, s32 = P17 * 36;
+    constexpr int TV = T * 17, COLS = NB * TV;
+    float* const X0 = smem;                   // [P17][20]  in of layers 0, 2 ; out of layer 1
+    float* const Z0 = smem + s16;             // [P17][20]
+    float* const Y0 = smem + 2 * s16;         // [P17][36]  out of layers 0, 2 ; in of layers 1, 3
+    float* const Z1 = smem + 2 * s16 + s32;   // [P17][36]
+    float* const H = smem;                    // [P17][36]  out of layer 3 (over X0/Z0: 36 <= 40)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Prof prof;
+#ifdef MCD_PROFILE
+    prof.on = false; prof.acc = nullptr; prof.tlast = 0;
+#endif
+    for (int u = tid; u < COLS * C0; u += NTHREADS) {
+        const int c = u % C0, col = u / C0;
+        const int n = col / TV, t = (col / 17) % T, v = col % 17;
+        const int b = b0 + n < B ? b0 + n : B - 1;
+        X0[col * 20 + c] = load_coord(dv, b, c, frame_of(t), v, seg_len);
+    }
+    __syncthreads();
+    const float* wb = wbuf;
+    auto lw = [&](int l) {
+        LayerW w;
+        w.tq = tab_i(wb, TABC + l * F_STRIDE + F_TQ); w.am = tab_i(wb, TABC + l * F_STRIDE + F_AM);
+        w.wp = tab_i(wb, TABC + l * F_STRIDE + F_WP); w.bias = tab_i(wb, TABC + l * F_STRIDE + F_BIAS);
+        w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
+        return w;
+    };
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(0), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 2(16) -> 32
+    layer_generic<32, 16, 17, true, false, T, NB>(wb, lw(1), Y0, Z1, X0, nullptr, wave, lane, prof, 0);   // 32 -> 16
+    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(2), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 16 -> 32
+    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(3), Y0, Z1, H, nullptr, wave, lane, prof, 0);   // 32 -> 32
+    // bottleneck Linear: emb[n][j] = b[j] + sum_k W[j][k] H[n][k], k = c*TV + tv.  thread = (n, j, part of 16)
+    constexpr int F = 32 * TV;
+    gfloat* W = as_global(wb + tab_i(wb, TABC + TABC_LW));
+    gfloat* bb = as_global(wb + tab_i(wb, TABC + TABC_LB));
+    for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
+        const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
+        float a = 0.f;
+        for (int k = part; k < F; k += 16) a = fmaf(W[jo * F + k], H[(n * TV + k % TV) * 36 + k / TV], a);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+        if (part == 0) {
+            const float e = a + bb[jo];
+            if (emb_lds) emb_lds[n * EDIM + jo] = e;
+            if (emb_out && b0 + n < B) emb_out[(size_t)(b0 + n) * EDIM + jo] = e;
+        }
+    }
+}
+
+template <int T, int NB>
+__global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbuf, const DataView dv, const FrameIdx fi,
+                                                                int seg_len, float* __restrict__ emb_out, int B) {
+    constexpr int P17 = ceil16(NB * T * 17);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int u = threadIdx.x; u < P17 * (2 * 20 + 2 * 36); u += NTHREADS) smem[u] = 0.f;
+    __syncthreads();
+    cond_fast_body<T, NB>(wbuf, dv, [&](int t) { return fi.idx[t]; }, seg_len, smem, blockIdx.x * NB, B, nullptr, emb_out);
+}
 
 // ------------------------------------------------------------------------------------------------
 // The persistent scoring kernel.  mode 0: full reverse-diffusion trajectories + loss (mcd_score);
@@ -979,14 +1098,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int tid = tid0;
     int lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int chain0 = blockIdx.x * NB;
+    // this workgroup: windows win0 .. win0 + NB - 1, samples part, part + split, ...
+    const int grp = blockIdx.x / P.split, part = blockIdx.x - grp * P.split;
+    const int win0 = grp * NB;
     const int Tx = P.n_corrupt;
+    auto window_of = [&](int n) { const int b = win0 + n; return b < P.B ? b : P.B - 1; };     // (clamped: empty slots recompute the last window)
     if (threadIdx.x < NB) {
-        int chain = chain0 + threadIdx.x;
-        if (chain >= P.n_chains) chain = P.n_chains - 1;
-        WM[threadIdx.x] = P.win_mask ? P.win_mask[chain / P.S] : P.fixed_mask;
-        WM[4 + threadIdx.x] = chain / P.S;
-        WM[8 + threadIdx.x] = chain % P.S;
+        const int b = window_of(threadIdx.x);
+        WM[threadIdx.x] = P.win_mask ? P.win_mask[b] : P.fixed_mask;
+        WM[4 + threadIdx.x] = b;
     }
     // biases the W-first layers add inside their mix store functors: from LDS there, not from global memory (a global
     // load in a functor that also stores to LDS is re-issued per call: one L2 round trip per output row)
@@ -995,9 +1115,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // for 'concat' with the condition at the END of the window, where the reference reads the prediction at the corrupt
         // frames' ORIGINAL indices, mocodad.py:829-838); with per-window frame sets (random_imp) every clear bit updates itself
         const int i = threadIdx.x - 128, n = i / T, t = i % T;
-        int chain = chain0 + n;
-        if (chain >= P.n_chains) chain = P.n_chains - 1;
-        const int fixed = P.win_mask ? P.win_mask[chain / P.S] : P.fixed_mask;
+        const int fixed = P.win_mask ? P.win_mask[window_of(n)] : P.fixed_mask;
         const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
         UPD[i] = k < 0 ? -1 : (n * T + (P.win_mask ? t : P.pos_of[k])) * 17;
     }
@@ -1005,6 +1123,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     // T*17 cost ~35 VALU instructions per thread and pass when done in place)
     static_assert(NB <= 4 && T <= 16 && NB * T <= 16, "tail index packing: 4 bits (chain, frame) | 2 bits chain | 4 bits frame");
     int* const TT = reinterpret_cast<int*>(ZO + PL::ZO);
+    float* const CE = reinterpret_cast<float*>(TT + PL::TT);
+    float* const LOSSB = CE + PL::CE;
     for (int u = threadIdx.x; u < COLS17 * C0; u += NTHREADS) {
         const int col = u / C0, n = col / TV17, t = (col / 17) % T, v = col % 17;
         TT[u] = (n * T + t) | (n << 4) | (t << 6) | (v << 10);
@@ -1014,38 +1134,23 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     const int CTV = C0 * Tx * 17;          // elements of one generated pose
     const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
 
+    // ---- condition embeddings of the workgroup's windows -> CE[n][16]: computed right here with the condition encoder's
+    //      MFMA stages (the shipped architecture at T condition frames), or read from the caller's (B,16) tensor
+    if (P.cond_inkernel) {
+        for (int u = tid; u < PL::R; u += NTHREADS) smem[u] = 0.f;
+        __syncthreads();
+        cond_fast_body<T, NB>(P.wbuf, P.dv, [&](int t) { return P.cond_idx[t]; }, P.seg_len, smem, win0, P.B, CE, nullptr);
+        __syncthreads();
+    } else if (threadIdx.x < NB * EDIM) {
+        CE[threadIdx.x] = P.cond_emb ? P.cond_emb[(size_t)window_of(threadIdx.x / EDIM) * EDIM + threadIdx.x % EDIM] : 0.f;
+    }
     // zero the whole activation area once: pad columns / pad channels must hold finite values
     for (int u = tid; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
     __syncthreads();
 
-    // ---- x_T (or the given x in single-pass mode) -> XT[col] = (x0, x1, z0, z1)
-    for (int u = tid; u < COLS17; u += NTHREADS) {
-        const int n = u / TV17, t = (u / 17) % T, v = u % 17;
-        int chain = chain0 + n;
-        if (chain >= P.n_chains) chain = P.n_chains - 1;
-        const int b = chain / P.S, s = chain % P.S;
-        const int fixed = WM[n];
-        float xv[C0];
-#pragma unroll
-        for (int c = 0; c < C0; ++c) {
-            if (P.mode == 1) {
-                xv[c] = P.x_in ? P.x_in[((b * C0 + c) * T + t) * 17 + v] : 0.f;
-            } else if ((fixed >> t) & 1) {
-                xv[c] = load_coord(P.dv, b, c, fm_src(P, t), v, P.seg_len);
-            } else {
-                const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
-                if (P.noise) xv[c] = P.noise[((size_t)(s * K + 0) * P.B + b) * CTV + e];
-                else xv[c] = philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
-            }
-        }
-        XT[u * 4 + 0] = xv[0];
-        XT[u * 4 + 1] = xv[1];
-    }
-    __syncthreads();
-
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.acc = reinterpret_cast<unsigned*>(ZO + PL::ZO + PL::TT);
+    prof.acc = reinterpret_cast<unsigned*>(LOSSB + PL::LOSS);
     if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
@@ -1056,8 +1161,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 __syncthreads();
                 for (int u = threadIdx.x; u < NB * C * T * V; u += NTHREADS) {
                     const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % C, n = u / (V * T * C);
-                    int b = chain0 + n;
-                    if (b >= P.n_chains) b = P.n_chains - 1;
+                    const int b = window_of(n);
                     region[((n * T + t) * V + v) * cs + c] = P.lt_in[(((size_t)b * C + c) * T + t) * V + v];
                 }
                 __syncthreads();
@@ -1070,8 +1174,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 __syncthreads();
                 for (int u = threadIdx.x; u < NB * C * T * V; u += NTHREADS) {
                     const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % C, n = u / (V * T * C);
-                    const int b = chain0 + n;
-                    if (b < P.n_chains) P.lt_out[(((size_t)b * C + c) * T + t) * V + v] = region[((n * T + t) * V + v) * cs + c];
+                    const int b = win0 + n;
+                    if (b < P.B) P.lt_out[(((size_t)b * C + c) * T + t) * V + v] = region[((n * T + t) * V + v) * cs + c];
                 }
                 __syncthreads();
             }
@@ -1088,21 +1192,58 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     // embeddings of the first pass; those of pass i-1 are computed during the last layer of pass i
     auto silu_row = [&](int step, int t_id) {      // SEN[n][k] = SiLU(pe(step)[k] + cond[window of chain n][k])
         if (t_id >= 0 && t_id < NB * EDIM) {
-            const int n = t_id / EDIM, k = t_id % EDIM;
-            int chain = chain0 + n;
-            if (chain >= P.n_chains) chain = P.n_chains - 1;
-            float e = P.step_table[step * (4 + EDIM) + 4 + k];
-            if (P.cond_emb) e += P.cond_emb[(chain / P.S) * EDIM + k];
+            const float e = P.step_table[step * (4 + EDIM) + 4 + (t_id % EDIM)] + CE[t_id];
             SEN[t_id] = e / (1.f + expf(-e));
         }
     };
+    // ================= the samples of this workgroup's windows, one trajectory after the other =================
+    for (int s = part; s < P.S; s += P.split) {
+    // The parameters the per-sample prologue / epilogue need are read through a pointer to the kernarg segment that is
+    // opaque per sample, and the thread id likewise: otherwise their (loop-invariant) scalar loads and per-lane addresses are
+    // hoisted above this loop and stay live -- in SGPRs / VGPRs the step loop has none to spare of -- across every pass.
+    typedef const ScoreParams __attribute__((address_space(4))) KScoreParams;
+    KScoreParams* Q = (KScoreParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Q));
+    int tid_s = tid0;
+    asm volatile("" : "+v"(tid_s));
+    // ---- x_T (or the given x in single-pass mode) -> XT[col] = (x0, x1, z0, z1)
+    {
+        DataView dv;
+        dv.data = Q->dv.data; dv.base = Q->dv.base; dv.sc = Q->dv.sc; dv.st = Q->dv.st; dv.trans = Q->dv.trans; dv.aff = Q->dv.aff;
+        const float* noise = Q->noise;
+        const float* x_in = Q->x_in;
+        const int mode = Q->mode, seg_len = Q->seg_len, Bq = Q->B;
+        const unsigned long long seed = Q->seed;
+        const long long first_window = Q->first_window;
+        for (int u = tid_s; u < COLS17; u += NTHREADS) {
+            const int n = u / TV17, t = (u / 17) % T, v = u % 17;
+            const int b = WM[4 + n];
+            const int fixed = WM[n];
+            float xv[C0];
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+                if (mode == 1) {
+                    xv[c] = x_in ? x_in[((b * C0 + c) * T + t) * 17 + v] : 0.f;
+                } else if ((fixed >> t) & 1) {
+                    xv[c] = load_coord(dv, b, c, fm_src(P, t), v, seg_len);
+                } else {
+                    const int e = (c * Tx + fm_tx(P, fixed, t)) * 17 + v;
+                    if (noise) xv[c] = noise[((size_t)(s * K + 0) * Bq + b) * CTV + e];
+                    else xv[c] = philox_normal(seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(first_window + b));
+                }
+            }
+            XT[u * 4 + 0] = xv[0];
+            XT[u * 4 + 1] = xv[1];
+        }
+    }
+    __syncthreads();
     {
         EmbRow er, er2;
-        er.load(P.wbuf, tid0);
-        er2.load(P.wbuf, emb_row2(tid0));
-        silu_row(i_first, tid0);
+        er.load(P.wbuf, tid_s);
+        er2.load(P.wbuf, emb_row2(tid_s));
+        silu_row(i_first, tid_s);
         __syncthreads();
-        emb_compute<NB>(er, er2, SEN, EMB, E10 + (i_first & 1) * 16, tid0);
+        emb_compute<NB>(er, er2, SEN, EMB, E10 + (i_first & 1) * 16, tid_s);
         __syncthreads();
     }
     LMix<0, T, NB> mc0;                              // layer 0's mix coefficients: fetched one stage ahead like all the others,
@@ -1134,7 +1275,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
                 const int fixed = WM[n];
                 if (!((fixed >> t) & 1)) {
-                    const int b = WM[4 + n], s = WM[8 + n];
+                    const int b = WM[4 + n];
                     const int tx = fm_tx(P, fixed, t);
                     const int k = P.ns - sidx;
                     if (P.noise) {
@@ -1385,12 +1526,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     const float l10 = prelu(ZO[u] + Pb[col * 20 + C0 + c] + BIA[64 + c], slope10) + E10[e10_off + n * 4 + c];
                     const float eps = l10 + x;
                     if constexpr (LT) {      // layer 10 alone: without the U-Net's residual (+ x)
-                        const int chain = chain0 + n;
-                        if (P.lt_stage == 10 && chain < P.n_chains) P.lt_out[(((size_t)chain * C0 + c) * T + t) * 17 + v] = l10;
+                        const int b = win0 + n;
+                        if (P.lt_stage == 10 && b < P.B) P.lt_out[(((size_t)b * C0 + c) * T + t) * 17 + v] = l10;
                     }
                     if (single) {
-                        const int chain = chain0 + n;
-                        if (chain < P.n_chains && P.eps_out) P.eps_out[(((chain / P.S) * C0 + c) * T + t) * 17 + v] = eps;
+                        const int b = win0 + n;
+                        if (b < P.B && P.eps_out) P.eps_out[(((size_t)b * C0 + c) * T + t) * 17 + v] = eps;
                     } else {
                         const int cbase = UPD[tt & 15];
                         if (cbase >= 0) {
@@ -1412,111 +1553,65 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(17);
         }
     }
-#ifdef MCD_PROFILE
-    if (prof.on) for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];    // thread 0's own ds_adds: in order
-#endif
-    if (P.mode == 1) return;
+    if (P.mode == 1) break;
 
     // ---- per-chain loss: mean over (C, Tx, V) of loss_fn(x_0 - corrupt)   (mocodad.py:484)
     float* RED = RG;
     const int per = CTV;
-    for (int u = tid; u < NB * per; u += NTHREADS) {
-        const int n = u / per, e = u % per;
-        const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
-        int chain = chain0 + n;
-        const bool valid = chain < P.n_chains;
-        if (!valid) chain = P.n_chains - 1;
-        const int b = chain / P.S, s = chain % P.S;
-        int tu = P.pos_of[tx];
-        if (P.win_mask) {                       // frame of the tx-th corrupt frame = tx-th clear bit of the window's mask
-            const int fixed = WM[n];
-            int cnt = 0;
-            for (int t = 0; t < T; ++t)
-                if (!((fixed >> t) & 1)) { if (cnt == tx) tu = t; ++cnt; }
+    {
+        asm volatile("" : "+s"(Q));
+        tid_s = tid0;
+        asm volatile("" : "+v"(tid_s));
+        DataView dv;
+        dv.data = Q->dv.data; dv.base = Q->dv.base; dv.sc = Q->dv.sc; dv.st = Q->dv.st; dv.trans = Q->dv.trans; dv.aff = Q->dv.aff;
+        const int seg_len = Q->seg_len, Bq = Q->B, Sq = Q->S, loss_fn = Q->loss_fn;
+        float* pose_out = Q->pose_out;
+        float* loss_out = Q->loss_out;
+        const bool wmask = Q->win_mask != nullptr;
+        for (int u = tid_s; u < NB * per; u += NTHREADS) {
+            const int n = u / per, e = u % per;
+            const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
+            const bool valid = win0 + n < Bq;
+            const int b = WM[4 + n];
+            int tu = P.pos_of[tx];
+            if (wmask) {                       // frame of the tx-th corrupt frame = tx-th clear bit of the window's mask
+                const int fixed = WM[n];
+                int cnt = 0;
+                for (int t = 0; t < T; ++t)
+                    if (!((fixed >> t) & 1)) { if (cnt == tx) tu = t; ++cnt; }
+            }
+            const float x0 = XT[((n * T + tu) * 17 + v) * 4 + c];
+            const float gt = load_coord(dv, b, c, fm_src(P, tu), v, seg_len);
+            const float d = fabsf(x0 - gt);
+            float l;
+            if (loss_fn == MCD_LOSS_SMOOTH_L1) l = d < 1.f ? 0.5f * d * d : d - 0.5f;
+            else if (loss_fn == MCD_LOSS_L1) l = d;
+            else l = d * d;
+            RED[u] = l;
+            if (valid && pose_out) pose_out[(size_t)(b * Sq + s) * per + e] = x0;
         }
-        const float x0 = XT[((n * T + tu) * 17 + v) * 4 + c];
-        const float gt = load_coord(P.dv, b, c, fm_src(P, tu), v, P.seg_len);
-        const float d = fabsf(x0 - gt);
-        float l;
-        if (P.loss_fn == MCD_LOSS_SMOOTH_L1) l = d < 1.f ? 0.5f * d * d : d - 0.5f;
-        else if (P.loss_fn == MCD_LOSS_L1) l = d;
-        else l = d * d;
-        RED[u] = l;
-        if (valid && P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
-    }
-    __syncthreads();
-    if (wave < NB) {
-        float sum = 0.f;
-        for (int e = lane; e < per; e += 64) sum += RED[wave * per + e];
+        __syncthreads();
+        if (tid_s < NB * 64) {
+            const int n = tid_s >> 6, ln = tid_s & 63;
+            float sum = 0.f;
+            for (int e = ln; e < per; e += 64) sum += RED[n * per + e];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-        const int chain = chain0 + wave;
-        if (lane == 0 && chain < P.n_chains) P.loss_out[chain] = sum / (float)per;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+            if (ln == 0) {
+                const float l = sum / (float)per;
+                if (win0 + n < Bq && loss_out) loss_out[(size_t)(win0 + n) * Sq + s] = l;
+                if (s < 64) LOSSB[n * 64 + s] = l;
+            }
+        }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// condition encoder, fast path for the shipped architecture (channels [32,16,32] + h_dim 32, latent 16):
-// the same MFMA mix / GEMM stages as the U-Net, NB windows per 512-thread workgroup, followed by the
-// bottleneck Linear over the (c,t,v) flattening (stsae.py:73-89).  Reads the condition frames straight from the
-// window tensor (no gather pass).  Other channel lists use cond_encode_kernel below.
-// ------------------------------------------------------------------------------------------------
-constexpr int TABC = 128;                  // cond table: second 128 words of the weight buffer
-constexpr int TABC_LW = 40, TABC_LB = 41;  // bottleneck Linear weight [16][32*T*17] / bias
-struct FrameIdx { int idx[MCD_MAX_FRAMES]; };
-
-template <int T, int NB>
-__global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbuf, const DataView dv, const FrameIdx fi,
-                                                                int seg_len, float* __restrict__ emb_out, int B) {
-    constexpr int P17 = ceil16(NB * T * 17);
-    constexpr int s16 = P17 * 20, s32 = P17 * 36;
-    constexpr int TV = T * 17, COLS = NB * TV;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const X0 = smem;                   // [P17][20]  in of layers 0, 2 ; out of layer 1
-    float* const Z0 = smem + s16;             // [P17][20]
-    float* const Y0 = smem + 2 * s16;         // [P17][36]  out of layers 0, 2 ; in of layers 1, 3
-    float* const Z1 = smem + 2 * s16 + s32;   // [P17][36]
-    float* const H = smem;                    // [P17][36]  out of layer 3 (over X0/Z0: 36 <= 40)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = blockIdx.x * NB;
-    Prof prof;
+    __syncthreads();        // RED (the work region) and XT are rewritten by the next sample
+    }   // samples
 #ifdef MCD_PROFILE
-    prof.on = false; prof.acc = nullptr; prof.tlast = 0;
+    if (prof.on) for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];    // thread 0's own ds_adds: in order
 #endif
-    for (int u = tid; u < 2 * s16 + 2 * s32; u += NTHREADS) smem[u] = 0.f;
-    __syncthreads();
-    for (int u = tid; u < COLS * C0; u += NTHREADS) {
-        const int c = u % C0, col = u / C0;
-        const int n = col / TV, t = (col / 17) % T, v = col % 17;
-        const int b = b0 + n < B ? b0 + n : B - 1;
-        X0[col * 20 + c] = load_coord(dv, b, c, fi.idx[t], v, seg_len);
-    }
-    __syncthreads();
-    const float* wb = wbuf;
-    auto lw = [&](int l) {
-        LayerW w;
-        w.tq = tab_i(wb, TABC + l * F_STRIDE + F_TQ); w.am = tab_i(wb, TABC + l * F_STRIDE + F_AM);
-        w.wp = tab_i(wb, TABC + l * F_STRIDE + F_WP); w.bias = tab_i(wb, TABC + l * F_STRIDE + F_BIAS);
-        w.slope = tab_f(wb, TABC + l * F_STRIDE + F_SLOPE);
-        return w;
-    };
-    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(0), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 2(16) -> 32
-    layer_generic<32, 16, 17, true, false, T, NB>(wb, lw(1), Y0, Z1, X0, nullptr, wave, lane, prof, 0);   // 32 -> 16
-    layer_generic<16, 32, 17, true, false, T, NB>(wb, lw(2), X0, Z0, Y0, nullptr, wave, lane, prof, 0);   // 16 -> 32
-    layer_generic<32, 32, 17, false, false, T, NB>(wb, lw(3), Y0, Z1, H, nullptr, wave, lane, prof, 0);   // 32 -> 32
-    // bottleneck Linear: emb[n][j] = b[j] + sum_k W[j][k] H[n][k], k = c*TV + tv.  thread = (n, j, part of 16)
-    constexpr int F = 32 * TV;
-    gfloat* W = as_global(wb + tab_i(wb, TABC + TABC_LW));
-    gfloat* bb = as_global(wb + tab_i(wb, TABC + TABC_LB));
-    for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
-        const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
-        float a = 0.f;
-        for (int k = part; k < F; k += 16) a = fmaf(W[jo * F + k], H[(n * TV + k % TV) * 36 + k / TV], a);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
-        if (part == 0 && b0 + n < B) emb_out[(size_t)(b0 + n) * EDIM + jo] = a + bb[jo];
-    }
+    // ---- aggregation over the samples (mocodad.py:454-520; loss-based strategies), when this workgroup has seen them all
+    if (P.mode == 0 && P.loss_agg && tid0 < NB && win0 + tid0 < P.B)
+        P.loss_agg[win0 + tid0] = aggregate_losses(LOSSB + tid0 * 64, P.S, P.aggr, P.aggr_q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2290,42 +2385,78 @@ int ensure_lds_limit(const void* fn, size_t bytes, std::atomic<unsigned long lon
 #define LDS_LIMIT(kernel_expr, bytes) do { static std::atomic<unsigned long long> done_{0}; \
     int rc_ = ensure_lds_limit(reinterpret_cast<const void*>(kernel_expr), (bytes), done_); if (rc_ != MCD_OK) return rc_; } while (0)
 
+// Workgroup slots of the device for a kernel (resident workgroups per CU x CUs), asked once per (kernel, device).
+int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NTHREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    v = per_cu * cus;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+// How a scoring call is cut into workgroups.  A workgroup owns NB windows and runs `units` = S / split of their samples in
+// sequence.  split = 1 (window-major) lets the condition encoder and the aggregation run inside the workgroup -- one launch
+// per call -- and is taken when it fills the device's workgroup slots at least as well as split = S (chain-major: one
+// trajectory per workgroup); `fill` = useful slot-time / occupied slot-time for in-order dispatch of equal units.
+int choose_split(int n_groups, int S, int slots) {
+    auto fill = [&](long long wgs, int units) {
+        const long long rounds = (wgs + slots - 1) / slots;
+        return (double)(wgs * units) / ((double)rounds * slots * units);
+    };
+    return fill(n_groups, S) + 1e-9 >= fill((long long)n_groups * S, 1) ? 1 : S;
+}
+
 template <int T, int NB, int MINW, bool BF3 = false, bool LT = false>
-int launch_score_t(const ScoreParams& P, hipStream_t st) {
+int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
     using PL = Plan<T, NB>;
     LDS_LIMIT((&score_kernel<T, NB, MINW, BF3, LT>), PL::BYTES);
-    const int nblocks = (P.n_chains + NB - 1) / NB;
-    hipLaunchKernelGGL((score_kernel<T, NB, MINW, BF3, LT>), dim3(nblocks), dim3(NTHREADS), PL::BYTES, st, P);
+    static std::atomic<int> slots_cache[64];
+    const int groups = (P.B + NB - 1) / NB;
+    const int slots = wg_slots(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW, BF3, LT>), PL::BYTES, slots_cache);
+    P.split = P.mode == 0 ? choose_split(groups, P.S, slots) : 1;
+    if (P.force_split > 0) P.split = P.force_split < P.S ? P.force_split : P.S;
+    // the in-kernel condition encoder / aggregation need the workgroup to see all samples of its windows (and S <= 64)
+    const bool whole = P.split == 1 && P.mode == 0;
+    if (!(whole && P.S <= 64)) P.loss_agg = nullptr;
+    if (fused) *fused = P.loss_agg != nullptr;
+    if (P.loss_agg && P.loss_out_optional) P.loss_out = nullptr;
+    if (P.mode == 0 && !P.loss_agg && !P.loss_out) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes): per-sample losses of an unfused aggregation");
+    hipLaunchKernelGGL((score_kernel<T, NB, MINW, BF3, LT>), dim3(groups * P.split), dim3(NTHREADS), PL::BYTES, st, P);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
 
-int launch_score(const mcd_weights* w, int T, const ScoreParams& P, hipStream_t st) {
+int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bool* fused = nullptr) {
+    P.force_split = w->opt[MCD_OPT_SPLIT];
     const int variant = w->opt[MCD_OPT_VARIANT];          // tuning experiments only
     // opt-in split-bf16 channel GEMMs (layers 2..9) for 3, 6 and 12 U-Net frames (see gemm_tiles_bf3); everything measured and
     // reported by bench.py uses the fp32 path
     const bool bf3 = w->opt[MCD_OPT_BF16X3] != 0;
 #ifdef MCD_FAST_T6      // developer builds: one instantiation
-    return launch_score_t<6, 1, 4>(P, st);
+    return launch_score_t<6, 1, 4>(P, st, fused);
 #elif defined(MCD_FAST_BUILD)   // developer builds: only the two default-shape instantiations
-    if (T == 3 && bf3) return launch_score_t<3, 2, 4, true>(P, st);
-    if (T == 3) return variant == 2 ? launch_score_t<3, 2, 2>(P, st) : launch_score_t<3, 2, 4>(P, st);
+    if (T == 3 && bf3) return launch_score_t<3, 2, 4, true>(P, st, fused);
+    if (T == 3) return variant == 2 ? launch_score_t<3, 2, 2>(P, st, fused) : launch_score_t<3, 2, 4>(P, st, fused);
     return fail(MCD_EUNSUPPORTED, "fast build");
 #else
     switch (T) {
         case 3:
-            if (bf3) return launch_score_t<3, 2, 4, true>(P, st);
-            if (variant == 0) return launch_score_t<3, 2, 4>(P, st);   // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
-            if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st);   // 4 chains / WG, 1 WG per CU
-            if (variant == 3) return launch_score_t<3, 1, 4>(P, st);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
-            return launch_score_t<3, 2, 2>(P, st);
+            if (bf3) return launch_score_t<3, 2, 4, true>(P, st, fused);
+            if (variant == 0) return launch_score_t<3, 2, 4>(P, st, fused);   // default: 2 chains / WG, 2 WGs per CU (<=128 VGPR)
+            if (variant == 1) return launch_score_t<3, 4, (NWAVES == 16 ? 4 : 2)>(P, st, fused);   // 4 chains / WG, 1 WG per CU
+            if (variant == 3) return launch_score_t<3, 1, 4>(P, st, fused);   // 1 chain / WG (tuning experiment with MCD_NWAVES=4)
+            return launch_score_t<3, 2, 2>(P, st, fused);
         case 6:
-            if (bf3) return launch_score_t<6, 1, 4, true>(P, st);
-            if (variant == 1) return launch_score_t<6, 2, 2>(P, st);   // 2 chains / WG, 1 WG per CU (no register cap)
-            return launch_score_t<6, 1, 4>(P, st);                     // 1 chain / WG, 2 WGs per CU
-        case 12: return bf3 ? launch_score_t<12, 1, 2, true>(P, st) : launch_score_t<12, 1, 2>(P, st);
-        case 4: return launch_score_t<4, 1, 4>(P, st);                 // e.g. seg_len 8 split in halves
-        case 8: return launch_score_t<8, 1, 2>(P, st);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
+            if (bf3) return launch_score_t<6, 1, 4, true>(P, st, fused);
+            if (variant == 1) return launch_score_t<6, 2, 2>(P, st, fused);   // 2 chains / WG, 1 WG per CU (no register cap)
+            return launch_score_t<6, 1, 4>(P, st, fused);                     // 1 chain / WG, 2 WGs per CU
+        case 12: return bf3 ? launch_score_t<12, 1, 2, true>(P, st, fused) : launch_score_t<12, 1, 2>(P, st, fused);
+        case 4: return launch_score_t<4, 1, 4>(P, st, fused);                 // e.g. seg_len 8 split in halves
+        case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 6, 8, 12)");
     }
 #endif
@@ -2749,8 +2880,8 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
     return fail(MCD_EUNSUPPORTED, "fast build");
 #else
     switch (w->cfg.t_unet) {
-        case 3: return launch_score_t<3, 2, 4, false, true>(P, (hipStream_t)stream);
-        case 6: return launch_score_t<6, 1, 4, false, true>(P, (hipStream_t)stream);
+        case 3: return launch_score_t<3, 2, 4, false, true>(P, (hipStream_t)stream, nullptr);
+        case 6: return launch_score_t<6, 1, 4, false, true>(P, (hipStream_t)stream, nullptr);
         default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3 and 6 U-Net frames (the fixtures' shapes)");
     }
 #endif
@@ -2794,6 +2925,7 @@ int mcd_philox_noise(uint64_t seed, int64_t first_window_id, int32_t n_windows, 
     return MCD_OK;
 }
 
+static int64_t ws_loss_bytes(int64_t B, int64_t S) { return (B * S * 4 + 255) / 256 * 256; }
 static int64_t ws_cond_bytes(const mcd_weights* w, int64_t B) {
     const int64_t raw = B * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
     return (raw + 255) / 256 * 256;
@@ -2805,7 +2937,7 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
     int64_t gen = 0;
     if (!w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET]) gen = gen_scratch_bytes((int64_t)cfg->n_windows * cfg->n_samples, w->cfg.t_unet);
     if (w->cond_unet) { const int64_t g2 = gen_scratch_bytes(cfg->n_windows, w->cond.Tc); if (g2 > gen) gen = g2; }
-    return ws_cond_bytes(w, cfg->n_windows) + gen;
+    return ws_cond_bytes(w, cfg->n_windows) + ws_loss_bytes(cfg->n_windows, cfg->n_samples) + gen;
 }
 
 __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out, int B, int C, int T, int V, int n,
@@ -2816,19 +2948,29 @@ __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out,
     out[u] = load_coord(dv, b, c, fi.idx[k], v, T);
 }
 
-int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise, uint64_t seed,
-              int64_t first_window_id, const float* step_table, void* workspace, float* loss_out, float* pose_out,
-              void* stream) {
-    return mcd_score_view(w, cfg, data, nullptr, noise, seed, first_window_id, step_table, workspace, loss_out, pose_out, stream);
+static int launch_aggregate(const AggrParams& A, hipStream_t st) {
+    hipLaunchKernelGGL(aggregate_kernel, dim3((A.B + 63) / 64), dim3(64), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
 }
 
-int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
-                   const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
-                   float* loss_out, float* pose_out, void* stream) {
+// One scoring call.  aggr = 0: per-sample losses only (loss_all required).  aggr = a loss-based MCD_AGGR_* strategy: loss_agg
+// (B,) is produced too -- inside the trajectory kernel when its workgroups see all samples of their windows (one launch per
+// call), by aggregate_kernel otherwise.
+static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
+                      const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+                      int aggr, float quantile, float* loss_agg, float* loss_all, float* pose_out, void* stream) {
     if (!w || !cfg) return fail(MCD_EINVAL, "null argument");
     const int B = cfg->n_windows, S = cfg->n_samples;
     if (B <= 0) return MCD_OK;
-    if (!data || !step_table || !loss_out) return fail(MCD_EINVAL, "null argument");
+    if (!data || !step_table) return fail(MCD_EINVAL, "null argument");
+    if (aggr == 0 && !loss_all) return fail(MCD_EINVAL, "null argument");
+    if (aggr != 0) {
+        if (!loss_agg) return fail(MCD_EINVAL, "null argument");
+        if (aggr != MCD_AGGR_BEST && aggr != MCD_AGGR_WORST && aggr != MCD_AGGR_MEAN && aggr != MCD_AGGR_MEDIAN && aggr != MCD_AGGR_QUANTILE)
+            return fail(MCD_EINVAL, "mcd_score_fused aggregates losses (best, worst, mean, median, quantile); the *_pose strategies go through mcd_score + mcd_aggregate");
+        if (S > 64) return fail(MCD_EUNSUPPORTED, "aggregation supports n_generated_samples <= 64");
+    }
     if (S < 1 || cfg->noise_steps < 2) return fail(MCD_EINVAL, "need n_samples >= 1 and noise_steps >= 2");
     if (cfg->n_corrupt < 1 || cfg->n_cond + cfg->n_corrupt != cfg->seg_len || cfg->seg_len > MCD_MAX_FRAMES)
         return fail(MCD_EINVAL, "cond/corrupt index lists do not partition seg_len");
@@ -2851,10 +2993,12 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
         P.dv.trans = view->trans; P.dv.aff = view->affine;
         if (rnd) P.win_mask = view->cond_mask;
         if (!view->base) { P.dv.sc = (long long)cfg->seg_len * 17; P.dv.st = 17; }
-    } P.noise = noise; P.step_table = step_table; P.loss_out = loss_out; P.pose_out = pose_out;
+    }
+    P.noise = noise; P.step_table = step_table; P.pose_out = pose_out;
     P.seed = seed; P.first_window = first_window_id;
     P.B = B; P.S = S; P.ns = cfg->noise_steps; P.seg_len = cfg->seg_len; P.n_corrupt = cfg->n_corrupt;
-    P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S;
+    P.loss_fn = cfg->loss_fn; P.mode = 0; P.n_chains = B * S; P.split = 1;
+    P.aggr = aggr; P.aggr_q = quantile; P.loss_agg = aggr ? loss_agg : nullptr;
     // U-Net frame layout: concat = condition frames first (mocodad.py:668), imputation = natural frame order
     // (mocodad.py:672-683), inject / no_condition = the corrupt frames only
     FrameMaps M;
@@ -2882,15 +3026,36 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
     for (int t = 0; t < 12; ++t) {      // the specialised kernels (<= 12 frames) carry the maps in their parameter block
         P.src_frame[t] = M.src_frame[t]; P.tx_of[t] = M.tx_of[t]; P.pos_of[t] = M.pos_of[t]; P.upd_of[t] = M.upd_of[t];
     }
-    // workspace: [condition embeddings | gathered condition frames][scratch slabs of the runtime-shape kernels]
-    float* gen_scratch = workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ws_cond_bytes(w, B)) : nullptr;
+    // workspace: [condition embeddings | gathered condition frames][per-sample losses (B,S)][scratch slabs of the runtime-shape kernels]
+    char* wsb = reinterpret_cast<char*>(workspace);
+    float* ws_loss = wsb ? reinterpret_cast<float*>(wsb + ws_cond_bytes(w, B)) : nullptr;
+    float* gen_scratch = wsb ? reinterpret_cast<float*>(wsb + ws_cond_bytes(w, B) + ws_loss_bytes(B, S)) : nullptr;
+    P.loss_out = loss_all ? loss_all : ws_loss;       // (skipped by a fused launch when the caller did not ask for it)
     auto score = [&]() -> int {
-        if (!generic) return launch_score(w, Tu, P, st);
-        if (!workspace) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape kernel");
-        return launch_score_generic(w, P, M, gen_scratch, st);
+        bool fused = false;
+        int rc;
+        if (!generic) {
+            P.loss_out_optional = loss_all == nullptr;
+            rc = launch_score(w, Tu, P, st, &fused);
+        } else {
+            if (!workspace) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape kernel");
+            rc = launch_score_generic(w, P, M, gen_scratch, st);
+        }
+        if (rc != MCD_OK || aggr == 0 || fused) return rc;
+        AggrParams A;        // the workgroups did not see all samples of their windows: aggregate the (B,S) losses afterwards
+        memset(&A, 0, sizeof(A));
+        A.loss_all = P.loss_out; A.loss_agg = loss_agg; A.B = B; A.S = S; A.C = C0; A.Tx = cfg->n_corrupt; A.V = 17;
+        A.seg_len = cfg->seg_len; A.strategy = aggr; A.loss_fn = cfg->loss_fn; A.q = quantile;
+        return launch_aggregate(A, st);
     };
     if (strat == MCD_STRATEGY_INJECT) {
-        if (!workspace) return fail(MCD_EINVAL, "workspace required for the inject strategy");
+        // the shipped encoder with as many condition frames as the U-Net has frames runs inside the trajectory kernel
+        if (!generic && w->cond_fast && !w->opt[MCD_OPT_COND_GENERIC] && cfg->n_cond == Tu && Tu <= 12) {
+            P.cond_inkernel = 1;
+            for (int k = 0; k < Tu; ++k) P.cond_idx[k] = cfg->cond_idx[k];
+            return score();
+        }
+        if (!workspace) return fail(MCD_EINVAL, "workspace required for this condition encoder");
         float* emb = reinterpret_cast<float*>(workspace);
         float* cbuf = emb + (size_t)B * EDIM + 16;
         const int Tc = cfg->n_cond;
@@ -2915,6 +3080,26 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
     return score();
 }
 
+int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise, uint64_t seed,
+              int64_t first_window_id, const float* step_table, void* workspace, float* loss_out, float* pose_out,
+              void* stream) {
+    return score_impl(w, cfg, data, nullptr, noise, seed, first_window_id, step_table, workspace, 0, 0.f, nullptr, loss_out, pose_out, stream);
+}
+
+int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
+                   const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+                   float* loss_out, float* pose_out, void* stream) {
+    return score_impl(w, cfg, data, view, noise, seed, first_window_id, step_table, workspace, 0, 0.f, nullptr, loss_out, pose_out, stream);
+}
+
+int mcd_score_fused(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
+                    const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
+                    int32_t aggregation, float quantile, float* loss_agg, float* loss_all, float* pose_out, void* stream) {
+    if (aggregation == MCD_AGGR_ALL) return fail(MCD_EINVAL, "MCD_AGGR_ALL is mcd_score");
+    return score_impl(w, cfg, data, view, noise, seed, first_window_id, step_table, workspace, aggregation, quantile, loss_agg, loss_all,
+                      pose_out, stream);
+}
+
 int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,
                   const float* loss_all, const float* pose_all, const float* data, float* loss_agg, float* pose_agg,
                   void* stream) {
@@ -2933,9 +3118,7 @@ int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_join
     P.B = cfg->n_windows; P.S = cfg->n_samples; P.C = num_coords; P.Tx = cfg->n_corrupt; P.V = n_joints;
     P.seg_len = cfg->seg_len; P.strategy = strategy; P.loss_fn = cfg->loss_fn; P.q = quantile;
     for (int t = 0; t < cfg->n_corrupt && t < MCD_MAX_FRAMES; ++t) P.corrupt_idx[t] = cfg->corrupt_idx[t];
-    hipLaunchKernelGGL(aggregate_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
-    HIP_TRY(hipGetLastError());
-    return MCD_OK;
+    return launch_aggregate(P, (hipStream_t)stream);
 }
 
 int mcd_scatter_max(const float* scores, const int32_t* frames, const int32_t* row, int64_t n, int32_t seg_len,

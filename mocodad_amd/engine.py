@@ -150,6 +150,21 @@ class HipScorer:
         buffers, test-time transform applied on load) -> (loss (B,S), poses (B,S,C,Tx,V) | None).
         cond_mask (random_imp only): (B,) int32, bit t set = frame t of the window conditions.
         Asynchronous on the current stream."""
+        _, loss, poses = self._score(data, n_samples, noise_steps, noise, seed, first_window_id, loss_fn, want_poses, cond_mask,
+                                     aggregation=None, want_all=True, out=None)
+        return loss, poses
+
+    def score_fused(self, data, *, n_samples: int, noise_steps: int, aggregation: str = "best", noise: Optional[torch.Tensor] = None,
+                    seed: int = 0, first_window_id: int = 0, loss_fn: str = "smooth_l1", want_all: bool = False, want_poses: bool = False,
+                    cond_mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        """`score` + the loss-based aggregation over the samples ('best' | 'worst' | 'mean' | 'median' | 'quantile:q') in one
+        call -- one kernel launch whenever the workgroups own whole windows (mcd_score_fused).
+        -> (aggregated loss (B,), loss (B,S) | None, poses | None).  out: optional preallocated (B,) result."""
+        return self._score(data, n_samples, noise_steps, noise, seed, first_window_id, loss_fn, want_poses, cond_mask,
+                           aggregation=aggregation, want_all=want_all, out=out)
+
+    def _score(self, data, n_samples, noise_steps, noise, seed, first_window_id, loss_fn, want_poses, cond_mask, *, aggregation,
+               want_all, out):
         view = None
         keep = None
         if (cond_mask is not None) != (self.strategy == "random_imp"):
@@ -178,24 +193,40 @@ class HipScorer:
         S = int(n_samples)
         Tx = len(self.corrupt_idx)
         cfg = self._score_cfg(B, S, int(noise_steps), loss_fn)
-        loss = torch.empty(B, S, device=self.device, dtype=torch.float32)
+        loss = torch.empty(B, S, device=self.device, dtype=torch.float32) if want_all else None
         poses = torch.empty(B, S, self.num_coords, Tx, self.n_joints, device=self.device, dtype=torch.float32) if want_poses else None
         if noise is not None:
             noise = _f32c(noise, self.device)
             exp = (S, max(noise_steps - 1, 1), B, self.num_coords, Tx, self.n_joints)
             if tuple(noise.shape) != exp:
                 raise ValueError(f"noise must have shape {exp}, got {tuple(noise.shape)}")
+        agg, q, name = None, 0.0, None
+        if aggregation is not None:
+            name = aggregation
+            if "quantile" in aggregation:
+                q, name = float(aggregation.split(":")[-1]), "quantile"
+            if name not in ("best", "worst", "mean", "median", "quantile"):
+                raise ValueError(f"score_fused aggregates losses (best, worst, mean, median, quantile:q), not {aggregation!r}")
+            if out is None:
+                agg = torch.empty(B, device=self.device, dtype=torch.float32)
+            elif out.shape != (B,) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+                raise ValueError("out must be a contiguous float32 (B,) tensor on the scorer's device")
+            else:
+                agg = out
         need = int(self.L.mcd_score_workspace_bytes(self._h, C.byref(cfg)))
         with torch.cuda.device(self.device):
             sid = torch.cuda.current_stream().cuda_stream
             ws = self._ws.get(sid)
             if ws is None or ws.numel() < need:
-                ws = self._ws[sid] = torch.empty(need, device=self.device, dtype=torch.uint8)
-            _lib.check(self.L.mcd_score_view(self._h, C.byref(cfg), _ptr(data), C.byref(view) if view is not None else None,
-                                             _ptr(noise), C.c_uint64(seed & (2**64 - 1)), C.c_int64(first_window_id),
-                                             _ptr(self.table(noise_steps)), _ptr(ws), _ptr(loss), _ptr(poses), _stream()))
+                ws = self._ws[sid] = torch.empty(max(need, 256), device=self.device, dtype=torch.uint8)
+            common = (self._h, C.byref(cfg), _ptr(data), C.byref(view) if view is not None else None, _ptr(noise),
+                      C.c_uint64(seed & (2**64 - 1)), C.c_int64(first_window_id), _ptr(self.table(noise_steps)), _ptr(ws))
+            if aggregation is None:
+                _lib.check(self.L.mcd_score_view(*common, _ptr(loss), _ptr(poses), _stream()))
+            else:
+                _lib.check(self.L.mcd_score_fused(*common, _lib.AGGR[name], C.c_float(q), _ptr(agg), _ptr(loss), _ptr(poses), _stream()))
         del keep
-        return loss, poses
+        return agg, loss, poses
 
     # stage ids of mcd_layer_forward: (Cin, Vin, Cout, Vout)
     _STAGES = {0: (2, 17, 16, 17), 1: (16, 17, 32, 17), 2: (32, 17, 32, 17), 3: (32, 12, 64, 12), 4: (64, 12, 64, 12),

@@ -323,10 +323,16 @@ class MoCoDAD(_Base):
                 raise NotImplementedError("the *_pose aggregations are not available with 'random_imp'")
             if cond_mask is None:
                 cond_mask = self.draw_random_imp_mask(tensor_data.shape[0])
-        loss_all, poses_all = sc.score(tensor_data, n_samples=S, noise_steps=ns, noise=noise, seed=self.seed,
-                                       first_window_id=window_offset, loss_fn=self.loss_name, want_poses=want_pose,
-                                       cond_mask=cond_mask)
-        selected_x, loss = self._aggregate(sc, tensor_data, loss_all, poses_all, aggr, want_pose)
+        kw = dict(n_samples=S, noise_steps=ns, noise=noise, seed=self.seed, first_window_id=window_offset, loss_fn=self.loss_name,
+                  cond_mask=cond_mask)
+        fusable = aggr in ("best", "worst", "mean", "median") or "quantile" in aggr
+        if fusable and not want_pose and S <= 64:
+            # loss-only output: trajectories, condition encoder and the aggregation over the samples in ONE launch
+            loss, _, _ = sc.score_fused(tensor_data, aggregation=aggr, **kw)
+            selected_x = None
+        else:
+            loss_all, poses_all = sc.score(tensor_data, want_poses=want_pose, **kw)
+            selected_x, loss = self._aggregate(sc, tensor_data, loss_all, poses_all, aggr, want_pose)
         return self._pack_out_data(selected_x, loss, [tensor_data] + meta_out, return_=ret)
 
     def draw_random_imp_mask(self, n_windows: int) -> torch.Tensor:

@@ -71,6 +71,54 @@ def test_trajectory_vs_golden(variant, ns, S):
             np.testing.assert_allclose(sel.cpu().numpy(), g[f"pose_{key}"], atol=ATOL, rtol=1e-5, err_msg=aggr)
 
 
+FUSED_AGGR = ("best", "worst", "mean", "median", "quantile:0.3")
+
+
+@pytest.mark.parametrize("variant,ns,S", [("inject", 10, 5), ("inject", 50, 8), ("concat", 10, 5), ("T12", 10, 2), ("injtail", 10, 2)])
+def test_fused_scoring_vs_golden(variant, ns, S):
+    """mcd_score_fused (condition encoder + trajectories + aggregation over the samples in one call) against the reference's
+    aggregated losses, for the three ways the call can be cut into workgroups: the library's choice, window-major (a
+    workgroup runs all samples of its windows: ONE launch, encoder and aggregation inside) and chain-major (one trajectory
+    per workgroup, aggregate_kernel afterwards).  Per-sample losses are bit-identical across the three."""
+    sc, _, _ = _scorer(variant)
+    g = load_golden(f"traj_{variant}_ns{ns}_S{S}.npz")
+    data = torch.from_numpy(g["data"])
+    noise = torch.from_numpy(g["noise"].astype(np.float32))
+    ref_all = None
+    for split in (0, 1, S):
+        sc.set_option("split", split)
+        for aggr in FUSED_AGGR:
+            key = aggr.replace(":", "_").replace(".", "p")
+            agg, all_, _ = sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation=aggr, noise=noise, want_all=True)
+            np.testing.assert_allclose(agg.cpu().numpy(), g[f"loss_{key}"], atol=ATOL, rtol=0, err_msg=f"{aggr} split={split}")
+            np.testing.assert_allclose(all_.cpu().numpy(), g["loss_all"], atol=ATOL, rtol=0)
+            ref_all = all_.clone() if ref_all is None else ref_all
+            assert torch.equal(all_, ref_all), f"split={split}"
+            only, none_, _ = sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation=aggr, noise=noise)
+            assert none_ is None and torch.equal(only, agg)
+    # the stand-alone condition-encoder launch (runtime-channel-list kernel) feeds the same trajectories
+    if variant != "concat":
+        sc.set_option("split", 0)
+        sc.set_option("cond_generic", 1)
+        agg, _, _ = sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation="best", noise=noise)
+        np.testing.assert_allclose(agg.cpu().numpy(), g["loss_best"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 511, 513])
+def test_fused_scoring_ragged_batches_perf_mode(B):
+    """Batches that leave workgroup window slots empty / do not fill the device, perf mode: fused == unfused, any split."""
+    sc, _, _ = _scorer("inject")
+    gen = torch.Generator().manual_seed(B)
+    data = torch.randn(B, 2, 6, 17, generator=gen)
+    loss, _ = sc.score(data, n_samples=3, noise_steps=4, seed=5, first_window_id=17)
+    for split in (0, 1, 3):
+        sc.set_option("split", split)
+        agg, all_, _ = sc.score_fused(data, n_samples=3, noise_steps=4, aggregation="best", seed=5, first_window_id=17, want_all=True)
+        assert torch.equal(all_, loss) and torch.equal(agg, loss.min(1)[0])
+        mean, _, _ = sc.score_fused(data, n_samples=3, noise_steps=4, aggregation="mean", seed=5, first_window_id=17)
+        np.testing.assert_allclose(mean.cpu().numpy(), loss.mean(1).cpu().numpy(), rtol=1e-6)
+
+
 @pytest.mark.parametrize("B", [1, 3, 4, 5, 37])
 def test_ragged_batch_vs_oracle(B):
     """Batch sizes that do not fill the last workgroup's chain slots: parity vs. the oracle."""

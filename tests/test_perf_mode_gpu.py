@@ -120,3 +120,48 @@ def test_score_distribution_and_auc_over_seeds_match_the_oracle(tmp_path):
     se = np.sqrt((auc_h.var(ddof=1) + auc_r.var(ddof=1)) / seeds)
     print(f"AUC hip {auc_h.round(5)} median {np.median(auc_h):.5f}; oracle {auc_r.round(5)} median {np.median(auc_r):.5f}; |diff of means| {abs(auc_h.mean()-auc_r.mean()):.5f} (se {se:.5f})")
     assert abs(auc_h.mean() - auc_r.mean()) < max(1e-3, 3 * se)
+
+
+def test_auc_over_thousands_of_seeds_philox_vs_torch_randn(tmp_path):
+    """The acceptance reading of SURVEY.md 8d (AUC within 0.001 absolute) needs more seeds than a CPU oracle can run: the
+    seed-to-seed AUC spread on a small clip set is ~0.03.  The same HIP kernel is therefore run in parity mode with
+    torch.randn draws (the mode pinned to the reference within 1e-4 per score by the golden trajectories) and in perf mode
+    (Philox) for 3000 seeds each -- BASELINE configs[1] shape, 'best' of 5 samples -- and the seed-averaged AUCs are compared:
+    |difference| < max(0.001, 3 standard errors); likewise the seed-averaged score of every window."""
+    from sklearn.metrics import roc_auc_score
+    from mocodad_amd.data import synthetic
+    from mocodad_amd.engine import FrameScoreAssembler
+    sc, _ = _scorer()
+    data, trans, meta, frames, gts = synthetic.make_dataset(n_clips=3, frames_per_clip=80, persons_per_clip=2, num_transform=2)
+    N, ns, S, R, calls = data.shape[0], 10, 5, 50, 60
+    asm = FrameScoreAssembler(gts, {}, num_transform=2, pad_size=-1, filter_kernel_size=3, frames_shift=2, device="cuda:0")
+    dtrans, dmeta, dframes = trans.cuda(), meta.cuda(), frames.cuda()
+    rep = data.cuda().repeat(R, 1, 1, 1)                       # R seeds per launch: replicas of the clip set under distinct window ids
+    gen = torch.Generator(device="cuda").manual_seed(2026)
+    auc = {"philox": [], "randn": []}
+    mean = {"philox": torch.zeros(N, device="cuda", dtype=torch.float64), "randn": torch.zeros(N, device="cuda", dtype=torch.float64)}
+    sq = {k: torch.zeros_like(v) for k, v in mean.items()}
+    for c in range(calls):
+        z = torch.randn(S, ns - 1, N * R, 2, 3, 17, device="cuda", generator=gen)
+        runs = {"philox": sc.score(rep, n_samples=S, noise_steps=ns, seed=4242, first_window_id=c * N * R)[0],
+                "randn": sc.score(rep, n_samples=S, noise_steps=ns, noise=z)[0]}
+        for k, loss in runs.items():
+            best = loss.min(1)[0].view(R, N)
+            mean[k] += best.double().sum(0)
+            sq[k] += (best.double() ** 2).sum(0)
+            for r in range(R):
+                auc[k].append(roc_auc_score(asm.gt, asm(best[r], dtrans, dmeta, dframes)))
+    n = R * calls
+    a, b = np.array(auc["philox"]), np.array(auc["randn"])
+    se = np.sqrt((a.var(ddof=1) + b.var(ddof=1)) / n)
+    print(f"{n} seeds each: AUC philox {a.mean():.5f} +- {a.std(ddof=1):.4f}, torch.randn {b.mean():.5f} +- {b.std(ddof=1):.4f}; "
+          f"|diff of means| {abs(a.mean() - b.mean()):.5f} (se {se:.5f})")
+    assert abs(a.mean() - b.mean()) < max(1e-3, 3 * se)
+    mp, mr = (mean["philox"] / n).cpu().numpy(), (mean["randn"] / n).cpu().numpy()
+    vp = (sq["philox"] / n).cpu().numpy() - mp ** 2
+    vr = (sq["randn"] / n).cpu().numpy() - mr ** 2
+    zw = (mp - mr) / np.sqrt((vp + vr) / n)
+    print(f"per-window seed-averaged 'best' score: z mean {zw.mean():.3f} rms {np.sqrt((zw ** 2).mean()):.3f} max {np.abs(zw).max():.2f}; "
+          f"variance ratio philox/randn {np.mean(vp / vr):.4f}")
+    assert abs(zw.mean()) < 5 / np.sqrt(N) and np.sqrt((zw ** 2).mean()) < 1.2 and np.abs(zw).max() < 5
+    assert abs(np.mean(vp / vr) - 1) < 0.02
