@@ -167,6 +167,9 @@ def main():
                     "batch i+1 fills the tail of batch i, +2 %%; per-launch durations then overlap, so the default keeps 1)")
     ap.add_argument("--bf16x3", action="store_true", help="OPT-IN, not the headline: channel GEMMs on the bf16 matrix path with both "
                     "operands split into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate; scores within ~1e-6 of the fp32 path)")
+    ap.add_argument("--split", type=int, default=0, help="tuning / A-B: workgroups per window group (0 = library's choice; 1 = one "
+                    "launch with encoder and aggregation inside; n_samples = one trajectory per workgroup, 3 launches)")
+    ap.add_argument("--phase", type=int, default=0, help="tuning experiment: start offset of the second half of the grid, x 1024 cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational H2D-inclusive and opt-in legs")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
@@ -207,7 +210,7 @@ def main():
     ci, xi = frame_split(seg_len, cfg["conditioning_indices"], strat)
     sc = HipScorer(sd, strategy=strat, seg_len=seg_len, cond_idx=ci, corrupt_idx=xi,
                    cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev,
-                   options={"bf16x3": 1} if args.bf16x3 else None)
+                   options=dict({"bf16x3": 1} if args.bf16x3 else {}, split=args.split, phase=args.phase))
     if args.scaling == "weak":
         # every rank owns its own shard of B windows per step (global window ids keep the Philox streams distinct and
         # independent of the number of GPUs)

@@ -140,7 +140,8 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
  *                         n_samples = one trajectory per workgroup, better fill for odd batch sizes); n > 0 forces it
  *                         (tests). */
 enum { MCD_OPT_BF16X3 = 0, MCD_OPT_VARIANT = 1, MCD_OPT_COND_GENERIC = 2, MCD_OPT_GENERIC_UNET = 3, MCD_OPT_SPLIT = 4,
-       MCD_OPT_COUNT = 5 };
+       MCD_OPT_PHASE = 5, /* tuning experiment: start the second half of the grid `value` x 1024 clock cycles late */
+       MCD_OPT_COUNT = 6 };
 int mcd_set_option(mcd_weights_t* w, int32_t option, int32_t value);
 
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.

@@ -51,6 +51,18 @@ typedef const float __attribute__((address_space(4))) cfloat;
 typedef const float __attribute__((address_space(1))) gfloat;
 typedef const f32x4 __attribute__((address_space(1))) gf32x4;
 __device__ __forceinline__ gfloat* as_global(const float* p) { return (gfloat*)p; }
+// LDS accesses through explicit 32-bit LDS addresses: a per-lane base computed once (and made opaque where the compiler would
+// rather re-derive it per use), constant byte offsets folded into the instruction's offset field
+typedef float __attribute__((address_space(3))) lds_float;
+typedef f32x4 __attribute__((address_space(3))) lds_f32x4;
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(lds_float*)p; }
+__device__ __forceinline__ float4 lds_load4(unsigned addr) {
+    const f32x4 v = *(lds_f32x4*)(uintptr_t)addr;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_store4(unsigned addr, float a, float b, float c, float d) {
+    *(lds_f32x4*)(uintptr_t)addr = f32x4{a, b, c, d};
+}
 __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byte aligned global load
     const f32x4 v = *(gf32x4*)p;
     return make_float4(v[0], v[1], v[2], v[3]);
@@ -174,6 +186,8 @@ struct ScoreParams {
     int split, aggr, cond_inkernel;
     int force_split;          // host only (MCD_OPT_SPLIT): 0 = choose
     int loss_out_optional;    // host only: loss_out is the library's own scratch, not wanted when the aggregation is fused
+    int plan_only;            // host only: choose `split`, do not launch
+    int phase;                // tuning experiment (MCD_OPT_PHASE): the second half of the grid starts `phase` x 1024 cycles late
     float aggr_q;
     float* loss_agg;          // (B,) aggregated loss, or null
     int cond_idx[12];         // cond_inkernel: data frames the condition encoder reads
@@ -405,8 +419,8 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
     auto load_x = [&](int u, float (&x)[KS][T]) {
         const int rest = u / NQ;
         const int cb = rest % CB, n = rest / CB;
-        const float* xin_p = in + (n * T * V + voff_pair) * cs_in + cb * 16 + j;
-        const float* xin_l = in + (n * T * V + g) * cs_in + cb * 16 + j;
+        const float* xin_p = in + __mul24(n * T * V + voff_pair, cs_in) + cb * 16 + j;       // (small indices: full-rate 24-bit multiply)
+        const float* xin_l = in + __mul24(n * T * V + g, cs_in) + cb * 16 + j;
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
@@ -576,7 +590,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
         const int u = wave + i * NWAVES;
         if (u < UNITS) {
             const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
-            const float* xin = in + (nt * VIN) * cs_in + cb * 16 + j;
+            const float* xin = in + __mul24(nt * VIN, cs_in) + cb * 16 + j;
             static_for<KS>([&](auto si) {
                 constexpr int ks = decltype(si)::value;
                 int row;
@@ -613,7 +627,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
                 for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
                 if constexpr (SK == 5 && !J16) acc[MT - 1][0] += skip[i * SK + 4];   // joint 16: lane group g = 0, row 0 of m-tile 1
             }
-            float* zo = out + (nt * VOUT + 4 * g) * cs_out + cb * 16 + j;
+            float* zo = out + __mul24(nt * VOUT + 4 * g, cs_out) + cb * 16 + j;
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt)
 #pragma unroll
@@ -626,7 +640,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
                 const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
                 float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]) + bias[1][0];
                 if constexpr (ADD && SK == 5) z16 += skip[i * SK + 4];          // captured by lane group g = 0 (k-step 4: joint 16 + g)
-                if (g == 0) out[(nt * VOUT + 16) * cs_out + cb * 16 + j] = z16;
+                if (g == 0) out[__mul24(nt * VOUT + 16, cs_out) + cb * 16 + j] = z16;
             }
         }
     });
@@ -664,26 +678,34 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
 
 // FORCE: pin the read-ahead order with scheduling barriers -- only for the kernels without a register cap (the
 // scheduler otherwise sinks every read to its use; with the 128-VGPR cap pinning costs spills and loses)
+// cinit: what a tile's accumulators start from when the layer has no identity residual -- the folded bias of the lane's 4
+// output channels (two packed adds per tile less in the epilogue), or zero
 template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, class Epi>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
-                                           const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0) {
+                                           const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0,
+                                           const float4 cinit = make_float4(0.f, 0.f, 0.f, 0.f)) {
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
     const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
     const int j = lane & 15, g = lane >> 4;
     const int c0 = mt * 16 + 4 * g;
+    // per-lane bases of this wave's FIRST tile, once per call; tile i sits at the compile-time offset i * NG * 16 * stride
+    // (a per-tile col * stride is a quarter-rate v_mul_lo_u32 plus two adds on the VALU, which shares the SIMD with the MFMAs)
+    const int col0 = ng * 16 + j;
+    const float* const p1b = b1 + __mul24(col0, cs1) + 4 * g;
+    const float* const p2b = b2 + __mul24(col0, cs2) + 4 * g;
     static_for<MAXN>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
         const int nt = ng + i * NG;
         if (nt < NT) {
-            const int col = nt * 16 + j;
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            const int col = col0 + i * NG * 16;
+            f32x4 c = {cinit.x, cinit.y, cinit.z, cinit.w};
+            const float* p1 = p1b + i * NG * 16 * cs1;
+            const float* p2 = p2b + i * NG * 16 * cs2;
             if (IDRES) {
-                const float4 r = *reinterpret_cast<const float4*>(b2 + col * cs2 + c0);
+                const float4 r = *reinterpret_cast<const float4*>(p2 - 4 * g + c0);
                 c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
             }
-            const float* p1 = b1 + col * cs1 + 4 * g;
-            const float* p2 = b2 + col * cs2 + 4 * g;
             // B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH reads ahead of the MFMAs that consume them: read
             // right before its use each fragment exposes an LDS round trip per 4 MFMAs on this wave's matrix-pipe stream
             constexpr int KQ = KQ1 + KQ2;
@@ -705,7 +727,7 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u.z, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u.w, c, 0, 0, 0);
             });
-            epi(ii, col, c0, c);
+            epi(ii, col, c0, c, col0, ng);
         }
     });
 }
@@ -795,7 +817,7 @@ __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch]), lo, c, 0, 0, 0);       // hi_w * lo_x
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a[2 * ch + 1]), hi, c, 0, 0, 0);   // lo_w * hi_x
             });
-            epi(ii, col, c0, c);
+            epi(ii, col, c0, c, ng * 16 + j, ng);
         }
     });
 }
@@ -823,12 +845,15 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr);
     else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     const float* bias = wb + lw.bias;
+    // (the folded bias starts the first tile's accumulators: fetched here, with the weight fragments, so that its L2 latency
+    // hides behind the mix as well)
+    float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
     mix_stage<CIN, V, T, NB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
                              [&](int n, int q, int w0, int c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
                                  // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store)
-                                 float* zp = z + ((n * T + q) * V + w0) * CSI + c;
+                                 float* zp = z + __mul24((n * T + q) * V + w0, CSI) + c;
                                  if constexpr (std::is_same_v<decltype(v), f32x4>) {
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)
@@ -843,34 +868,70 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                              });
     __syncthreads();
     prof.mark(prof_id);
-    float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
     pre_gemm();
     const float slope = lw.slope;
     const float pinf = prelu_bound(slope);     // see prelu()
-    auto epi = [&](auto, int col, int c0, f32x4 acc) {
-        if (col < COLS && c0 < COUT) {
+    constexpr int TILE_STEP = Tiling<MT, NT>::NG * 16;      // columns between a wave's consecutive n-tiles
+    // the folded bias starts the accumulators of the layers with a residual convolution (identity residuals start from X)
+    constexpr bool FOLD = RES && !BF3;
+    // Per-lane offsets of the wave's first tile in `out` and of its 4 channels in the embedding row: computed ONCE per GEMM call
+    // and made opaque, so that the tiles address with immediates instead of re-deriving col * stride + c0 (3 VALU instructions
+    // per tile: the compiler prefers rematerialising to holding a register)
+    unsigned oaddr = 0, eaddr = 0;      // LDS byte addresses
+    auto set_bases = [&](int mi) {
+        const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
+        const int c0 = mt * 16 + 4 * (lane >> 4);
+        oaddr = lds_addr(out) + 4u * (unsigned)(__mul24(ng * 16 + (lane & 15), CSO) + c0);
+        eaddr = HASEMB ? lds_addr(embl) + 4u * (unsigned)c0 : 0u;
+        asm volatile("" : "+v"(oaddr), "+v"(eaddr));
+    };
+    set_bases(0);
+    auto epi = [&](auto ti, int col, int c0, f32x4 acc, int, int ng) {
+        // pad columns (col >= COLS) are computed and stored like the others: every region has ceil16(COLS) rows, nobody reads
+        // them, and no per-tile bounds check runs on the VALU.  Output channels: only COUT not a multiple of 16 needs the check.
+        // (the split-bf16 path keeps the check: its pad rows hold bf16 planes of stale fp32 data, which can read as NaN, and a
+        // NaN written to a pad row would meet the zero weights of the resamplers' K padding: NaN x 0)
+        if ((COUT % 16 == 0 || c0 < COUT) && (!BF3 || col < COLS)) {
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HASEMB)      // this column's chain: no integer division on the tile epilogue's path when there are two chains
-                e = *reinterpret_cast<const float4*>(embl + (NB == 2 ? (col >= TV ? EMB_STRIDE : 0) : (col / TV) * EMB_STRIDE) + c0);
-            // packed adds / multiply on channel pairs (v_pk_add_f32, v_pk_mul_f32) around the four v_med3_f32 of the PReLU:
-            // 10 VALU instructions for the lane's 4 channels
-            const f32x2 t0 = f32x2{acc[0], acc[1]} + f32x2{bcur.x, bcur.y}, t1 = f32x2{acc[2], acc[3]} + f32x2{bcur.z, bcur.w};
+            if (HASEMB) {
+                // this column's chain.  Two chains: a tile lies on one side of the chain boundary (wave-uniform: picked on the
+                // scalar unit) except the one tile that straddles it
+                if constexpr (NB == 2) {
+                    const int tile_lo = (ng + decltype(ti)::value * Tiling<MT, NT>::NG) * 16;
+                    unsigned eo = tile_lo >= TV ? 4u * EMB_STRIDE : 0u;                          // scalar unit
+                    if (tile_lo < TV && tile_lo + 16 > TV) {                                      // the straddling tile: per lane
+                        eo = col >= TV ? 4u * EMB_STRIDE : 0u;
+                        asm volatile("" : "+v"(eo));       // (keeps this a scalar branch: if-converted it costs every tile 5 VALU instructions)
+                    }
+                    e = lds_load4(eaddr + eo);
+                } else if constexpr (NB > 2) {
+                    const int n = col / TV;
+                    e = lds_load4(eaddr + 4u * (unsigned)((n < NB ? n : NB - 1) * EMB_STRIDE));
+                } else {
+                    e = lds_load4(eaddr);
+                }
+            }
+            // packed adds / multiply on channel pairs (v_pk_add_f32, v_pk_mul_f32) around the four v_med3_f32 of the PReLU
+            f32x2 t0 = f32x2{acc[0], acc[1]}, t1 = f32x2{acc[2], acc[3]};
+            if constexpr (!FOLD) { t0 += f32x2{bcur.x, bcur.y}; t1 += f32x2{bcur.z, bcur.w}; }
             const f32x2 m0 = t0 * slope, m1 = t1 * slope;
             const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf)} + f32x2{e.x, e.y};
             const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf)} + f32x2{e.z, e.w};
-            if constexpr (OUTP) store_split4<COUT>(out + col * CSO, c0, r0[0], r0[1], r1[0], r1[1]);
-            else *reinterpret_cast<float4*>(out + col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
+            constexpr unsigned tile_bytes = 4u * decltype(ti)::value * TILE_STEP * CSO;
+            if constexpr (OUTP) store_split4<COUT>(out + __mul24(col, CSO), c0, r0[0], r0[1], r1[0], r1[1]);
+            else lds_store4(oaddr + tile_bytes, r0[0], r0[1], r1[0], r1[1]);
         }
     };
     if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi);
-    else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi);
+    else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, 0, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
         if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, mi);
         else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
         bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
+        set_bases(mi);
         if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
-        else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
+        else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     pre_barrier();
     __syncthreads();
@@ -1098,6 +1159,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int tid = tid0;
     int lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (P.phase > 0 && blockIdx.x * 2 >= gridDim.x) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)P.phase * 1024ull) __builtin_amdgcn_s_sleep(32);
+    }
     // this workgroup: windows win0 .. win0 + NB - 1, samples part, part + split, ...
     const int grp = blockIdx.x / P.split, part = blockIdx.x - grp * P.split;
     const int win0 = grp * NB;
@@ -1371,8 +1436,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             float* Pb = RG + PL::L6_p;
             MixCoef<64, 10, T, NB> mc6;
             mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
-            auto epi6 = [&](auto, int col, int c0, f32x4 acc) {
-                if (col < COLS) *reinterpret_cast<float4*>(Pb + col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            auto epi6 = [&](auto ti, int col, int c0, f32x4 acc, int col0, int) {
+                constexpr int STEP = Tiling<8, NT>::NG * 16 * 132;
+                if (col < COLS) *reinterpret_cast<float4*>(Pb + __mul24(col0, 132) + c0 + decltype(ti)::value * STEP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
             if constexpr (BF3) gemm_tiles_bf3<8, NT, 4, 0, false, true, true>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
             else gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
@@ -1392,14 +1458,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float pinf6 = prelu_bound(slope6);
             mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w0, int c, std::true_type) {   // the fragment's 4 joints at once
-                                         const float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
+                                         const float* pp = Pb + __mul24((n * T + q) * 10 + w0, 132) + 64 + c;
                                          // joints >= 10 read the next frame's rows (inside the 64-column region): an MFMA's D rows
                                          // are independent and those rows are never stored
                                          return f32x4{pp[0], pp[132], pp[264], pp[396]};
                                      },
                                      [&](int n, int q, int w0, int c, f32x4 v) {
                                          const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
-                                         float* pp = Pb + ((n * T + q) * 10 + w0) * 132 + 64 + c;
+                                         float* pp = Pb + __mul24((n * T + q) * 10 + w0, 132) + 64 + c;
                                          const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{bias, bias}, t1 = f32x2{v[2], v[3]} + f32x2{bias, bias};
                                          const f32x2 m0 = t0 * slope6, m1 = t1 * slope6;
                                          const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf6), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf6)} + f32x2{e, e};
@@ -2398,16 +2464,18 @@ int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64]) {
     cache[dev].store(v, std::memory_order_relaxed);
     return v;
 }
-// How a scoring call is cut into workgroups.  A workgroup owns NB windows and runs `units` = S / split of their samples in
-// sequence.  split = 1 (window-major) lets the condition encoder and the aggregation run inside the workgroup -- one launch
-// per call -- and is taken when it fills the device's workgroup slots at least as well as split = S (chain-major: one
-// trajectory per workgroup); `fill` = useful slot-time / occupied slot-time for in-order dispatch of equal units.
+// How a scoring call is cut into workgroups.  A workgroup owns NB windows and runs S / split of their samples in sequence.
+// split = 1 (window-major) lets the condition encoder and the aggregation run inside the workgroup -- ONE launch per call,
+// no workspace -- split = S (chain-major) is one trajectory per workgroup with the encoder and the aggregation as their own
+// small launches.
 int choose_split(int n_groups, int S, int slots) {
-    auto fill = [&](long long wgs, int units) {
-        const long long rounds = (wgs + slots - 1) / slots;
-        return (double)(wgs * units) / ((double)rounds * slots * units);
-    };
-    return fill(n_groups, S) + 1e-9 >= fill((long long)n_groups * S, 1) ? 1 : S;
+    // estimated makespan in units of one trajectory: rounds of workgroups x trajectories per workgroup.  Window-major pays 2 %
+    // (measured, profiles/r02d_split_ab.txt: its static schedule cannot rebalance between faster and slower CUs the way a grid
+    // of many short workgroups does); chain-major pays its two extra launches (~0.05 trajectories).
+    auto rounds = [&](long long wgs) { return (double)((wgs + slots - 1) / slots); };
+    const double window_major = rounds(n_groups) * S * 1.02;
+    const double chain_major = rounds((long long)n_groups * S) + 0.05;
+    return S > 1 && chain_major < window_major ? S : 1;
 }
 
 template <int T, int NB, int MINW, bool BF3 = false, bool LT = false>
@@ -2417,8 +2485,11 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
     static std::atomic<int> slots_cache[64];
     const int groups = (P.B + NB - 1) / NB;
     const int slots = wg_slots(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW, BF3, LT>), PL::BYTES, slots_cache);
-    P.split = P.mode == 0 ? choose_split(groups, P.S, slots) : 1;
-    if (P.force_split > 0) P.split = P.force_split < P.S ? P.force_split : P.S;
+    if (P.plan_only || P.mode != 0) {
+        P.split = P.mode == 0 ? choose_split(groups, P.S, slots) : 1;
+        if (P.mode == 0 && P.force_split > 0) P.split = P.force_split < P.S ? P.force_split : P.S;
+        if (P.plan_only) return MCD_OK;
+    }
     // the in-kernel condition encoder / aggregation need the workgroup to see all samples of its windows (and S <= 64)
     const bool whole = P.split == 1 && P.mode == 0;
     if (!(whole && P.S <= 64)) P.loss_agg = nullptr;
@@ -2432,6 +2503,7 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
 
 int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bool* fused = nullptr) {
     P.force_split = w->opt[MCD_OPT_SPLIT];
+    P.phase = w->opt[MCD_OPT_PHASE];
     const int variant = w->opt[MCD_OPT_VARIANT];          // tuning experiments only
     // opt-in split-bf16 channel GEMMs (layers 2..9) for 3, 6 and 12 U-Net frames (see gemm_tiles_bf3); everything measured and
     // reported by bench.py uses the fp32 path
@@ -3031,6 +3103,12 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
     float* ws_loss = wsb ? reinterpret_cast<float*>(wsb + ws_cond_bytes(w, B)) : nullptr;
     float* gen_scratch = wsb ? reinterpret_cast<float*>(wsb + ws_cond_bytes(w, B) + ws_loss_bytes(B, S)) : nullptr;
     P.loss_out = loss_all ? loss_all : ws_loss;       // (skipped by a fused launch when the caller did not ask for it)
+    if (!generic) {           // how the call is cut into workgroups (decides where the condition encoder runs)
+        P.plan_only = 1;
+        const int rc = launch_score(w, Tu, P, st);
+        if (rc != MCD_OK) return rc;
+        P.plan_only = 0;
+    }
     auto score = [&]() -> int {
         bool fused = false;
         int rc;
@@ -3049,8 +3127,9 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
         return launch_aggregate(A, st);
     };
     if (strat == MCD_STRATEGY_INJECT) {
-        // the shipped encoder with as many condition frames as the U-Net has frames runs inside the trajectory kernel
-        if (!generic && w->cond_fast && !w->opt[MCD_OPT_COND_GENERIC] && cfg->n_cond == Tu && Tu <= 12) {
+        // the shipped encoder with as many condition frames as the U-Net has frames runs inside the trajectory kernel when
+        // its workgroups own whole windows (otherwise every workgroup of a window would repeat it: its own launch then)
+        if (!generic && P.split == 1 && w->cond_fast && !w->opt[MCD_OPT_COND_GENERIC] && cfg->n_cond == Tu && Tu <= 12) {
             P.cond_inkernel = 1;
             for (int k = 0; k < Tu; ++k) P.cond_idx[k] = cfg->cond_idx[k];
             return score();

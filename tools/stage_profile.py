@@ -19,16 +19,21 @@ _lib.LIB_PATH = so
 import bench
 from mocodad_amd.engine import HipScorer
 
-sd, cfg = bench.load_weights()
-sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0, 1, 2], corrupt_idx=[3, 4, 5],
-               cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0", options={"variant": VARIANT})
+CONFIG = sys.argv[2] if len(sys.argv) > 2 else "avenue"
+variant_w, B, NS, S, _ = bench.CONFIGS[CONFIG]
+sd, cfg = bench.load_weights(variant_w)
+ci, xi = bench.frame_split(cfg["seg_len"], cfg["conditioning_indices"], cfg["conditioning_strategy"])
+sc = HipScorer(sd, strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"], cond_idx=ci, corrupt_idx=xi,
+               cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0", options={"variant": VARIANT, "split": S})
+B = min(B, 1024)
+NS = min(NS, 10)
 L = _lib.lib()
 prof = torch.zeros(96, dtype=torch.int64, device="cuda:0")
-data = bench.synth_windows(1024, 6, 1).cuda()
-sc.score(data, n_samples=5, noise_steps=10, seed=1)
+data = bench.synth_windows(B, cfg["seg_len"], 1).cuda()
+sc.score(data, n_samples=S, noise_steps=NS, seed=1)
 torch.cuda.synchronize()
 L.mcd_debug_set_prof(C.c_void_p(prof.data_ptr()))
-sc.score(data, n_samples=5, noise_steps=10, seed=1)
+sc.score(data, n_samples=S, noise_steps=NS, seed=1)
 torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(float)
 names = ["pass prologue", "-", "L0 sp1a", "L1 sd1.0", "L2 sd1.1", "down1", "L3 sd2.0", "L4 sd2.1", "down2", "L5 sd3.0",
@@ -40,14 +45,15 @@ for l in range(11):
         p[idx] += sub[l, 0] + sub[l, 1]
 sub10 = p[18:22].copy()        # layer 10: FMA product | x-block zeroing + next pass's embeddings | barrier | mix + DDPM store (then barrier = p[17])
 p[17] += sub10.sum()
+NP = NS - 1
 tot = p[:18].sum()
-print(f"variant={VARIANT}  cycles per pass (9 passes): total {tot/9:.0f}")
+print(f"variant={VARIANT}  cycles per pass ({NP} passes): total {tot/NP:.0f}")
 lay = {2: 0, 3: 1, 4: 2, 6: 3, 7: 4, 9: 5, 13: 7, 14: 8, 16: 9}
 for i, (n, v) in enumerate(zip(names, p)):
     extra = ""
     if i in lay:
         l = lay[i]
-        extra = f"   mix {sub[l,0]/9:7.0f}  gemm {sub[l,1]/9:7.0f}  epilogue {(v - sub[l,0] - sub[l,1])/9:7.0f}"
+        extra = f"   mix {sub[l,0]/NP:7.0f}  gemm {sub[l,1]/NP:7.0f}  epilogue {(v - sub[l,0] - sub[l,1])/NP:7.0f}"
     if i == 17:
-        extra = f"   product {sub10[0]/9:6.0f}  zero+emb {sub10[1]/9:6.0f}  barrier {sub10[2]/9:6.0f}  mix+barrier+tail {sub10[3]/9:6.0f}  barrier {(v - sub10.sum())/9:6.0f}"
-    print(f"  {n:14s} {v/9:9.0f}  {100*v/tot:5.1f}%{extra}")
+        extra = f"   product {sub10[0]/NP:6.0f}  zero+emb {sub10[1]/NP:6.0f}  barrier {sub10[2]/NP:6.0f}  mix+barrier+tail {sub10[3]/NP:6.0f}  barrier {(v - sub10.sum())/NP:6.0f}"
+    print(f"  {n:14s} {v/NP:9.0f}  {100*v/tot:5.1f}%{extra}")
