@@ -32,9 +32,50 @@ F_UNET = {3: 4_290_352, 6: 8_799_400, 12: 18_524_464}
 F_COND = {3: 545_904, 12: 2_484_720}
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per launch and matrix-pipe counters of the default workload from the rocprofv3 PMC passes committed under
-# profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); constants of a profile, not measured by this run
-PMC_DEFAULT = {"source": "profiles/r01t_pmc.txt", "hbm_bytes_per_launch": 7.65e6}
+# rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/r02_profile.sh): per-launch counter averages
+# of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
+# measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
+PMC_PROFILES = {"avenue": ("profiles/r02e_avenue_pmc.txt", 1024, 10, 5), "ubnormal_concat": ("profiles/r02e_ubnormal_concat_pmc.txt", 1024, 10, 5),
+                "seq24": ("profiles/r02e_seq24_pmc.txt", 1024, 50, 8)}
+CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
+
+
+def pmc_profile(config, B, ns, S, flop_per_window, kern_ms):
+    """Per-launch HBM bytes (FETCH_SIZE x 2, the guide's gfx950 correction, + WRITE_SIZE, all kernels of a step) and the
+    matrix-pipe statistics of the trajectory kernel from the committed PMC profile of this configuration."""
+    if config not in PMC_PROFILES:
+        return None
+    path, pB, pns, pS = PMC_PROFILES[config]
+    try:
+        kernels, cur = {}, None
+        for line in open(os.path.join(ROOT, path)):
+            if line.startswith("#") or not line.strip():
+                continue
+            if not line.startswith(" "):
+                cur = kernels.setdefault(line.strip(), {})
+            else:
+                f = line.split()
+                cur[f[0]] = float(f[1])
+    except Exception:
+        return None
+    sk = next((v for k, v in kernels.items() if k.startswith("score_kernel")), None)
+    if not sk:
+        return None
+    scale = (B * S * (ns - 1)) / float(pB * pS * (pns - 1))       # counters scale with the chain-passes of a launch
+    out = {"source": path, "profiled_workload": {"windows": pB, "noise_steps": pns, "samples": pS}}
+    mfma = sk.get("SQ_INSTS_MFMA")
+    if mfma:
+        mfma *= scale
+        # 16x16x4 fp32 MFMAs: 2048 FLOP and 32 cycles of one of the 1024 SIMDs each
+        out["mfma_issued_per_launch"] = round(mfma)
+        out["useful_mfma_frac"] = round(min(1.0, B * flop_per_window / 2048.0 / mfma), 4)
+        out["mfma_pipe_busy_frac"] = round(mfma * 32 / (1024 * CLOCK_GHZ * 1e9 * kern_ms * 1e-3), 4)
+        if "SQ_INSTS_VALU" in sk:
+            out["other_valu_per_mfma"] = round((sk["SQ_INSTS_VALU"] * scale - mfma) / mfma, 3)
+    if (B, ns, S) == (pB, pns, pS) and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in kernels.values()):
+        out["hbm_bytes_per_step"] = sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in kernels.values()) * 1024.0
+    return out
+
 
 # name -> (golden weights variant, windows per step, noise_steps, samples, description)
 CONFIGS = {
@@ -295,7 +336,7 @@ def main():
         P = S * (ns - 1)
         flop_per_window = P * F_UNET[sc.t_unet] + (F_COND[sc.t_cond] if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
-        default_wl = (args.config, B, ns, S, args.bf16x3) == ("avenue", 1024, 10, 5, False)
+        pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms)
         nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2"}[sc.t_unet]
         out = {
             "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
@@ -314,14 +355,16 @@ def main():
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
                          "hbm_algorithmic_bytes_per_window": 2 * seg_len * 17 * 4 + 4,
-                         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
-                         # a constant of the committed profile of the default workload, null elsewhere
-                         "traffic": PMC_DEFAULT["hbm_bytes_per_launch"] if default_wl else None,
-                         "traffic_source": PMC_DEFAULT["source"] if default_wl else None,
-                         # the HBM roofline north_star asks to see beside it: measured bytes / launch time vs 8 TB/s
-                         "hbm": ({"achieved_GBps": round(PMC_DEFAULT["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
-                                  "frac": round(PMC_DEFAULT["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 6)}
-                                 if default_wl else None)},
+                         # `traffic`: HBM bytes per step from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE x 2,
+                         # the guide's gfx950 correction, + WRITE_SIZE); null when the workload is not the profiled one
+                         "traffic": pmc["hbm_bytes_per_step"] if pmc and "hbm_bytes_per_step" in pmc else None,
+                         "traffic_source": pmc["source"] if pmc else None,
+                         # the HBM roofline north_star asks to see beside it: those bytes / this run's launch time vs 8 TB/s
+                         "hbm": ({"achieved_GBps": round(pmc["hbm_bytes_per_step"] / (kern_ms * 1e-3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBS,
+                                  "frac": round(pmc["hbm_bytes_per_step"] / (kern_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 6)}
+                                 if pmc and "hbm_bytes_per_step" in pmc else None),
+                         # matrix-pipe statistics from the same profile: frac ~= mfma_pipe_busy_frac x useful_mfma_frac
+                         "pmc": pmc},
         }
         if use_dist:
             out["ranks"] = dict(rank_info, backend="rccl" if args.dist_backend == "nccl" else args.dist_backend)

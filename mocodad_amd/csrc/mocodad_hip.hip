@@ -1657,17 +1657,25 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (valid && pose_out) pose_out[(size_t)(b * Sq + s) * per + e] = x0;
         }
         __syncthreads();
-        if (tid_s < NB * 64) {
-            const int n = tid_s >> 6, ln = tid_s & 63;
+        // two-level sum in a fixed order, through LDS: 8 partial sums per chain, then one thread per chain.  (A wave shuffle
+        // reduction needs the lane id, which the compiler computes at kernel entry and keeps alive -- spilled -- across the
+        // whole trajectory; this runs once per sample.)
+        float* PART = RED + NB * per;
+        if (tid_s < NB * 8) {
+            const int n = tid_s >> 3, p8 = tid_s & 7;
             float sum = 0.f;
-            for (int e = ln; e < per; e += 64) sum += RED[n * per + e];
+            for (int e = p8; e < per; e += 8) sum += RED[n * per + e];
+            PART[tid_s] = sum;
+        }
+        __syncthreads();
+        if (tid_s < NB) {
+            const int n = tid_s;
+            float sum = 0.f;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-            if (ln == 0) {
-                const float l = sum / (float)per;
-                if (win0 + n < Bq && loss_out) loss_out[(size_t)(win0 + n) * Sq + s] = l;
-                if (s < 64) LOSSB[n * 64 + s] = l;
-            }
+            for (int k = 0; k < 8; ++k) sum += PART[n * 8 + k];
+            const float l = sum / (float)per;
+            if (win0 + n < Bq && loss_out) loss_out[(size_t)(win0 + n) * Sq + s] = l;
+            if (s < 64) LOSSB[n * 64 + s] = l;
         }
     }
     __syncthreads();        // RED (the work region) and XT are rewritten by the next sample
@@ -1676,8 +1684,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     if (prof.on) for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];    // thread 0's own ds_adds: in order
 #endif
     // ---- aggregation over the samples (mocodad.py:454-520; loss-based strategies), when this workgroup has seen them all
-    if (P.mode == 0 && P.loss_agg && tid0 < NB && win0 + tid0 < P.B)
-        P.loss_agg[win0 + tid0] = aggregate_losses(LOSSB + tid0 * 64, P.S, P.aggr, P.aggr_q);
+    int te = tid0;
+    asm volatile("" : "+v"(te));       // (opaque: win0 + tid from the prologue would otherwise be kept -- spilled -- until here)
+    if (P.mode == 0 && P.loss_agg && te < NB && win0 + te < P.B)
+        P.loss_agg[win0 + te] = aggregate_losses(LOSSB + te * 64, P.S, P.aggr, P.aggr_q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2470,7 +2480,7 @@ int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64]) {
 // small launches.
 int choose_split(int n_groups, int S, int slots) {
     // estimated makespan in units of one trajectory: rounds of workgroups x trajectories per workgroup.  Window-major pays 2 %
-    // (measured, profiles/r02d_split_ab.txt: its static schedule cannot rebalance between faster and slower CUs the way a grid
+    // (measured, profiles/r02e_split_ab.txt: its static schedule cannot rebalance between faster and slower CUs the way a grid
     // of many short workgroups does); chain-major pays its two extra launches (~0.05 trajectories).
     auto rounds = [&](long long wgs) { return (double)((wgs + slots - 1) / slots); };
     const double window_major = rounds(n_groups) * S * 1.02;

@@ -1,0 +1,33 @@
+# Round-2 profile set of the final kernels: bench lines, kernel traces and PMC passes of the three trajectory-kernel shapes,
+# the one-launch (window-major) variant of the default workload, and the split A/B.   usage: gpurun -- bash tools/r02_profile.sh <tag>
+set -x
+TAG=${1:-r02e}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+for c in avenue stc ubnormal_concat seq24; do
+  st=20; [ $c = seq24 ] && st=5
+  timeout 400 python bench.py --config $c --steps $st > $O/bench_$c.json 2> $O/bench_$c.err
+done
+# chain-major (default, 3 launches) vs window-major (one launch) on this box, interleaved
+{ for rep in 1 2 3; do for sp in 5 1; do echo -n "avenue B=1024 split=$sp: "; python bench.py --split $sp --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'clips/s  frac', d['roofline']['frac'], ' kernel ms/step', d['roofline']['kernel_ms_per_step'])"; done; done
+  for sp in 5 1; do echo -n "avenue B=4096 split=$sp: "; python bench.py --batch 4096 --split $sp --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'clips/s  frac', d['roofline']['frac'])"; done; } > $O/split_ab.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+for c in avenue avenue_onelaunch ubnormal_concat seq24; do
+  st=20; ex=""; cfg=$c
+  [ $c = seq24 ] && st=3 && ex="--batch 1024"
+  [ $c = avenue_onelaunch ] && cfg=avenue && ex="--split 1"
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$c -- python $R/bench.py --config $cfg --steps $st --warmup 2 --no-cpu-baseline --no-extras $ex > $O/prof_$c.log 2>&1
+  python $R/tools/rocpd_summary.py $(find $O/prof_$c -name "*_results.db" | head -1) > $O/${c}_kernel_stats.txt
+  rm -rf $O/prof_$c
+  [ $c = avenue_onelaunch ] && continue
+  i=0
+  for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc_${c}_$i -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras $ex > $O/pmc_${c}_$i.log 2>&1
+  done
+  python $R/tools/pmc_summary.py $(find $O/pmc_${c}_* -name "*_results.db") > $O/${c}_pmc.txt
+  rm -rf $O/pmc_${c}_*
+done
+ls -la $O; cat $O/split_ab.txt
