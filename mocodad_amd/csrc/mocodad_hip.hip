@@ -358,7 +358,13 @@ struct MixCfg {
     // output frames computed together by one unit: all of them (shared X reads) when that still gives every wave
     // work, otherwise one frame per unit
     static constexpr int QALL = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;
-    static constexpr int QC = (NB * CB * (T / QALL) >= NWAVES) ? QALL : 1;
+    // the largest chunk (3, 2, 1 frames) that still gives every wave a unit; failing that, the largest one that keeps more
+    // than half of them busy in a single round (e.g. 32 channels at 6 frames: 6 two-frame units -- one round, X reads shared
+    // by the pair, no mid-stage coefficient fetch -- instead of 12 single-frame units in two rounds)
+    static constexpr int Q2 = (T % 2 == 0) ? 2 : 1;
+    static constexpr int units_of(int qc) { return NB * CB * (T / qc); }
+    static constexpr int QC = units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
+                            : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
     static constexpr int NQ = T / QC;
     static constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
     static constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;   // rounds
