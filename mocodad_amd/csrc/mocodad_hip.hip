@@ -269,6 +269,19 @@ __device__ __forceinline__ float prelu_bound(float a) {
 }
 __device__ __forceinline__ float prelu(float x, float a) { return __builtin_amdgcn_fmed3f(x, a * x, prelu_bound(a)); }
 
+// sum over the 16 lanes of a DPP row, result in every lane: quad swaps, then half-row and row mirrors (no lane id, no LDS)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    v += dpp_f<0x140>(v);     // row_mirror
+    return v;
+}
+
 // aggregation of one window's S per-sample losses (mocodad.py:504-512 best / worst with strict comparisons from 1e10 / -1,
 // :489-492 mean / median, :513-516 quantile): torch's conventions -- median = lower middle, quantile = linear interpolation
 // (torch.lerp).  Sorts L in place for the order statistics.
@@ -1002,15 +1015,23 @@ __device__ __forceinline__ void emb_row(const EmbRow& f, int o, const float* __r
         else if (o < EMB_TOTAL) e10[n * 4 + (o - emb_off(10))] = r;
     }
 }
-// thread tid owns output channel tid (row `f`) and, for the EMB_TOTAL - NTHREADS channels beyond, tid + NTHREADS (row
-// `f2`, loaded by every thread with a clamped index: a conditionally loaded register struct costs phi copies)
-__device__ __forceinline__ int emb_row2(int tid) { return tid + NTHREADS < EMB_TOTAL ? tid + NTHREADS : EMB_TOTAL - 1; }
+// thread tid owns output channel tid (row `f`, fetched from L2 a stage ahead) and, for the EMB_TOTAL - NTHREADS channels
+// beyond, tid + NTHREADS: those few rows are kept in LDS (exw[row][20]: 16 weights, bias; copied once per workgroup) -- as
+// a second register row per thread they were fetched right before their use and the first wave waited an L2 round trip
+// for them in front of the stage's barrier
+constexpr int EMB_EXTRA = EMB_TOTAL > NTHREADS ? EMB_TOTAL - NTHREADS : 0;
 template <int NB>
-__device__ __forceinline__ void emb_compute(const EmbRow& f, const EmbRow& f2, const float* __restrict__ se,
+__device__ __forceinline__ void emb_compute(const EmbRow& f, const float* __restrict__ exw, const float* __restrict__ se,
                                             float* __restrict__ emb, float* __restrict__ e10, int tid) {
     static_assert(EMB_TOTAL <= 2 * NTHREADS, "two rows per thread cover the embedding outputs");
     emb_row<NB>(f, tid, se, emb, e10);
-    if (tid + NTHREADS < EMB_TOTAL) emb_row<NB>(f2, tid + NTHREADS, se, emb, e10);
+    if (tid < EMB_EXTRA) {
+        EmbRow f2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f2.w[q] = *reinterpret_cast<const float4*>(exw + tid * 20 + 4 * q);
+        f2.b = exw[tid * 20 + 16];
+        emb_row<NB>(f2, tid + NTHREADS, se, emb, e10);
+    }
 }
 
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
@@ -1051,12 +1072,13 @@ struct Plan {
     static constexpr int TT = P17 * 2;          // per (column, coordinate) of the element-wise tail: packed (chain, frame, joint) indices
     static constexpr int CE = 4 * EDIM;         // condition embeddings of the workgroup's windows [NB <= 4][16]
     static constexpr int LOSS = NB * 64;        // per-sample losses of the workgroup's windows [NB][S <= 64] (in-kernel aggregation)
+    static constexpr int EXW = EMB_EXTRA * 20;  // embedding rows beyond the first NTHREADS: [row][16 weights, bias, pad]
 #ifdef MCD_PROFILE
     static constexpr int PROF = PROF_SLOTS;
 #else
     static constexpr int PROF = 0;
 #endif
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + PROF;
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + EXW + PROF;
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 
@@ -1115,10 +1137,13 @@ __device__ __forceinline__ void cond_fast_body(const float* wbuf, const DataView
     gfloat* bb = as_global(wb + tab_i(wb, TABC + TABC_LB));
     for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
         const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
+        // (c, tv) loops instead of k % TV, k / TV per element; the 16 parts of an output are the 16 lanes of a DPP row
         float a = 0.f;
-        for (int k = part; k < F; k += 16) a = fmaf(W[jo * F + k], H[(n * TV + k % TV) * 36 + k / TV], a);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+        gfloat* wr = W + jo * F + part;
+        const float* hr = H + (n * TV + part) * 36;
+        for (int c = 0; c < 32; ++c)
+            for (int tv = 0; tv + part < TV; tv += 16) a = fmaf(wr[c * TV + tv], hr[tv * 36 + c], a);
+        a = row16_sum(a);
         if (part == 0) {
             const float e = a + bb[jo];
             if (emb_lds) emb_lds[n * EDIM + jo] = e;
@@ -1196,6 +1221,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int* const TT = reinterpret_cast<int*>(ZO + PL::ZO);
     float* const CE = reinterpret_cast<float*>(TT + PL::TT);
     float* const LOSSB = CE + PL::CE;
+    float* const EXW = LOSSB + PL::LOSS;
+    for (int u = threadIdx.x; u < EMB_EXTRA * 17; u += NTHREADS) {
+        const int r = u / 17, k = u % 17;
+        EXW[r * 20 + k] = k < 16 ? P.wbuf[tab_i(P.wbuf, TAB_WE) + (NTHREADS + r) * EDIM + k] : P.wbuf[tab_i(P.wbuf, TAB_BE) + NTHREADS + r];
+    }
     for (int u = threadIdx.x; u < COLS17 * C0; u += NTHREADS) {
         const int col = u / C0, n = col / TV17, t = (col / 17) % T, v = col % 17;
         TT[u] = (n * T + t) | (n << 4) | (t << 6) | (v << 10);
@@ -1221,7 +1251,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 
     Prof prof;
 #ifdef MCD_PROFILE
-    prof.acc = reinterpret_cast<unsigned*>(LOSSB + PL::LOSS);
+    prof.acc = reinterpret_cast<unsigned*>(EXW + PL::EXW);
     if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
@@ -1309,12 +1339,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }
     __syncthreads();
     {
-        EmbRow er, er2;
+        EmbRow er;
         er.load(P.wbuf, tid_s);
-        er2.load(P.wbuf, emb_row2(tid_s));
         silu_row(i_first, tid_s);
         __syncthreads();
-        emb_compute<NB>(er, er2, SEN, EMB, E10 + (i_first & 1) * 16, tid_s);
+        emb_compute<NB>(er, EXW, SEN, EMB, E10 + (i_first & 1) * 16, tid_s);
         __syncthreads();
     }
     LMix<0, T, NB> mc0;                              // layer 0's mix coefficients: fetched one stage ahead like all the others,
@@ -1535,8 +1564,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             lt_dump(9, RG + PL::L9_out, 36, 32, 17);
             lt_inject(10, RG + PL::L10_in, 36, 32, 17);
             const float ca = srow[0], cb = srow[1], csg = srow[2];     // DDPM coefficients of this step (used two stages on)
-            EmbRow ef2;                                   // the 20 rows beyond the first NTHREADS: fetched here, used after
-            ef2.load(wb, emb_row2(tid));                  // the FMA product below
             float* Pb = RG + PL::L10_p;
             // P[col][r] = sum_k W4[r][k] X[col][k] for the 4 useful rows (P_t 0,1 ; P_r 2,3) with plain FMAs: as a 16-row MFMA
             // tile this product is 3/4 padding, and matrix-pipe time is what the kernel is short of.  wave = (row, block
@@ -1563,7 +1590,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             }
             STAGE(18);
             // next pass's embeddings: layers 0..9 straight into EMB (dead by now), layer 10's into the other E10 half
-            emb_compute<NB>(ef, ef2, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid);
+            emb_compute<NB>(ef, EXW, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid);
             STAGE(19);
             __syncthreads();
             STAGE(20);
@@ -1772,9 +1799,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
     for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
         const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
         float a = 0.f;
-        for (int k = part; k < F; k += 16) a = fmaf(W[jo * F + k], H[(n * TV10 + k % TV10) * 20 + k / TV10], a);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+        for (int c = 0; c < CU_OUT; ++c)
+            for (int tv = part; tv < TV10; tv += 16) a = fmaf(W[jo * F + c * TV10 + tv], H[(n * TV10 + tv) * 20 + c], a);
+        a = row16_sum(a);
         if (part == 0 && b0 + n < B) emb_out[(size_t)(b0 + n) * EDIM + jo] = a + bb[jo];
     }
 }
