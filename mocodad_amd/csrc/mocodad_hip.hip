@@ -1599,8 +1599,17 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const int e10_off = (sidx & 1) * 16;
             mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      ZeroInit{},
-                                     [&](int n, int t, int v, int c, float val) {
-                                         if (c < C0) ZO[((n * T + t) * 17 + v) * C0 + c] = val;
+                                     [&](int n, int t, int w0, int c, auto val) {     // whole 4-joint fragments: one address, 4 stores
+                                         if (c < C0) {
+                                             float* zp = ZO + ((n * T + t) * 17 + w0) * C0 + c;
+                                             if constexpr (std::is_same_v<decltype(val), f32x4>) {
+#pragma unroll
+                                                 for (int r = 0; r < 4; ++r)
+                                                     if (w0 + r < 17) zp[r * C0] = val[r];
+                                             } else {
+                                                 *zp = val;
+                                             }
+                                         }
                                      });
             __syncthreads();
             // element-wise tail of the pass, one (column, coordinate) per thread: eps = PReLU(mix(P_t) + P_r + b) + e + x
@@ -2513,7 +2522,7 @@ int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64]) {
 // small launches.
 int choose_split(int n_groups, int S, int slots) {
     // estimated makespan in units of one trajectory: rounds of workgroups x trajectories per workgroup.  Window-major pays 2 %
-    // (measured, profiles/r02e_split_ab.txt: its static schedule cannot rebalance between faster and slower CUs the way a grid
+    // (measured, profiles/r02f_split_ab.txt: its static schedule cannot rebalance between faster and slower CUs the way a grid
     // of many short workgroups does); chain-major pays its two extra launches (~0.05 trajectories).
     auto rounds = [&](long long wgs) { return (double)((wgs + slots - 1) / slots); };
     const double window_major = rounds(n_groups) * S * 1.02;
