@@ -1,0 +1,95 @@
+"""GPU: seeded random configurations of the whole forward surface against the oracle -- conditioning strategy, condition
+encoder, window length (specialised kernels and the runtime-shape fallback), loss, number of samples / steps, batch size,
+aggregation (fused in the kernel, aggregate_kernel, pose strategies), how the call is cut into workgroups.  Randomly
+initialised models with perturbed BatchNorm statistics (no reference fixture exists for these shapes); tolerance 1e-4."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_weights, make_args
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def _draw(seed):
+    r = random.Random(seed)
+    strategy = r.choice(["inject", "inject", "concat", "no_condition", "inbetween_imp", "random_imp"])
+    arch, channels, h_dim = "AE", [32, 16, 32], 32
+    if strategy == "inject":
+        arch = r.choice(["AE", "E", "E_unet"])
+        if arch == "E":
+            channels, h_dim = [r.choice([8, 24, 40]) for _ in range(r.choice([1, 2, 3]))], r.choice([8, 16, 32])
+    if strategy in ("inject", "concat"):
+        seg_len = r.choice([4, 6, 6, 7, 8, 9, 10, 12, 14])
+        if r.random() < 0.5:
+            ci = r.choice([d for d in (2, 3, 4) if seg_len // d >= 1 and seg_len - seg_len // d >= 1])     # int: first seg_len // ci frames
+        else:
+            k = r.randint(1, seg_len - 1)
+            ci = list(range(k)) if r.random() < 0.6 else list(range(seg_len - k, seg_len))
+    elif strategy == "no_condition":
+        seg_len, ci = r.choice([3, 4, 5, 6, 8, 11]), None
+    elif strategy == "inbetween_imp":
+        seg_len = r.choice([6, 8, 10, 12])
+        ci = r.choice([2, 2, sorted(r.sample(range(seg_len), r.randint(1, seg_len - 1)))])
+        if isinstance(ci, int) and seg_len % ci:
+            ci = 2
+    else:
+        seg_len = r.choice([5, 6, 8])
+        ci = r.randint(1, seg_len - 1)
+    return dict(strategy=strategy, arch=arch, channels=channels, h_dim=h_dim, seg_len=seg_len, ci=ci,
+                loss_fn=r.choice(["smooth_l1", "smooth_l1", "l1", "mse"]), S=r.choice([1, 2, 3, 5]), ns=r.choice([2, 3, 4, 6]),
+                B=r.choice([1, 2, 3, 5, 9]), split=r.choice([0, 0, 1, 99]),
+                aggr=r.choice(["best", "worst", "mean", "median", "quantile:0.4", "mean_pose", "median_pose", "all"]))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_vs_oracle(seed):
+    from mocodad_amd.models.mocodad import MoCoDAD
+    from oracle import mocodad_oracle as O
+    c = _draw(seed)
+    if c["strategy"] == "random_imp" and c["aggr"] in ("mean_pose", "median_pose"):
+        c["aggr"] = "best"
+    _, cfg = golden_weights("inject")
+    torch.manual_seed(1000 + seed)
+    m = MoCoDAD(make_args(cfg, conditioning_strategy=c["strategy"], seg_len=c["seg_len"], conditioning_indices=c["ci"],
+                          noise_steps=c["ns"], n_generated_samples=c["S"], conditioning_architecture=c["arch"], channels=c["channels"],
+                          h_dim=c["h_dim"], loss_fn=c["loss_fn"]))
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=gen) + 0.5)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.1)
+            if isinstance(mod, torch.nn.PReLU):
+                mod.weight.copy_(torch.rand(mod.weight.shape, generator=gen) * 0.3 + 0.1)
+        last = m.model.st_gcnnsu3[-1]              # keep the random eps-prediction O(1) over the chain
+        last.tcn[0].weight.mul_(0.25)
+        last.residual[0].weight.mul_(0.25)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda:0")
+    m.hip_options = {"split": c["split"]}
+    B, S, ns, T = c["B"], c["S"], c["ns"], c["seg_len"]
+    data = torch.randn(B, 2, T, 17, generator=gen).clamp_(-3, 3)
+    Tx = m.n_frames_corrupt
+    noise = torch.randn(S, max(ns - 1, 1), B, 2, Tx, 17, generator=gen)
+    mask = None
+    if c["strategy"] == "random_imp":
+        mask = torch.tensor([sum(1 << f for f in random.Random(seed * 100 + b).sample(range(T), c["ci"])) for b in range(B)], dtype=torch.int32)
+    batch = [data, torch.zeros(B), torch.zeros(B, 4), torch.zeros(B, T)]
+    out = m.forward(batch, aggr_strategy=c["aggr"], return_="all", noise=noise, cond_mask=mask)
+    only = m.forward(batch, aggr_strategy=c["aggr"], return_="loss", noise=noise, cond_mask=mask)      # loss only: the fused call
+    with torch.no_grad():
+        poses, corrupt = O.reverse_diffusion(sd, data, noise, noise_steps=ns, strategy=c["strategy"], conditioning_indices=c["ci"],
+                                             cond_mask=mask)
+        sel, loss = O.aggregate(poses, corrupt, c["aggr"], c["loss_fn"])
+    scale = max(1.0, float(loss.abs().max()))
+    msg = str(c)
+    np.testing.assert_allclose(out[0].cpu().numpy(), loss.numpy(), atol=ATOL * scale, rtol=0, err_msg=msg)
+    np.testing.assert_allclose(only[0].cpu().numpy(), loss.numpy(), atol=ATOL * scale, rtol=0, err_msg=msg)
+    if sel is not None and out[1] is not None:
+        np.testing.assert_allclose(out[1].cpu().numpy(), sel.numpy(), atol=ATOL * max(1.0, float(sel.abs().max())), rtol=1e-5, err_msg=msg)
