@@ -141,7 +141,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sd, cfg, ns, S, budget_s=15.0):
+def cpu_baseline(sd, cfg, ns, S, budget_s=20.0):
     """The oracle (a PyTorch-CPU op-for-op port of the reference path) timed on this host's cores, on a bounded sample:
     a small probe sizes the timed sample to about `budget_s` seconds; a 1-thread figure on a smaller sample beside it."""
     from oracle import mocodad_oracle as O
@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--phase", type=int, default=0, help="tuning experiment: start offset of the second half of the grid, x 1024 cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational H2D-inclusive and opt-in legs")
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample (all threads + one thread)")
     ap.add_argument("--dist-backend", default="nccl", help="'nccl' (= RCCL over xGMI, the default) or 'gloo' (tests that "
                     "place several ranks on one GPU)")
     args = ap.parse_args()
@@ -350,7 +350,9 @@ def main():
                        "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), one all-gather of scores",
                        "streams": max(args.streams, 1)},
             "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
-            "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}> (condition encoder and aggregation inside)",
+            "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (" (condition encoder and aggregation inside: one launch per step)" if args.split == 1
+                                    else (f" + cond_fast_kernel<{sc.t_cond}>" if strat == "inject" else "") + " + aggregate_kernel (the library's chain-major default: "
+                                         "3 small-to-large launches per step, 1-2 % faster than the one-launch form, profiles/r02f_split_ab.txt)"),
                          "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),
