@@ -10,7 +10,8 @@ d = np.load(os.path.join(ROOT, "tests", "golden", "weights_inject.npz"))
 w = {k: d[k] for k in d.files}
 cfg = json.loads(bytes(w.pop("__cfg__")).decode())
 sd = {k: torch.from_numpy(v) for k, v in w.items()}
-sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0,1,2], corrupt_idx=[3,4,5], cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+sc = HipScorer(sd, strategy="inject", seg_len=6, cond_idx=[0,1,2], corrupt_idx=[3,4,5], cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0",
+               options={"split": 5})      # chain-major: one trajectory pair per workgroup, as when the probe was written
 for B in (51, 102, 153, 204, 256, 307, 408, 1024):
     data = torch.randn(B, 2, 6, 17).clamp_(-5, 5).cuda()
     for _ in range(3): sc.score(data, n_samples=5, noise_steps=10, seed=1)
