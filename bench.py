@@ -226,6 +226,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
+    if world > ndev and args.dist_backend == "nccl":
+        # RCCL refuses two ranks on one GPU (and would otherwise hang in its bootstrap)
+        print(f"bench.py: {world} ranks but {ndev} GPU(s) visible; one rank per GPU is required with the nccl backend", file=sys.stderr)
+        sys.exit(2)
     dev_index = local_rank % ndev          # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
