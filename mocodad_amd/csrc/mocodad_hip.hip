@@ -376,7 +376,10 @@ struct MixCfg {
     // by the pair, no mid-stage coefficient fetch -- instead of 12 single-frame units in two rounds)
     static constexpr int Q2 = (T % 2 == 0) ? 2 : 1;
     static constexpr int units_of(int qc) { return NB * CB * (T / qc); }
-    static constexpr int QC = units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
+    // 12 frames, 64 channels: six frames per unit -- one round of 8 units instead of two of 16, every X value read once
+    // per half of the output frames (the shape has no register cap)
+    static constexpr int Q6 = (T == 12) ? 6 : 1;
+    static constexpr int QC = (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
     static constexpr int NQ = T / QC;
     static constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)

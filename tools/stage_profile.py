@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "mocodad_amd", "libmocodad_hip_prof.so")
+so = os.environ.get("MCD_PROF_LIB") or os.path.join(ROOT, "mocodad_amd", "libmocodad_hip_prof.so")
 if not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMCD_PROFILE",
                            "-o", so, os.path.join(ROOT, "mocodad_amd", "csrc", "mocodad_hip.hip")])
