@@ -126,8 +126,31 @@ __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
 // s_memtime delta of each stage to an LDS accumulator (fire-and-forget ds_add: the timing wave never waits on global
 // memory for the instrumentation); the accumulators are written to P.prof[] when the kernel ends.
 #ifdef MCD_PROFILE
-constexpr int PROF_SLOTS = 96;
+constexpr int PROF_BAR = 40;                             // barriers of one pass that get a slot
+constexpr int PROF_SLOTS = 96 + 16 + PROF_BAR * 16;      // stage times | per-wave barrier counters | wait[barrier][wave <= 16]
+// LDS byte address of the profile area of the running score kernel (0: none) -- lets bsync() find it without a parameter
+__device__ unsigned g_prof_lds;
 #endif
+// workgroup barrier; profile builds add, per wave, the cycles it waited there (block 0): which waves a stage waits for
+__device__ __forceinline__ void bsync() {
+#ifdef MCD_PROFILE
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    __syncthreads();
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        const unsigned base = *(volatile unsigned*)&g_prof_lds;
+        if (base) {
+            typedef unsigned __attribute__((address_space(3))) lds_u32;
+            lds_u32* area = (lds_u32*)(uintptr_t)(base + 96 * 4);
+            const unsigned w = threadIdx.x >> 6, idx = area[w];
+            area[w] = idx + 1;
+            if (idx < PROF_BAR) area[16 + idx * 16 + w] += (unsigned)(t1 - t0);
+        }
+    }
+#else
+    __syncthreads();
+#endif
+}
 struct Prof {
 #ifdef MCD_PROFILE
     unsigned* acc;               // LDS, PROF_SLOTS words
@@ -888,7 +911,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                                      else *zp = v;
                                  }
                              });
-    __syncthreads();
+    bsync();
     prof.mark(prof_id);
     pre_gemm();
     const float slope = lw.slope;
@@ -956,7 +979,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
         else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     pre_barrier();
-    __syncthreads();
+    bsync();
     prof.mark(prof_id + 1);
 }
 // self-contained form (condition encoder): coefficients loaded at the top of the layer
@@ -1121,7 +1144,7 @@ __device__ __forceinline__ void cond_fast_body(const float* wbuf, const DataView
         const int b = b0 + n < B ? b0 + n : B - 1;
         X0[col * 20 + c] = load_coord(dv, b, c, frame_of(t), v, seg_len);
     }
-    __syncthreads();
+    bsync();
     const float* wb = wbuf;
     auto lw = [&](int l) {
         LayerW w;
@@ -1161,7 +1184,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
     constexpr int P17 = ceil16(NB * T * 17);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int u = threadIdx.x; u < P17 * (2 * 20 + 2 * 36); u += NTHREADS) smem[u] = 0.f;
-    __syncthreads();
+    bsync();
     cond_fast_body<T, NB>(wbuf, dv, [&](int t) { return fi.idx[t]; }, seg_len, smem, blockIdx.x * NB, B, nullptr, emb_out);
 }
 
@@ -1242,46 +1265,47 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     //      MFMA stages (the shipped architecture at T condition frames), or read from the caller's (B,16) tensor
     if (P.cond_inkernel) {
         for (int u = tid; u < PL::R; u += NTHREADS) smem[u] = 0.f;
-        __syncthreads();
+        bsync();
         cond_fast_body<T, NB>(P.wbuf, P.dv, [&](int t) { return P.cond_idx[t]; }, P.seg_len, smem, win0, P.B, CE, nullptr);
-        __syncthreads();
+        bsync();
     } else if (threadIdx.x < NB * EDIM) {
         CE[threadIdx.x] = P.cond_emb ? P.cond_emb[(size_t)window_of(threadIdx.x / EDIM) * EDIM + threadIdx.x % EDIM] : 0.f;
     }
     // zero the whole activation area once: pad columns / pad channels must hold finite values
     for (int u = tid; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
-    __syncthreads();
+    bsync();
 
     Prof prof;
 #ifdef MCD_PROFILE
     prof.acc = reinterpret_cast<unsigned*>(EXW + PL::EXW);
-    if (tid0 < PROF_SLOTS) prof.acc[tid0] = 0u;     // a barrier follows before the first mark
+    for (int i = tid0; i < PROF_SLOTS; i += NTHREADS) prof.acc[i] = 0u;     // a barrier follows before the first mark
+    if (tid0 == 0 && blockIdx.x == 0) g_prof_lds = P.prof ? lds_addr(EXW + PL::EXW) : 0u;
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
 #endif
     // layer test: (B,C,T,V) global tensor <-> LDS region [col = (n,t,v)][channel]
     auto lt_inject = [&](int id, float* region, int cs, int C, int V) {
         if constexpr (LT) {
             if (P.lt_stage == id) {
-                __syncthreads();
+                bsync();
                 for (int u = threadIdx.x; u < NB * C * T * V; u += NTHREADS) {
                     const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % C, n = u / (V * T * C);
                     const int b = window_of(n);
                     region[((n * T + t) * V + v) * cs + c] = P.lt_in[(((size_t)b * C + c) * T + t) * V + v];
                 }
-                __syncthreads();
+                bsync();
             }
         }
     };
     auto lt_dump = [&](int id, const float* region, int cs, int C, int V) {
         if constexpr (LT) {
             if (P.lt_stage == id) {
-                __syncthreads();
+                bsync();
                 for (int u = threadIdx.x; u < NB * C * T * V; u += NTHREADS) {
                     const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % C, n = u / (V * T * C);
                     const int b = win0 + n;
                     if (b < P.B) P.lt_out[(((size_t)b * C + c) * T + t) * V + v] = region[((n * T + t) * V + v) * cs + c];
                 }
-                __syncthreads();
+                bsync();
             }
         }
     };
@@ -1340,14 +1364,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             XT[u * 4 + 1] = xv[1];
         }
     }
-    __syncthreads();
+    bsync();
     {
         EmbRow er;
         er.load(P.wbuf, tid_s);
         silu_row(i_first, tid_s);
-        __syncthreads();
+        bsync();
         emb_compute<NB>(er, EXW, SEN, EMB, E10 + (i_first & 1) * 16, tid_s);
-        __syncthreads();
+        bsync();
     }
     LMix<0, T, NB> mc0;                              // layer 0's mix coefficients: fetched one stage ahead like all the others,
     mc0.load(P.wbuf + tab_i(P.wbuf, F_TQ), P.wbuf + tab_i(P.wbuf, F_AM), wave, lane);   // i.e. in the last stage of the previous pass
@@ -1397,6 +1421,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         noise_part(tid);
         STAGE(0);
         STAGE(1);
+#ifdef MCD_PROFILE
+        if (lane == 0) prof.acc[96 + wave] = 0u;       // barrier slots count from the top of the pass
+#endif
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
         // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.
         auto mixload = [&](auto& mc, int l) { mc.load(wb + tab_i(wb, l * F_STRIDE + F_TQ), wb + tab_i(wb, l * F_STRIDE + F_AM), wave, lane); };
@@ -1432,7 +1459,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         LMix<3, T, NB> mc3;
         mix_early(mc3, 3);
         resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
-        __syncthreads();
+        bsync();
         STAGE(5);
         lt_dump(11, RG + PL::DN1_out, 36, 32, 12);
         lt_inject(3, RG + PL::L3_in, 36, 32, 12);
@@ -1453,7 +1480,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
-        if constexpr (!FUSE64) __syncthreads();
+        if constexpr (!FUSE64) bsync();
         STAGE(8);
         lt_dump(12, RG + PL::DN2_out, 68, 64, 10);
         lt_inject(5, RG + PL::L5_in, 68, 64, 10);
@@ -1490,7 +1517,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
                 }
             }
-            __syncthreads();
+            bsync();
             STAGE(10);
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);
@@ -1514,7 +1541,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         RsCoef<64, 10, 12, T, NB, false> rc3;
         rs_early(rc3, 2);
-        if constexpr (!FUSE64) __syncthreads();     // aligned: up3 reads only this wave's own layer-6 output block
+        if constexpr (!FUSE64) bsync();     // aligned: up3 reads only this wave's own layer-6 output block
         STAGE(11);
         lt_dump(6, RG + PL::L6_p + 64, 132, 64, 10);
         lt_inject(13, RG + PL::L6_p + 64, 132, 64, 10);
@@ -1526,7 +1553,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         LMix<7, T, NB> mc7;
         mix_early(mc7, 7);
         resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
-        __syncthreads();
+        bsync();
         STAGE(12);
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
         lt_inject(7, RG + PL::L7_in, 68, 64, 12);
@@ -1545,7 +1572,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         LMix<9, T, NB> mc9;
         mix_early(mc9, 9);
         resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
-        __syncthreads();
+        bsync();
         STAGE(15);
         lt_dump(14, RG + PL::UP2_out, 36, 32, 17);
         lt_inject(9, RG + PL::L9_in, 36, 32, 17);
@@ -1595,7 +1622,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // next pass's embeddings: layers 0..9 straight into EMB (dead by now), layer 10's into the other E10 half
             emb_compute<NB>(ef, EXW, SEN, EMB, E10 + ((sidx - 1) & 1) * 16, tid);
             STAGE(19);
-            __syncthreads();
+            bsync();
             STAGE(20);
             const float slope10 = lw.slope;
             const bool single = P.mode == 1, zadd = sidx > 1;
@@ -1614,7 +1641,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                              }
                                          }
                                      });
-            __syncthreads();
+            bsync();
             // element-wise tail of the pass, one (column, coordinate) per thread: eps = PReLU(mix(P_t) + P_r + b) + e + x
             // (layer 10 + the U-Net's residual), then the DDPM update of the frame this prediction drives and the next
             // pass's input block.  (Inside the mix's store functor this ran on 2 of every 16 lanes of 6 waves.)
@@ -1654,13 +1681,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     }
                 }
             }
-            if (P.upd_shift) __syncthreads();
+            if (P.upd_shift) bsync();
 #pragma unroll
             for (int it = 0; it < TAIL_IT; ++it)
                 if (dst_t[it] >= 0) XT[dst_t[it]] = xn_t[it];
             mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);      // for the next pass
             STAGE(21);
-            __syncthreads();
+            bsync();
             STAGE(17);
         }
     }
@@ -1701,7 +1728,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             RED[u] = l;
             if (valid && pose_out) pose_out[(size_t)(b * Sq + s) * per + e] = x0;
         }
-        __syncthreads();
+        bsync();
         // two-level sum in a fixed order, through LDS: 8 partial sums per chain, then one thread per chain.  (A wave shuffle
         // reduction needs the lane id, which the compiler computes at kernel entry and keeps alive -- spilled -- across the
         // whole trajectory; this runs once per sample.)
@@ -1712,7 +1739,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             for (int e = p8; e < per; e += 8) sum += RED[n * per + e];
             PART[tid_s] = sum;
         }
-        __syncthreads();
+        bsync();
         if (tid_s < NB) {
             const int n = tid_s;
             float sum = 0.f;
@@ -1723,10 +1750,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (s < 64) LOSSB[n * 64 + s] = l;
         }
     }
-    __syncthreads();        // RED (the work region) and XT are rewritten by the next sample
+    bsync();        // RED (the work region) and XT are rewritten by the next sample
     }   // samples
 #ifdef MCD_PROFILE
-    if (prof.on) for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];    // thread 0's own ds_adds: in order
+    if (prof.on) { for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i]; g_prof_lds = 0u; }   // thread 0's own ds_adds: in order
 #endif
     // ---- aggregation over the samples (mocodad.py:454-520; loss-based strategies), when this workgroup has seen them all
     int te = tid0;

@@ -1,20 +1,24 @@
 # Round-2 profile set of the final kernels: bench lines, kernel traces and PMC passes of the three trajectory-kernel shapes,
-# the one-launch (window-major) variant of the default workload, and the split A/B.   usage: gpurun -- bash tools/r02_profile.sh <tag>
+# the one-launch (window-major) variant of the default workload, and the split A/B.   usage: gpurun -- bash tools/r02_profile.sh <tag> ["<configs>"]
 set -x
 TAG=${1:-r02e}
+CFGS=${2:-"avenue stc ubnormal_concat seq24"}
+PCFGS=${2:-"avenue avenue_onelaunch ubnormal_concat seq24"}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-for c in avenue stc ubnormal_concat seq24; do
+for c in $CFGS; do
   st=20; [ $c = seq24 ] && st=5
   timeout 400 python bench.py --config $c --steps $st > $O/bench_$c.json 2> $O/bench_$c.err
 done
+if [ -z "$2" ]; then
 # chain-major (default, 3 launches) vs window-major (one launch) on this box, interleaved
 { for rep in 1 2 3; do for sp in 5 1; do echo -n "avenue B=1024 split=$sp: "; python bench.py --split $sp --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'clips/s  frac', d['roofline']['frac'], ' kernel ms/step', d['roofline']['kernel_ms_per_step'])"; done; done
   for sp in 5 1; do echo -n "avenue B=4096 split=$sp: "; python bench.py --batch 4096 --split $sp --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'clips/s  frac', d['roofline']['frac'])"; done; } > $O/split_ab.txt 2>&1
+fi
 cd /tmp && export TMPDIR=/tmp
-for c in avenue avenue_onelaunch ubnormal_concat seq24; do
+for c in $PCFGS; do
   st=20; ex=""; cfg=$c
   [ $c = seq24 ] && st=3 && ex="--batch 1024"
   [ $c = avenue_onelaunch ] && cfg=avenue && ex="--split 1"
@@ -30,4 +34,4 @@ for c in avenue avenue_onelaunch ubnormal_concat seq24; do
   python $R/tools/pmc_summary.py $(find $O/pmc_${c}_* -name "*_results.db") > $O/${c}_pmc.txt
   rm -rf $O/pmc_${c}_*
 done
-ls -la $O; cat $O/split_ab.txt
+ls -la $O; [ -f $O/split_ab.txt ] && cat $O/split_ab.txt

@@ -28,7 +28,7 @@ sc = HipScorer(sd, strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"]
 B = min(B, 1024)
 NS = min(NS, 10)
 L = _lib.lib()
-prof = torch.zeros(96, dtype=torch.int64, device="cuda:0")
+prof = torch.zeros(1024, dtype=torch.int64, device="cuda:0")
 data = bench.synth_windows(B, cfg["seg_len"], 1).cuda()
 sc.score(data, n_samples=S, noise_steps=NS, seed=1)
 torch.cuda.synchronize()
@@ -57,3 +57,13 @@ for i, (n, v) in enumerate(zip(names, p)):
     if i == 17:
         extra = f"   product {sub10[0]/NP:6.0f}  zero+emb {sub10[1]/NP:6.0f}  barrier {sub10[2]/NP:6.0f}  mix+barrier+tail {sub10[3]/NP:6.0f}  barrier {(v - sub10.sum())/NP:6.0f}"
     print(f"  {n:14s} {v/NP:9.0f}  {100*v/tot:5.1f}%{extra}")
+
+# per-wave cycles spent waiting at each barrier of a pass (the wave with the smallest wait arrived last: the stage's critical path)
+bar = p[96 + 16:96 + 16 + 40 * 16].reshape(40, 16) / NP
+nw = int((bar.sum(0) > 0).sum())
+if nw:
+    print(f"\nbarrier waits per pass (cycles), {nw} waves: barrier | per wave | min  mean")
+    for i in range(40):
+        if bar[i, :nw].sum() > 0:
+            print(f"  {i:2d} | " + " ".join(f"{x:6.0f}" for x in bar[i, :nw]) + f" | {bar[i, :nw].min():6.0f} {bar[i, :nw].mean():6.0f}")
+    print(f"  sum of per-barrier minima {bar[:, :nw].min(1).sum():.0f}   mean wait per wave {bar[:, :nw].sum(0).mean():.0f}   (pass total {tot/NP:.0f})")
