@@ -126,8 +126,10 @@ __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
 // s_memtime delta of each stage to an LDS accumulator (fire-and-forget ds_add: the timing wave never waits on global
 // memory for the instrumentation); the accumulators are written to P.prof[] when the kernel ends.
 #ifdef MCD_PROFILE
-constexpr int PROF_BAR = 40;                             // barriers of one pass that get a slot
-constexpr int PROF_SLOTS = 96 + 16 + PROF_BAR * 16;      // stage times | per-wave barrier counters | wait[barrier][wave <= 16]
+constexpr int PROF_STAGE = 72;                           // stage-time slots
+constexpr int PROF_BAR = 30;                             // barriers of one pass that get a slot
+constexpr int PROF_NW = NWAVES;                         // (small on purpose: the 3-frame plan has 1.3 KB to spare below 2 workgroups per CU)
+constexpr int PROF_SLOTS = PROF_STAGE + PROF_NW + PROF_BAR * PROF_NW;   // stage times | per-wave barrier counters | wait[barrier][wave]
 // LDS byte address of the profile area of the running score kernel (0: none) -- lets bsync() find it without a parameter
 __device__ unsigned g_prof_lds;
 #endif
@@ -141,10 +143,10 @@ __device__ __forceinline__ void bsync() {
         const unsigned base = *(volatile unsigned*)&g_prof_lds;
         if (base) {
             typedef unsigned __attribute__((address_space(3))) lds_u32;
-            lds_u32* area = (lds_u32*)(uintptr_t)(base + 96 * 4);
+            lds_u32* area = (lds_u32*)(uintptr_t)(base + PROF_STAGE * 4);
             const unsigned w = threadIdx.x >> 6, idx = area[w];
             area[w] = idx + 1;
-            if (idx < PROF_BAR) area[16 + idx * 16 + w] += (unsigned)(t1 - t0);
+            if (idx < PROF_BAR) area[PROF_NW + idx * PROF_NW + w] += (unsigned)(t1 - t0);
         }
     }
 #else
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(0);
         STAGE(1);
 #ifdef MCD_PROFILE
-        if (lane == 0) prof.acc[96 + wave] = 0u;       // barrier slots count from the top of the pass
+        if (lane == 0) prof.acc[PROF_STAGE + wave] = 0u;       // barrier slots count from the top of the pass
 #endif
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
         // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.

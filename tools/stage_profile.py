@@ -59,11 +59,11 @@ for i, (n, v) in enumerate(zip(names, p)):
     print(f"  {n:14s} {v/NP:9.0f}  {100*v/tot:5.1f}%{extra}")
 
 # per-wave cycles spent waiting at each barrier of a pass (the wave with the smallest wait arrived last: the stage's critical path)
-bar = p[96 + 16:96 + 16 + 40 * 16].reshape(40, 16) / NP
-nw = int((bar.sum(0) > 0).sum())
-if nw:
-    print(f"\nbarrier waits per pass (cycles), {nw} waves: barrier | per wave | min  mean")
-    for i in range(40):
-        if bar[i, :nw].sum() > 0:
-            print(f"  {i:2d} | " + " ".join(f"{x:6.0f}" for x in bar[i, :nw]) + f" | {bar[i, :nw].min():6.0f} {bar[i, :nw].mean():6.0f}")
-    print(f"  sum of per-barrier minima {bar[:, :nw].min(1).sum():.0f}   mean wait per wave {bar[:, :nw].sum(0).mean():.0f}   (pass total {tot/NP:.0f})")
+NW = int(os.environ.get("MCD_NWAVES", "8"))           # PROF_NW of the build
+bar = p[72 + NW:72 + NW + 30 * NW].reshape(30, NW) / NP
+if bar.sum() > 0:
+    print(f"\nbarrier waits per pass (cycles), {NW} waves: barrier | per wave | min  mean")
+    for i in range(30):
+        if bar[i].sum() > 0:
+            print(f"  {i:2d} | " + " ".join(f"{x:6.0f}" for x in bar[i]) + f" | {bar[i].min():6.0f} {bar[i].mean():6.0f}")
+    print(f"  sum of per-barrier minima {bar.min(1).sum():.0f}   mean wait per wave {bar.sum(0).mean():.0f}   (pass total {tot/NP:.0f})")
