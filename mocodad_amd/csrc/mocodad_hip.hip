@@ -1316,6 +1316,18 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     using RS2 = RsCfg<64, 12, 10, T, NB, true>;
     float skip1[RS1::PER * RS1::SK];
     float skip2[RS2::PER * RS2::SK];
+    // 6 frames under the 128-VGPR cap (two workgroups per CU): d2 does not fit beside the 128-channel layers' fragments and
+    // the register allocator spilled it where it was read (before its own use) and reloaded it in front of every consumer.
+    // Parked in private memory by hand instead -- stored after down2 has used it, fetched back in front of the barrier
+    // that precedes up3, whose MFMAs run before the skip values are added: the round trip is off the critical path.
+#ifndef MCD_STASH
+#define MCD_STASH 1
+#endif
+    constexpr bool STASH2 = !LT && MINW >= 4 && ((T == 6 && (MCD_STASH & 1)) || (T == 3 && (MCD_STASH & 4)));
+    constexpr bool STASH1 = !LT && MINW >= 4 && ((T == 6 && (MCD_STASH & 2)) || (T == 3 && (MCD_STASH & 8)));
+    float stash1_mem[STASH1 ? RS1::PER * RS1::SK : 1];
+    float stash2_mem[STASH2 ? RS2::PER * RS2::SK : 1];
+    typedef float __attribute__((address_space(5))) priv_float;         // (explicit private address space: scratch_*, not flat_*)
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
@@ -1461,6 +1473,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         LMix<3, T, NB> mc3;
         mix_early(mc3, 3);
         resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
+        if constexpr (STASH1) {
+            priv_float* sp = (priv_float*)stash1_mem;
+            asm volatile("" : "+v"(sp));
+#pragma unroll
+            for (int i = 0; i < RS1::PER * RS1::SK; ++i) sp[i] = skip1[i];
+        }
         bsync();
         STAGE(5);
         lt_dump(11, RG + PL::DN1_out, 36, 32, 12);
@@ -1480,6 +1498,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         LMix<5, T, NB> mc5;
         mix_early(mc5, 5);
         resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
+        if constexpr (STASH2) {
+            priv_float* sp = (priv_float*)stash2_mem;
+            asm volatile("" : "+v"(sp));            // opaque: the array stays in memory, plain (cached) scratch accesses
+#pragma unroll
+            for (int i = 0; i < RS2::PER * RS2::SK; ++i) sp[i] = skip2[i];
+        }
         // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
         if constexpr (!FUSE64) bsync();
@@ -1541,6 +1565,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                          if (w0 + 2 < 10) { pp[264] = r1[0]; pp[396] = r1[1]; }
                                      });
         }
+        if constexpr (STASH2) {
+            const priv_float* sp = (const priv_float*)stash2_mem;
+            asm volatile("" : "+v"(sp));
+#pragma unroll
+            for (int i = 0; i < RS2::PER * RS2::SK; ++i) skip2[i] = sp[i];
+        }
         RsCoef<64, 10, 12, T, NB, false> rc3;
         rs_early(rc3, 2);
         if constexpr (!FUSE64) bsync();     // aligned: up3 reads only this wave's own layer-6 output block
@@ -1567,7 +1597,15 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_inject(8, RG + PL::L8_in, 68, 64, 12);
         RsCoef<32, 12, 17, T, NB, false> rc4;
         layer_std<8, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
-                            [&] { rs_early(rc4, 3); }, nohook);                                            // su4.1
+                            [&] { rs_early(rc4, 3); },
+                            [&] {
+                                if constexpr (STASH1) {
+                                    const priv_float* sp = (const priv_float*)stash1_mem;
+                                    asm volatile("" : "+v"(sp));
+#pragma unroll
+                                    for (int i = 0; i < RS1::PER * RS1::SK; ++i) skip1[i] = sp[i];
+                                }
+                            });                                            // su4.1
         STAGE(14);
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
