@@ -40,7 +40,7 @@ PMC_PROFILES = {"avenue": ("profiles/r02f_avenue_pmc.txt", 1024, 10, 5), "ubnorm
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
 
 
-def pmc_profile(config, B, ns, S, flop_per_window, kern_ms):
+def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
     """Per-launch HBM bytes (FETCH_SIZE x 2, the guide's gfx950 correction, + WRITE_SIZE, all kernels of a step) and the
     matrix-pipe statistics of the trajectory kernel from the committed PMC profile of this configuration."""
     if config not in PMC_PROFILES:
@@ -68,12 +68,18 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms):
         mfma *= scale
         # 16x16x4 fp32 MFMAs: 2048 FLOP and 32 cycles of one of the 1024 SIMDs each
         out["mfma_issued_per_launch"] = round(mfma)
-        out["useful_mfma_frac"] = round(min(1.0, B * flop_per_window / 2048.0 / mfma), 4)
+        # the time mix (2 T^2 FLOP per (input channel, joint) of each of the 11 layers: sum of C_in V = 5396) runs on the
+        # VALU (DPP FMAs), everything else on the matrix cores; what the issued MFMAs exceed that by is tile padding
+        vec_flop = S * (ns - 1) * 2 * t_unet * t_unet * 5396
+        out["useful_mfma_frac"] = round(min(1.0, B * (flop_per_window - vec_flop) / 2048.0 / mfma), 4)
         out["mfma_pipe_busy_frac"] = round(mfma * 32 / (1024 * CLOCK_GHZ * 1e9 * kern_ms * 1e-3), 4)
         if "SQ_INSTS_VALU" in sk:
             out["other_valu_per_mfma"] = round((sk["SQ_INSTS_VALU"] * scale - mfma) / mfma, 3)
-    if (B, ns, S) == (pB, pns, pS) and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in kernels.values()):
-        out["hbm_bytes_per_step"] = sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in kernels.values()) * 1024.0
+    if (ns, S) == (pns, pS) and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in kernels.values()):
+        # same chain length: the bytes of a launch scale with its windows (inputs, scores, per-workgroup weight fetches, spills)
+        out["hbm_bytes_per_step"] = sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in kernels.values()) * 1024.0 * B / float(pB)
+        if B != pB:
+            out["hbm_bytes_scaled_from_windows"] = pB
     return out
 
 
@@ -340,7 +346,7 @@ def main():
         P = S * (ns - 1)
         flop_per_window = P * F_UNET[sc.t_unet] + (F_COND[sc.t_cond] if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
-        pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms)
+        pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
         nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2"}[sc.t_unet]
         out = {
             "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
