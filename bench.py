@@ -202,8 +202,11 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 5 for seq24: 0.39 s per step)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps right before the timed ones (default 20; 2 for seq24)")
+    ap.add_argument("--preroll-ms", type=float, default=200.0,
+                    help="untimed steps run for this long BEFORE the warm-up, to bring the GPU out of its idle clocks (the sclk ramp from "
+                         "~100 MHz takes tens of ms: tools/clock_probe.sh; with 3 warm-up steps = 7 ms the first timed steps ran below 2.4 GHz)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="avenue", help="workload shape (default: BASELINE configs[1])")
     ap.add_argument("--batch", type=int, default=None, help="windows per step: per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--noise-steps", type=int, default=None)
@@ -223,6 +226,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="'nccl' (= RCCL over xGMI, the default) or 'gloo' (tests that "
                     "place several ranks on one GPU)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 5 if args.config == "seq24" else 200
+    if args.warmup is None:
+        args.warmup = 2 if args.config == "seq24" else 20
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
@@ -314,10 +321,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the timed steps' events exist (hipEventCreate, signal pool growth) before anything is timed: torch creates them lazily
+    # at their first record(), which would otherwise happen inside the timed loop
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a_, b_ in ev:
+        a_.record()
+        b_.record()
+    torch.cuda.synchronize()
+    preroll_steps = 0
+    if args.preroll_ms > 0 and B > 0:
+        t_pre = time.perf_counter()
+        pre_out = torch.zeros(per, device=dev, dtype=torch.float32)
+        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:      # local launches only: no collective, ranks may differ
+            sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation="best", seed=preroll_steps, first_window_id=lo, out=pre_out[:B])
+            torch.cuda.synchronize()
+            preroll_steps += 1
     if args.warmup > 0:
         run(sc, args.warmup, 0)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     best = run(sc, args.steps, 100, ev)
     barrier()
@@ -350,7 +371,7 @@ def main():
         nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2"}[sc.t_unet]
         out = {
             "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
-            "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "bf16x3 split operands, f32 accumulate (opt-in)" if args.bf16x3 else "f32", "data": "synthetic",
             "config": {"workload": f"{desc}, noise_steps={ns}, {S} generated samples, {strat} conditioning, 'best' aggregation",
@@ -360,6 +381,8 @@ def main():
                        "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), one all-gather of scores",
                        "streams": max(args.streams, 1)},
             "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
+            "step_ms_first": [round(float(v), 4) for v in step_ms[:4]] if B > 0 else None,
+            "step_ms_max": [round(float(np.max(step_ms)), 4), int(np.argmax(step_ms))] if B > 0 else None,    # [ms, step index]
             "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (" (condition encoder and aggregation inside: one launch per step)" if args.split == 1
                                     else (f" + cond_fast_kernel<{sc.t_cond}>" if strat == "inject" else "") + " + aggregate_kernel (the library's chain-major default: "
                                          "3 small-to-large launches per step, 1-2 % faster than the one-launch form, profiles/r02f_split_ab.txt)"),
