@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/r02_profile.sh): per-launch counter averages
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
-PMC_PROFILES = {"avenue": ("profiles/r02f_avenue_pmc.txt", 1024, 10, 5), "ubnormal_concat": ("profiles/r02g_ubnormal_concat_pmc.txt", 1024, 10, 5),
-                "seq24": ("profiles/r02g_seq24_pmc.txt", 1024, 50, 8)}
+PMC_PROFILES = {"avenue": ("profiles/r02i_avenue_pmc.txt", 1024, 10, 5), "ubnormal_concat": ("profiles/r02i_ubnormal_concat_pmc.txt", 1024, 10, 5),
+                "seq24": ("profiles/r02i_seq24_pmc.txt", 1024, 50, 8)}
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
 
 
@@ -385,7 +385,7 @@ def main():
             "step_ms_max": [round(float(np.max(step_ms)), 4), int(np.argmax(step_ms))] if B > 0 else None,    # [ms, step index]
             "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (" (condition encoder and aggregation inside: one launch per step)" if args.split == 1
                                     else (f" + cond_fast_kernel<{sc.t_cond}>" if strat == "inject" else "") + " + aggregate_kernel (the library's chain-major default: "
-                                         "3 small-to-large launches per step, 1-2 % faster than the one-launch form, profiles/r02f_split_ab.txt)"),
+                                         "3 small-to-large launches per step, 1-2 % faster than the one-launch form, profiles/r02i_split_ab.txt)"),
                          "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),

@@ -9,8 +9,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 for c in $CFGS; do
-  st=20; [ $c = seq24 ] && st=5
-  timeout 400 python bench.py --config $c --steps $st > $O/bench_$c.json 2> $O/bench_$c.err
+  timeout 400 python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err
 done
 if [ -z "$2" ]; then
 # chain-major (default, 3 launches) vs window-major (one launch) on this box, interleaved
@@ -19,17 +18,17 @@ if [ -z "$2" ]; then
 fi
 cd /tmp && export TMPDIR=/tmp
 for c in $PCFGS; do
-  st=20; ex=""; cfg=$c
-  [ $c = seq24 ] && st=3 && ex="--batch 1024"
+  st=""; ex=""; cfg=$c                      # kernel trace: bench.py's own default steps / warm-up (the command of the bench line)
+  [ $c = seq24 ] && st="--steps 3 --warmup 2" && ex="--batch 1024"
   [ $c = avenue_onelaunch ] && cfg=avenue && ex="--split 1"
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$c -- python $R/bench.py --config $cfg --steps $st --warmup 2 --no-cpu-baseline --no-extras $ex > $O/prof_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$c -- python $R/bench.py --config $cfg $st --no-cpu-baseline --no-extras $ex > $O/prof_$c.log 2>&1
   python $R/tools/rocpd_summary.py $(find $O/prof_$c -name "*_results.db" | head -1) > $O/${c}_kernel_stats.txt
   rm -rf $O/prof_$c
   [ $c = avenue_onelaunch ] && continue
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc_${c}_$i -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-extras $ex > $O/pmc_${c}_$i.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc_${c}_$i -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --preroll-ms 0 --no-cpu-baseline --no-extras $ex > $O/pmc_${c}_$i.log 2>&1
   done
   python $R/tools/pmc_summary.py $(find $O/pmc_${c}_* -name "*_results.db") > $O/${c}_pmc.txt
   rm -rf $O/pmc_${c}_*
