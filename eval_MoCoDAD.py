@@ -47,7 +47,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % torch.cuda.device_count()   # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
+    ndev = torch.cuda.device_count()
+    if world > ndev and cli.dist_backend == "nccl":
+        # RCCL refuses two ranks on one GPU (and would otherwise hang in its bootstrap)
+        raise SystemExit(f"eval_MoCoDAD.py: {world} ranks but {ndev} GPU(s) visible; the nccl backend needs one rank per GPU "
+                         "(--dist-backend gloo is for tests that share a GPU)")
+    local = local % ndev   # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     use_dist = world > 1 or "LOCAL_RANK" in os.environ     # under torch.distributed.run: RCCL path even with one rank

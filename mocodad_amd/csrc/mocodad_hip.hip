@@ -129,35 +129,18 @@ __device__ __forceinline__ LayerW layer_w(const float* base, int l) {
 constexpr int PROF_STAGE = 72;                           // stage-time slots
 constexpr int PROF_BAR = 30;                             // barriers of one pass that get a slot
 constexpr int PROF_NW = NWAVES;                         // (small on purpose: the 3-frame plan has 1.3 KB to spare below 2 workgroups per CU)
-constexpr int PROF_SLOTS = PROF_STAGE + PROF_NW + PROF_BAR * PROF_NW;   // stage times | per-wave barrier counters | wait[barrier][wave]
-// LDS byte address of the profile area of the running score kernel (0: none) -- lets bsync() find it without a parameter
-__device__ unsigned g_prof_lds;
+constexpr int PROF_SLOTS = PROF_STAGE + PROF_NW + PROF_BAR * PROF_NW;   // stage times | (unused) | wait[barrier][wave]
 #endif
-// workgroup barrier; profile builds add, per wave, the cycles it waited there (block 0): which waves a stage waits for
-__device__ __forceinline__ void bsync() {
-#ifdef MCD_PROFILE
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    __syncthreads();
-    const unsigned long long t1 = __builtin_readcyclecounter();
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-        const unsigned base = *(volatile unsigned*)&g_prof_lds;
-        if (base) {
-            typedef unsigned __attribute__((address_space(3))) lds_u32;
-            lds_u32* area = (lds_u32*)(uintptr_t)(base + PROF_STAGE * 4);
-            const unsigned w = threadIdx.x >> 6, idx = area[w];
-            area[w] = idx + 1;
-            if (idx < PROF_BAR) area[PROF_NW + idx * PROF_NW + w] += (unsigned)(t1 - t0);
-        }
-    }
-#else
-    __syncthreads();
-#endif
-}
+// Everything the instrumentation needs lives in registers of the profiled workgroup (block 0): the timing adds are
+// fire-and-forget LDS atomics, no global memory access, no LDS round trip on the waves' paths.
 struct Prof {
 #ifdef MCD_PROFILE
     unsigned* acc;               // LDS, PROF_SLOTS words
     unsigned long long tlast;
-    bool on;
+    bool on;                     // thread 0 of block 0: stage times
+    bool won;                    // lane 0 of every wave of block 0: barrier waits
+    int bidx;                    // barrier index inside the pass (wave-uniform)
+    int wv;
     __device__ __forceinline__ void mark(int id) {
         if (on) {
             const unsigned long long t = __builtin_readcyclecounter();
@@ -165,10 +148,24 @@ struct Prof {
             tlast = t;
         }
     }
+    // workgroup barrier + the cycles this wave waited there (which waves a stage waits for)
+    __device__ __forceinline__ void sync() {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        __syncthreads();
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        if (won && bidx < PROF_BAR)
+            __hip_atomic_fetch_add(acc + PROF_STAGE + PROF_NW + bidx * PROF_NW + wv, (unsigned)(t1 - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++bidx;
+    }
+    __device__ __forceinline__ void off() { on = false; won = false; acc = nullptr; tlast = 0; bidx = 0; wv = 0; }
 #else
     __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ void off() {}
 #endif
 };
+// workgroup barrier: every scope that synchronises has a `Prof prof` in reach
+#define bsync() prof.sync()
 #define STAGE(id) prof.mark(id)
 
 // where the windows live: a dense (B,C,T,V) tensor, or a view into trajectory buffers with an optional affine
@@ -329,7 +326,7 @@ __device__ __forceinline__ float aggregate_losses(float* L, int S, int strategy,
         L[k + 1] = x;
     }
     if (strategy == MCD_AGGR_MEDIAN) return L[(S - 1) / 2];
-    const float pos = q * (float)(S - 1);
+    const float pos = fminf(fmaxf(q, 0.f), 1.f) * (float)(S - 1);      // (q is validated on the host; the clamp is a backstop)
     const int lo = (int)floorf(pos);
     const int hi = lo + 1 < S ? lo + 1 : S - 1;
     const float wgt = pos - (float)lo;
@@ -1137,9 +1134,7 @@ __device__ __forceinline__ void cond_fast_body(const float* wbuf, const DataView
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Prof prof;
-#ifdef MCD_PROFILE
-    prof.on = false; prof.acc = nullptr; prof.tlast = 0;
-#endif
+    prof.off();
     for (int u = tid; u < COLS * C0; u += NTHREADS) {
         const int c = u % C0, col = u / C0;
         const int n = col / TV, t = (col / 17) % T, v = col % 17;
@@ -1186,7 +1181,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_fast_kernel(const float* wbu
     constexpr int P17 = ceil16(NB * T * 17);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int u = threadIdx.x; u < P17 * (2 * 20 + 2 * 36); u += NTHREADS) smem[u] = 0.f;
-    bsync();
+    __syncthreads();
     cond_fast_body<T, NB>(wbuf, dv, [&](int t) { return fi.idx[t]; }, seg_len, smem, blockIdx.x * NB, B, nullptr, emb_out);
 }
 
@@ -1218,6 +1213,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int tid = tid0;
     int lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Prof prof;
+    prof.off();
     if (P.phase > 0 && blockIdx.x * 2 >= gridDim.x) {
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)P.phase * 1024ull) __builtin_amdgcn_s_sleep(32);
@@ -1277,12 +1274,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     for (int u = tid; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
     bsync();
 
-    Prof prof;
 #ifdef MCD_PROFILE
     prof.acc = reinterpret_cast<unsigned*>(EXW + PL::EXW);
     for (int i = tid0; i < PROF_SLOTS; i += NTHREADS) prof.acc[i] = 0u;     // a barrier follows before the first mark
-    if (tid0 == 0 && blockIdx.x == 0) g_prof_lds = P.prof ? lds_addr(EXW + PL::EXW) : 0u;
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
+    prof.won = ((tid0 & 63) == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.wv = tid0 >> 6;
+    __syncthreads();
 #endif
     // layer test: (B,C,T,V) global tensor <-> LDS region [col = (n,t,v)][channel]
     auto lt_inject = [&](int id, float* region, int cs, int C, int V) {
@@ -1436,7 +1433,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(0);
         STAGE(1);
 #ifdef MCD_PROFILE
-        if (lane == 0) prof.acc[PROF_STAGE + wave] = 0u;       // barrier slots count from the top of the pass
+        prof.bidx = 0;                                         // barrier slots count from the top of the pass
 #endif
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
         // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.
@@ -1793,7 +1790,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     bsync();        // RED (the work region) and XT are rewritten by the next sample
     }   // samples
 #ifdef MCD_PROFILE
-    if (prof.on) { for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i]; g_prof_lds = 0u; }   // thread 0's own ds_adds: in order
+    __syncthreads();
+    if (prof.on) { for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i]; }
 #endif
     // ---- aggregation over the samples (mocodad.py:454-520; loss-based strategies), when this workgroup has seen them all
     int te = tid0;
@@ -1830,9 +1828,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * NB;
     Prof prof;
-#ifdef MCD_PROFILE
-    prof.on = false; prof.acc = nullptr; prof.tlast = 0;
-#endif
+    prof.off();
     for (int u = tid; u < CondUnetLds<T, NB>::FLOATS; u += NTHREADS) smem[u] = 0.f;
     __syncthreads();
     for (int u = tid; u < COLS17 * C0; u += NTHREADS) {
@@ -2016,7 +2012,7 @@ __global__ void aggregate_kernel(const AggrParams P) {
         if (P.strategy == MCD_AGGR_MEDIAN) {
             P.loss_agg[b] = tmp[(S - 1) / 2];  // torch.median: lower of the two middle values
         } else {
-            const float pos = P.q * (float)(S - 1);
+            const float pos = fminf(fmaxf(P.q, 0.f), 1.f) * (float)(S - 1);
             const int lo = (int)floorf(pos);
             const int hi = lo + 1 < S ? lo + 1 : S - 1;
             const float wgt = pos - (float)lo;
@@ -3076,7 +3072,8 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
     switch (w->cfg.t_unet) {
         case 3: return launch_score_t<3, 2, 4, false, true>(P, (hipStream_t)stream, nullptr);
         case 6: return launch_score_t<6, 1, 4, false, true>(P, (hipStream_t)stream, nullptr);
-        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3 and 6 U-Net frames (the fixtures' shapes)");
+        case 12: return launch_score_t<12, 1, 2, false, true>(P, (hipStream_t)stream, nullptr);
+        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3, 6 and 12 U-Net frames (the fixtures' shapes)");
     }
 #endif
 }
@@ -3164,6 +3161,8 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
         if (aggr != MCD_AGGR_BEST && aggr != MCD_AGGR_WORST && aggr != MCD_AGGR_MEAN && aggr != MCD_AGGR_MEDIAN && aggr != MCD_AGGR_QUANTILE)
             return fail(MCD_EINVAL, "mcd_score_fused aggregates losses (best, worst, mean, median, quantile); the *_pose strategies go through mcd_score + mcd_aggregate");
         if (S > 64) return fail(MCD_EUNSUPPORTED, "aggregation supports n_generated_samples <= 64");
+        if (aggr == MCD_AGGR_QUANTILE && !(quantile >= 0.f && quantile <= 1.f))       // (also rejects NaN; torch.quantile raises)
+            return fail(MCD_EINVAL, "quantile must be in [0, 1]");
     }
     if (S < 1 || cfg->noise_steps < 2) return fail(MCD_EINVAL, "need n_samples >= 1 and noise_steps >= 2");
     if (cfg->n_corrupt < 1 || cfg->n_cond + cfg->n_corrupt != cfg->seg_len || cfg->seg_len > MCD_MAX_FRAMES)
@@ -3309,6 +3308,7 @@ int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_join
     if (!loss_all || !loss_agg) return fail(MCD_EINVAL, "null argument");
     if (cfg->n_samples > 64) return fail(MCD_EUNSUPPORTED, "aggregation supports n_generated_samples <= 64");
     if (strategy < MCD_AGGR_BEST || strategy > MCD_AGGR_QUANTILE) return fail(MCD_EINVAL, "unknown aggregation strategy");
+    if (strategy == MCD_AGGR_QUANTILE && !(quantile >= 0.f && quantile <= 1.f)) return fail(MCD_EINVAL, "quantile must be in [0, 1]");
     const bool need_pose = strategy == MCD_AGGR_MEAN_POSE || strategy == MCD_AGGR_MEDIAN_POSE;
     if (need_pose && (!pose_all || !data)) return fail(MCD_EINVAL, "pose strategies need pose_all and data");
     if (pose_agg && !pose_all) return fail(MCD_EINVAL, "pose_agg requested without pose_all");

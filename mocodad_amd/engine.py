@@ -23,6 +23,17 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _quantile_of(strategy: str) -> float:
+    """'quantile:q' -> q, rejected outside [0, 1] like torch.quantile does (mocodad.py:513-516)."""
+    try:
+        q = float(strategy.split(":")[-1])
+    except ValueError:
+        raise ValueError(f"bad quantile in aggregation strategy {strategy!r}") from None
+    if not 0.0 <= q <= 1.0:      # (NaN fails too)
+        raise ValueError(f"quantile() q must be in the range [0, 1], got {q} ({strategy!r})")
+    return q
+
+
 class HipScorer:
     """One packed model on one GPU.
 
@@ -81,7 +92,7 @@ class HipScorer:
 
     def set_option(self, name: str, value: int) -> None:
         """Per-handle switch of the library (include/mocodad_hip.h MCD_OPT_*): 'bf16x3', 'variant', 'cond_generic',
-        'generic_unet'."""
+        'generic_unet', 'split', 'phase'."""
         if name not in _lib.OPT:
             raise ValueError(f"unknown option {name!r} (known: {sorted(_lib.OPT)})")
         _lib.check(self.L.mcd_set_option(self._h, _lib.OPT[name], int(value)))
@@ -204,7 +215,7 @@ class HipScorer:
         if aggregation is not None:
             name = aggregation
             if "quantile" in aggregation:
-                q, name = float(aggregation.split(":")[-1]), "quantile"
+                q, name = _quantile_of(aggregation), "quantile"
             if name not in ("best", "worst", "mean", "median", "quantile"):
                 raise ValueError(f"score_fused aggregates losses (best, worst, mean, median, quantile:q), not {aggregation!r}")
             if out is None:
@@ -263,7 +274,7 @@ class HipScorer:
         q = 0.0
         name = strategy
         if "quantile" in strategy:
-            q = float(strategy.split(":")[-1])
+            q = _quantile_of(strategy)
             name = "quantile"
         if name not in _lib.AGGR or name == "all":
             raise ValueError(f"Unknown aggregation strategy {strategy}")
@@ -336,6 +347,11 @@ class FrameScoreAssembler:
         n = int(scores.numel())
         if meta.shape != (n, 4) or trans.numel() != n or frames.shape[0] != n:
             raise ValueError("scores / trans / meta / frames disagree on the number of windows")
+        # the scatter-max orders non-negative floats by their bit patterns: a NaN / negative / infinite window score (a
+        # diverged model) must surface as an error here, not as a plausible-looking AUC (the reference's NumPy path lets the
+        # NaN reach roc_auc_score, which raises)
+        if n and not bool((torch.isfinite(scores) & (scores >= 0)).all().item()):
+            raise ValueError("window scores must be finite and non-negative (got NaN / inf / negative values: diverged model?)")
         n_persons = int(meta[:, 2].max().item()) + 1 if n else 1
         cfg = self._cfg(max(n_persons, 1))
         need = int(self.L.mcd_frame_scores_workspace_bytes(C.byref(cfg)))

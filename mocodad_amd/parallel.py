@@ -48,8 +48,13 @@ class WindowShard:
         `self.host_meta` (the full arrays) set by the driver."""
         dev = device if device is not None and (dist.get_backend(self.group) == "nccl") else "cpu"
         local = out if torch.is_tensor(out) else torch.as_tensor(np.asarray(out))
-        if local.numel() != len(self):
-            raise ValueError(f"rank {self.rank} scored {local.numel()} windows, its shard has {len(self)}")
+        # the length check is collective: a rank that raised alone would leave the others blocked in the all-gather
+        bad = torch.tensor([int(local.numel() != len(self))], dtype=torch.int32, device=dev)
+        if self.world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        if int(bad.item()):
+            raise ValueError(f"rank {self.rank} scored {local.numel()} windows, its shard has {len(self)} "
+                             "(or another rank reported a mismatch: every rank fails together)")
         full = self.all_gather_scores(local.reshape(-1).to(device=dev, dtype=torch.float32)).cpu().numpy()
         hm = getattr(self, "host_meta", None)
         if hm is None:

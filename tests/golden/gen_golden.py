@@ -261,6 +261,159 @@ def extra4(MoCoDAD):
         save(f"traj_{vname}_ns{ns}_S{S}.npz", **tr)
 
 
+# `--extra5` (round 3): "hostile" weight statistics -- what a trained checkpoint can hold and the benign fixtures above do not:
+# folded BatchNorm gains gamma / sqrt(var + eps) spread log-uniformly over 0.1x..10x per channel (15 % of them negative),
+# large running means / biases, one PReLU slope per layer cycling through {1.5, -0.2, 0.01, 0} (slope > 1 and slope < 0 take the
+# other branch of the kernel's med3 form), the last U-Net layer NOT scaled down, windows pushed against the +-5 clip of the
+# data pipeline.  So that the 9-step chain stays finite each layer's BatchNorms are then rescaled by ONE positive factor per
+# layer (PReLU is positively homogeneous) to unit RMS output on a calibration batch: the 100x per-channel spread, the signs,
+# the slopes and the offsets stay.  Same three U-Net shapes as the main fixtures: inject (3 frames), concat (6), T12 (12).
+HOSTILE_SLOPES = (1.5, -0.2, 0.01, 0.0)
+HOSTILE = {"inject": ("inject", 6, (0, 1, 2)), "concat": ("concat", 6, (0, 1, 2)), "T12": ("inject", 24, 2)}
+
+
+def hostile_(model, gen):
+    k = 0
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            n = m.running_mean.shape
+            var = torch.rand(n, generator=gen) * 1.75 + 0.25
+            gain = 10.0 ** (torch.rand(n, generator=gen) * 2 - 1)
+            gain = torch.where(torch.rand(n, generator=gen) < 0.15, -gain, gain)
+            m.running_var.copy_(var)
+            m.running_mean.copy_(torch.randn(n, generator=gen) * 0.5)
+            m.weight.data.copy_(gain * torch.sqrt(var + m.eps))
+            m.bias.data.copy_(torch.randn(n, generator=gen) * 0.3)
+        if isinstance(m, nn.PReLU):
+            m.weight.data.fill_(HOSTILE_SLOPES[k % 4])
+            k += 1
+
+
+def calibrate_(model, run, target=1.0):
+    """One positive factor per ST-GCN layer / joint resampler, in execution order: RMS of what enters the PReLU (of the
+    BatchNorm output for a resampler) on the calibration batch -> `target`."""
+    from models.gcae.stsgcn import ST_GCNN_layer, CNN_layer
+    order = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: order.append(mod)) for m in model.modules()
+             if isinstance(m, (ST_GCNN_layer, CNN_layer))]
+    run()
+    for h in hooks:
+        h.remove()
+    seen = []
+    for mod in order:
+        if any(mod is s for s in seen):
+            continue
+        seen.append(mod)
+        cap = {}
+        if isinstance(mod, ST_GCNN_layer):
+            ident = isinstance(mod.residual, nn.Identity)
+            probe = mod.tcn[1] if ident else mod.prelu          # identity residual: only the tcn branch can be scaled
+            h = (probe.register_forward_hook(lambda m_, i, o: cap.setdefault("v", o.detach().clone())) if ident else
+                 probe.register_forward_pre_hook(lambda m_, i: cap.setdefault("v", i[0].detach().clone())))
+            bns = [mod.tcn[1]] + ([] if ident else [mod.residual[1]])
+        else:
+            h = mod.block[1].register_forward_hook(lambda m_, i, o: cap.setdefault("v", o.detach().clone()))
+            bns = [mod.block[1]]
+        run()
+        h.remove()
+        s = target / float(cap["v"].pow(2).mean().sqrt())
+        for bn in bns:
+            bn.weight.data.mul_(s)
+            bn.bias.data.mul_(s)
+
+
+def layer_io(model, gen, B=4):
+    """I/O of every ST-GCN layer and joint resampler of the U-Net ALONE (same keys as layers_{inject,concat}.npz)."""
+    unet, Tu = model.model, model.input_n_frames
+    lay = {}
+    e = torch.randn(B, 16, generator=gen)
+    lay["emb_in"] = e
+    blocks = [("st_gcnnsp1a", 0), ("st_gcnnsd1", 0), ("st_gcnnsd1", 1), ("st_gcnnsd2", 0), ("st_gcnnsd2", 1), ("st_gcnnsd3", 0),
+              ("st_gcnnsd3", 1), ("st_gcnnsu4", 0), ("st_gcnnsu4", 1), ("st_gcnnsu3", 0), ("st_gcnnsu3", 1)]
+    for bi, (bn, li) in enumerate(blocks):
+        layer = getattr(unet, bn)[li]
+        x = torch.randn(B, layer.in_channels, Tu, layer.joints_dim, generator=gen)
+        lay[f"L{bi}_in"] = x
+        lay[f"L{bi}_out"] = layer(x, e)
+        lay[f"L{bi}_gcn"] = layer.gcn(x)
+    for rn in ("down1", "down2", "up3", "up2"):
+        cl = getattr(unet, rn)
+        ch = {"down1": 32, "down2": 64, "up3": 64, "up2": 32}[rn]
+        x = torch.randn(B, ch, Tu, cl.block[0].in_channels, generator=gen)
+        lay[f"{rn}_in"] = x
+        lay[f"{rn}_out"] = cl(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()   # stsae_unet.py:205,213,381,391
+    return lay
+
+
+def extra5(MoCoDAD):
+    # (a) stage-level pins of the 12-frame U-Net from the ALREADY COMMITTED benign weights
+    d = np.load(os.path.join(HERE, "weights_T12.npz"))
+    cfg = json.loads(bytes(d["__cfg__"]).decode())
+    args, _ = make_args(strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"], cond_idx=cfg["conditioning_indices"])
+    m = MoCoDAD(args).eval()
+    m.load_state_dict({k: torch.from_numpy(d[k]) for k in d.files if k != "__cfg__"})
+    save("layers_T12.npz", **layer_io(m, torch.Generator().manual_seed(2024), B=2))
+    # (b) hostile weights: weights, stage I/O, single passes, trajectories (B = 4, ns = 10, S = 2)
+    ns, S, B = 10, 2, 4
+    for vname, (strategy, seg_len, cond_idx) in HOSTILE.items():
+        gen = torch.Generator().manual_seed(9000 + len(vname))
+        args, cfg = make_args(strategy=strategy, seg_len=seg_len, cond_idx=cond_idx, noise_steps=ns, n_gen=S, aggr="all", ret="all")
+        torch.manual_seed(90 + len(vname))
+        m = MoCoDAD(args).eval()
+        hostile_(m, gen)
+        Tu = m.input_n_frames
+        xc = torch.randn(8, 2, Tu, 17, generator=gen)
+        cdat = (synth_windows(8, m.n_frames_condition, gen) * 3).clamp_(-5, 5) if m.condition_encoder is not None else None
+
+        def run():
+            cond = m.condition_encoder(cdat, t=None)[0] if cdat is not None else None
+            m.model(xc, torch.full((8,), 5, dtype=torch.long), condition_data=cond)
+        calibrate_(m, run)
+        save(f"weights_hostile_{vname}.npz", __cfg__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **state_to_np(m))
+        lay = layer_io(m, gen, B=2 if vname == "T12" else 4)
+        if m.condition_encoder is not None:
+            ci = (synth_windows(lay["emb_in"].shape[0], m.n_frames_condition, gen) * 3).clamp_(-5, 5)
+            lay["cond_in"] = ci
+            lay["cond_emb"] = m.condition_encoder(ci, t=None)[0]
+        save(f"layers_hostile_{vname}.npz", **lay)
+        ps = {"x": torch.randn(B, 2, Tu, 17, generator=gen)}
+        cond = torch.randn(B, 16, generator=gen) * 0.5 if strategy == "inject" else None
+        if cond is not None:
+            ps["cond"] = cond
+        for tval in (1, 9):
+            ps[f"eps_t{tval}"] = m.model(ps["x"], torch.full((B,), tval, dtype=torch.long), condition_data=cond)[0]
+        save(f"pass_hostile_{vname}.npz", **ps)
+        data = (synth_windows(B, seg_len, gen) * 3).clamp_(-5, 5)          # a good part of the coordinates sits on the +-5 clip
+        Tx = m.n_frames_corrupt
+        noise = fp16_round(torch.randn(S, ns - 1, B, 2, Tx, 17, generator=gen))
+        batch = [data, torch.zeros(B, dtype=torch.long), torch.zeros(B, 4, dtype=torch.long), torch.zeros(B, seg_len, dtype=torch.int32)]
+        tr = dict(data=data, noise=noise.half())
+        orig = torch.randn_like
+        for aggr in ("all", "best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3"):
+            feeder = NoiseFeeder(noise)
+            torch.randn_like = feeder
+            try:
+                o = m.forward(batch, aggr_strategy=aggr, return_="all")
+            finally:
+                torch.randn_like = orig
+            assert feeder.calls == S * (ns - 1)
+            key = aggr.replace(":", "_").replace(".", "p")
+            if aggr == "all":
+                tr["loss_all"], tr["poses_all"] = o[0], o[1]
+            else:
+                tr[f"loss_{key}"] = o[0]
+                if o[1] is not None:
+                    tr[f"pose_{key}"] = o[1]
+        if m.condition_encoder is not None:
+            cd, _, _ = m._select_frames(data)
+            tr["cond_emb"] = m.condition_encoder(cd, t=None)[0]
+        print(vname, "clipped coords", float((data.abs() == 5).float().mean()), "max |pose|", float(tr["poses_all"].abs().max()),
+              "loss range", float(tr["loss_all"].min()), float(tr["loss_all"].max()),
+              "max |eps|", float(ps["eps_t9"].abs().max()))
+        assert torch.isfinite(tr["poses_all"]).all()
+        save(f"traj_hostile_{vname}_ns{ns}_S{S}.npz", **tr)
+
+
 def extra2():
     """Test-time affine transforms of the reference's dataset (utils/dataset_utils.py:255-310; applied in
     utils/dataset.py:67-76): `python tests/golden/gen_golden.py --extra2`."""
@@ -294,6 +447,9 @@ def main():
         return
     if "--extra4" in sys.argv:
         extra4(MoCoDAD)
+        return
+    if "--extra5" in sys.argv:
+        extra5(MoCoDAD)
         return
 
     # ---------------------------------------------------------------- 5. schedules

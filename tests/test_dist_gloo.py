@@ -62,6 +62,38 @@ def test_all_gather_scores_world2(n_total):
     assert spans[0][0] == 0 and spans[-1][1] == n_total
 
 
+def _mismatch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = WindowShard(10)
+        shard.host_meta = (np.arange(10), np.zeros((10, 4)), np.zeros((10, 6)))
+        n = len(shard) - (1 if rank == 1 else 0)          # rank 1 lost a window
+        try:
+            shard.gather(np.zeros(n, dtype=np.float32), None, None, None)
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "ValueError"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_length_mismatch_fails_on_every_rank():
+    """A rank whose score count does not match its shard must not leave the others blocked in the all-gather: the check is
+    collective, every rank raises."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: "ValueError", 1: "ValueError"}, res
+
+
 def _tiny_dataset():
     """One clip, one person, 9 windows: with 4 ranks the shards are 3 + 3 + 3 + 0 (ceil-divided), with 2 ranks 5 + 4."""
     from mocodad_amd.data import synthetic

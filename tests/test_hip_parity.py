@@ -71,6 +71,72 @@ def test_trajectory_vs_golden(variant, ns, S):
             np.testing.assert_allclose(sel.cpu().numpy(), g[f"pose_{key}"], atol=ATOL, rtol=1e-5, err_msg=aggr)
 
 
+HOSTILE = ["hostile_inject", "hostile_concat", "hostile_T12"]
+
+
+@pytest.mark.parametrize("variant", HOSTILE)
+def test_hostile_weights_vs_reference(variant):
+    """Reference-generated vectors from weights with TRAINED-SCALE statistics (tests/golden/gen_golden.py --extra5): folded
+    BatchNorm gains spread over 0.1x..10x per channel (some negative), PReLU slopes 1.5 / -0.2 / 0.01 / 0 on different layers
+    (slope > 1 and slope < 0 take the other branch of the kernel's med3 form of PReLU), the last layer not scaled down,
+    windows pushed against the +-5 clip.  Single passes, whole trajectories (B 4, ns 10, S 2) and every aggregation, on the
+    specialised kernel (3, 6 and 12 frames), the one-launch fused form and the runtime-shape kernel.
+    Bound: 1e-4 relative to the largest score / pose / eps value of the fixture."""
+    sc, _, _ = _scorer(variant)
+    gp = load_golden(f"pass_{variant}.npz")
+    cond = torch.from_numpy(gp["cond"]) if "cond" in gp else None
+    g = load_golden(f"traj_{variant}_ns10_S2.npz")
+    data = torch.from_numpy(g["data"])
+    noise = torch.from_numpy(g["noise"].astype(np.float32))
+    tol = 1e-4 * float(np.abs(g["loss_all"]).max())
+    ptol = 1e-4 * float(np.abs(g["poses_all"]).max())
+    if "cond_emb" in g:
+        emb = sc.cond_encode(data[:, :, sc.cond_idx, :]).cpu().numpy()
+        np.testing.assert_allclose(emb, g["cond_emb"], atol=1e-4 * float(np.abs(g["cond_emb"]).max()), rtol=0)
+    worst = 0.0
+    for generic in (0, 1):
+        sc.set_option("generic_unet", generic)
+        for tv in (1, 9):
+            eps = sc.unet_forward(torch.from_numpy(gp["x"]), tv, cond, noise_steps=10).cpu().numpy()
+            np.testing.assert_allclose(eps, gp[f"eps_t{tv}"], atol=1e-4 * float(np.abs(gp[f"eps_t{tv}"]).max()), rtol=0)
+        loss, poses = sc.score(data, n_samples=2, noise_steps=10, noise=noise, want_poses=True)
+        worst = max(worst, float(np.abs(loss.cpu().numpy() - g["loss_all"]).max()))
+        np.testing.assert_allclose(poses.cpu().numpy(), g["poses_all"], atol=ptol, rtol=0)
+        np.testing.assert_allclose(loss.cpu().numpy(), g["loss_all"], atol=tol, rtol=0)
+        for aggr in ("best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3"):
+            key = aggr.replace(":", "_").replace(".", "p")
+            sel, l = sc.aggregate(data, loss, poses, aggr, noise_steps=10)
+            np.testing.assert_allclose(l.cpu().numpy(), g[f"loss_{key}"], atol=tol, rtol=0, err_msg=aggr)
+            if sel is not None:
+                np.testing.assert_allclose(sel.cpu().numpy(), g[f"pose_{key}"], atol=ptol, rtol=0, err_msg=aggr)
+    sc.set_option("generic_unet", 0)
+    for split in (0, 1, 2):
+        sc.set_option("split", split)
+        agg, all_, _ = sc.score_fused(data, n_samples=2, noise_steps=10, aggregation="best", noise=noise, want_all=True)
+        np.testing.assert_allclose(agg.cpu().numpy(), g["loss_best"], atol=tol, rtol=0)
+        np.testing.assert_allclose(all_.cpu().numpy(), g["loss_all"], atol=tol, rtol=0)
+    print(f"{variant}: max |score - reference| = {worst:.3e} on scores up to {float(np.abs(g['loss_all']).max()):.2f}")
+
+
+def test_quantile_out_of_range_is_rejected():
+    """torch.quantile raises for q outside [0, 1] (mocodad.py:513-516); so do the host wrapper and the C ABI."""
+    sc, _, _ = _scorer("inject")
+    data = torch.randn(4, 2, 6, 17)
+    for bad in ("quantile:90", "quantile:-0.1", "quantile:nan"):
+        with pytest.raises(ValueError):
+            sc.score_fused(data, n_samples=3, noise_steps=4, aggregation=bad)
+        with pytest.raises(ValueError):
+            sc.aggregate(data, torch.zeros(4, 3, device="cuda:0"), None, bad, noise_steps=4)
+    import ctypes as C
+    from mocodad_amd import _lib
+    cfg = sc._score_cfg(4, 3, 4, "smooth_l1")
+    la = torch.zeros(4, 3, device="cuda:0")
+    out = torch.zeros(4, device="cuda:0")
+    rc = sc.L.mcd_aggregate(C.byref(cfg), 2, 17, _lib.AGGR["quantile"], C.c_float(1.5), C.c_void_p(la.data_ptr()), None, None,
+                            C.c_void_p(out.data_ptr()), None, None)
+    assert rc == -1 and b"quantile" in sc.L.mcd_last_error()
+
+
 FUSED_AGGR = ("best", "worst", "mean", "median", "quantile:0.3")
 
 

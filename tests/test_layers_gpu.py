@@ -1,7 +1,7 @@
 """GPU: every stage of the U-Net ALONE through the test entry mcd_layer_forward -- the production MFMA stage functions in
-the trajectory kernel's LDS plan -- against the reference's own layer I/O (tests/golden/layers_{inject,concat}.npz):
+the trajectory kernel's LDS plan -- against the reference's own layer I/O (tests/golden/layers_{inject,concat,T12,hostile_*}.npz):
 ST_GCNN_layer.forward (stsgcn.py:94-116) for the 11 layers, CNN_layer over the joint axis (stsgcn.py:187-199 as called at
-stsae_unet.py:205,213,381,391) for the 4 resamplers.  3 U-Net frames (inject) and 6 (concat)."""
+stsae_unet.py:205,213,381,391) for the 4 resamplers.  3 U-Net frames (inject), 6 (concat) and 12 (T12)."""
 import json
 
 import numpy as np
@@ -25,22 +25,28 @@ def _scorer(variant):
                      cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
 
 
-@pytest.mark.parametrize("variant", ["inject", "concat"])
+@pytest.mark.parametrize("variant", ["inject", "concat", "T12", "hostile_inject", "hostile_concat", "hostile_T12"])
 def test_every_layer_vs_reference_layer_io(variant):
+    """3, 6 and 12 U-Net frames (the 12-frame kernel has its own mix path, six output frames per unit); the `hostile_*` fixtures
+    hold trained-scale weight statistics (BatchNorm gains 0.1x..10x, PReLU slopes 1.5 / -0.2 / 0.01 / 0).  Bound: 2e-5,
+    relative to the stage's largest output where that exceeds 1."""
     sc = _scorer(variant)
     g = load_golden(f"layers_{variant}.npz")
     e = torch.from_numpy(g["emb_in"])
     worst = 0.0
     for i in range(11):
         out = sc.layer_forward(i, torch.from_numpy(g[f"L{i}_in"]), e).cpu().numpy()
-        err = np.abs(out - g[f"L{i}_out"]).max()
-        worst = max(worst, err)
-        np.testing.assert_allclose(out, g[f"L{i}_out"], atol=2e-5, rtol=1e-5, err_msg=f"layer {i}")
+        ref = g[f"L{i}_out"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst = max(worst, np.abs(out - ref).max() / scale)
+        np.testing.assert_allclose(out, ref, atol=2e-5 * scale, rtol=1e-5, err_msg=f"layer {i}")
     for sid, rn in ((11, "down1"), (12, "down2"), (13, "up3"), (14, "up2")):
         out = sc.layer_forward(sid, torch.from_numpy(g[f"{rn}_in"]), e).cpu().numpy()
-        worst = max(worst, np.abs(out - g[f"{rn}_out"]).max())
-        np.testing.assert_allclose(out, g[f"{rn}_out"], atol=2e-5, rtol=1e-5, err_msg=rn)
-    print(f"{variant}: max |stage output - reference| over the 15 stages = {worst:.3e}")
+        ref = g[f"{rn}_out"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst = max(worst, np.abs(out - ref).max() / scale)
+        np.testing.assert_allclose(out, ref, atol=2e-5 * scale, rtol=1e-5, err_msg=rn)
+    print(f"{variant}: max scaled |stage output - reference| over the 15 stages = {worst:.3e}")
 
 
 def test_layer_forward_ragged_batch_and_errors():

@@ -229,3 +229,40 @@ def test_c_abi_error_paths():
                       cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0"),)
     with pytest.raises(RuntimeError, match="<= 64"):
         sc3.aggregate(torch.zeros(2, 2, 6, 17), torch.zeros(2, 65, device="cuda:0"), None, "best", noise_steps=3)
+
+
+def test_integration_md_ctypes_stub_runs_as_written(monkeypatch):
+    """INTEGRATION.md section 2 -- the ctypes binding a maintainer of the reference would paste into models/mocodad.py -- is
+    extracted from the document and executed VERBATIM: its struct layouts, call signatures and argument order against the
+    built library, its result against a reference-generated trajectory (the reference's own attribute names on a stand-in
+    object: mocodad.py:46-81)."""
+    import os
+    import types
+    from mocodad_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = md.split("\n## 2.")[1].split("\n## 3.")[0]
+    code = sec.split("```python\n")[1].split("\n```")[0]
+    assert "mcd_pack_weights" in code and "mcd_score" in code and "mcd_aggregate" in code
+    monkeypatch.setenv("MOCODAD_HIP_LIB", _lib.LIB_PATH)
+    ns_ = {}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns_)
+    sd, cfg = golden_weights("inject")
+    g = load_golden("traj_inject_ns10_S5.npz")
+    ref = types.SimpleNamespace(                       # what the reference's MoCoDAD.__init__ sets (mocodad.py:46-81)
+        num_coords=2, n_joints=17, n_frames=cfg["seg_len"], input_n_frames=3, n_frames_condition=3, n_frames_corrupt=3,
+        embedding_dim=cfg["embedding_dim"], conditioning_strategy="inject", conditioning_indices=list(cfg["conditioning_indices"]),
+        cond_channels=list(cfg["channels"]), cond_h_dim=cfg["h_dim"], n_generated_samples=5, noise_steps=10,
+        device=torch.device("cuda:0"), state_dict=lambda: sd)
+    ns_["pack"](ref)
+    data = torch.from_numpy(g["data"]).cuda().contiguous()
+    noise = torch.from_numpy(g["noise"].astype(np.float32)).cuda().contiguous()
+    best = ns_["hot_loop"](ref, data, noise=noise)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(best.cpu().numpy(), g["loss_best"], atol=ATOL, rtol=0)
+    # perf mode through the stub == the shipped module's scorer with the same keys
+    a = ns_["hot_loop"](ref, data, seed=7, first_window_id=100)
+    m, _, _ = _model("inject", noise_steps=10, n_generated_samples=5)
+    b, _, _ = m.scorer().score_fused(data, n_samples=5, noise_steps=10, aggregation="best", seed=7, first_window_id=100)
+    assert torch.equal(a, b)
+    ns_["lib"].mcd_free_weights(ref._h)

@@ -1,5 +1,6 @@
-"""GPU (one device is enough): the multi-process path end to end.  Two ranks share cuda:0 (RCCL refuses two ranks on one
-GPU, so the collective runs on gloo here; on a node every rank has its own GPU and the backend is nccl = RCCL over xGMI):
+"""GPU: the multi-process path end to end.  On a box with ONE device two ranks share cuda:0 (RCCL refuses two ranks on one
+GPU, so the collective runs on gloo there); on a box with >= 2 devices the SAME tests also run with one rank per GPU on the
+nccl backend (= RCCL over xGMI) -- the configuration of the driver's 2/4/8-GPU scaling runs:
   - eval_MoCoDAD.py with WORLD_SIZE=2 gives the single-process scores and AUC bit for bit (noise keyed by global window id,
     contiguous shards, one all-gather, AUC on rank 0);
   - `python bench.py --gpus 2` launches its own ranks and prints ONE JSON line for the 2-rank job, weak and strong scaling."""
@@ -29,17 +30,38 @@ def _env():
     return e
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _rank_layouts():
+    """(backend, ranks): gloo with two ranks on cuda:0 always; nccl with one rank per visible GPU (up to 8) when there are >= 2."""
+    return [("gloo", 2), ("nccl", None)]
+
+
+def _resolve(backend, ranks):
+    if backend == "nccl":
+        n = min(_n_gpus(), 8)
+        if n < 2:
+            pytest.skip("the RCCL variant needs >= 2 GPUs (one rank per GPU); this box has %d" % n)
+        return n
+    return ranks
+
+
+@pytest.mark.parametrize("backend,ranks", _rank_layouts())
 @pytest.mark.parametrize("extra", [[], ["--device-windows"]])
-def test_eval_two_ranks_equals_one_process(tmp_path, extra):
+def test_eval_two_ranks_equals_one_process(tmp_path, extra, backend, ranks):
+    ranks = _resolve(backend, ranks)
     cfg = os.path.join(ROOT, "configs", "hr_avenue_test.yaml")
     common = ["-c", cfg, "--synthetic", "3", "--frames-per-clip", "90", "--random-init"] + extra
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "eval_MoCoDAD.py")] + common + ["--dump-scores", one],
                         capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r1.returncode == 0, r1.stdout + r1.stderr
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
                          "--master-port", str(_port()), os.path.join(ROOT, "eval_MoCoDAD.py")] + common +
-                        ["--dist-backend", "gloo", "--dump-scores", two], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+                        ["--dist-backend", backend, "--dump-scores", two], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r2.returncode == 0, r2.stdout + r2.stderr
     a, b = np.load(one), np.load(two)
     assert a["scores"].shape == b["scores"].shape and a["scores"].size > 1000
@@ -48,20 +70,36 @@ def test_eval_two_ranks_equals_one_process(tmp_path, extra):
     assert r2.stdout.count("AUC:") == 1          # rank 0 alone computes and prints it
 
 
+@pytest.mark.parametrize("backend,ranks", _rank_layouts())
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_self_launches_two_ranks(scaling):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256",
-                        "--dist-backend", "gloo", "--scaling", scaling], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+def test_bench_self_launches_two_ranks(scaling, backend, ranks):
+    ranks = _resolve(backend, ranks)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--batch", "256",
+                        "--dist-backend", backend, "--scaling", scaling], capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
-    assert len(d["ranks"]["kernel_ms"]) == 2 and len(d["ranks"]["all_gather_ms"]) == 2
-    total = 512 if scaling == "weak" else 256
+    assert d["n_gpus"] == ranks and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
+    assert len(d["ranks"]["kernel_ms"]) == ranks and len(d["ranks"]["all_gather_ms"]) == ranks
+    total = 256 * ranks if scaling == "weak" else 256
     assert d["config"]["windows_per_step_total"] == total
     assert sum(d["ranks"]["windows_per_step"]) == total
+    assert d["rccl_ranks"] == (ranks if backend == "nccl" else 0)
     assert "roofline" in d and "cpu_baseline" not in d
+
+
+def test_nccl_backend_refuses_more_ranks_than_gpus():
+    """One rank per GPU is required with RCCL; asking for more must fail fast (exit code 2 / a message), not hang."""
+    n = _n_gpus()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--batch", "64"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode != 0 and "one rank per GPU" in (r.stdout + r.stderr)
+    cfg = os.path.join(ROOT, "configs", "hr_avenue_test.yaml")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n + 1}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_port()), os.path.join(ROOT, "eval_MoCoDAD.py"), "-c", cfg, "--synthetic", "1", "--random-init"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert r.returncode != 0 and "one rank per GPU" in (r.stdout + r.stderr)
 
 
 def test_missing_checkpoint_is_an_error():
