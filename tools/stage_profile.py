@@ -28,7 +28,7 @@ sc = HipScorer(sd, strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"]
 B = min(B, 1024)
 NS = min(NS, 10)
 L = _lib.lib()
-prof = torch.zeros(1024, dtype=torch.int64, device="cuda:0")
+prof = torch.zeros(4096, dtype=torch.int64, device="cuda:0")
 data = bench.synth_windows(B, cfg["seg_len"], 1).cuda()
 sc.score(data, n_samples=S, noise_steps=NS, seed=1)
 torch.cuda.synchronize()
@@ -67,3 +67,19 @@ if bar.sum() > 0:
         if bar[i].sum() > 0:
             print(f"  {i:2d} | " + " ".join(f"{x:6.0f}" for x in bar[i]) + f" | {bar[i].min():6.0f} {bar[i].mean():6.0f}")
     print(f"  sum of per-barrier minima {bar.min(1).sum():.0f}   mean wait per wave {bar.sum(0).mean():.0f}   (pass total {tot/NP:.0f})")
+
+# per-wave time stamps of one pass (the second pass of workgroup 0's first trajectory), relative to the top of the pass:
+# per layer: entry | mix done (before its barrier) | after the barrier | GEMM starts (next stage's coefficient loads issued) |
+#            GEMM issued | stores landed | after the closing barrier
+PROF_SLOTS = 72 + NW + 30 * NW
+tr = p[PROF_SLOTS:PROF_SLOTS + 128 * NW].reshape(128, NW)
+if tr[0].sum() > 0:
+    t0 = tr[0].min()
+    tr = (tr - t0) % 2.0 ** 32 + t0          # (32-bit stamps)
+    print("\ntime stamps of one pass (cycles from the top of the pass), per wave; rows: layer / point")
+    pts = ["entry", "mix done", "barrier", "gemm start", "gemm issued", "stores landed", "barrier"]
+    for l in range(11):
+        for k in range(7):
+            row = tr[8 + 8 * l + k]
+            if row.sum() > 0:
+                print(f"  L{l:<2d} {pts[k]:14s} " + " ".join(f"{x - t0:7.0f}" for x in row) + f" | span {row.max() - row.min():6.0f}")
