@@ -359,6 +359,37 @@ __device__ __forceinline__ float mul_bc(float coef, float y) {
         asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(coef), "v"(y), "n"(L));
     return r;
 }
+// The time mix of a unit is QC independent chains (one per output frame) of T FMAs each.  Written chain after chain the
+// wave issues T DEPENDENT v_fmac_f32_dpp in a row (the compiler keeps asm statements in source order and pads each pair
+// with an s_nop): ~2x the issue time of independent instructions, and with two waves per SIMD (12 frames) nothing hides it.
+// tm_step issues time step t of ALL chains as ONE asm statement -- QC independent instructions back to back, in a fixed
+// order -- so no chain ever waits on itself.  INIT: v_mul (the chains' first step, outputs early-clobbered);
+// PAD: the statement ends with `s_nop 1` (its results feed MFMA operands next, see fmac_bc).
+#define MCD_DPP(OP, I) OP " %[y" #I "], %[c" #I "], %[x] row_newbcast:%[L] row_mask:0xf bank_mask:0xf\n\t"
+#define MCD_TM_IN(I) [c##I] "v"(c[I])
+#define MCD_TM2(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) NOP : [y0] CON(y[0]), [y1] CON(y[1]) \
+                                  : MCD_TM_IN(0), MCD_TM_IN(1), [x] "v"(x), [L] "n"(L))
+#define MCD_TM3(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) NOP : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]) \
+                                  : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), [x] "v"(x), [L] "n"(L))
+#define MCD_TM6(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) MCD_DPP(OP, 3) MCD_DPP(OP, 4) MCD_DPP(OP, 5) NOP \
+                                  : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]), [y3] CON(y[3]), [y4] CON(y[4]), [y5] CON(y[5]) \
+                                  : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), MCD_TM_IN(3), MCD_TM_IN(4), MCD_TM_IN(5), [x] "v"(x), [L] "n"(L))
+#define MCD_TM(N) do { if constexpr (INIT) { if constexpr (PAD) MCD_TM##N("v_mul_f32_dpp", "=&v", "s_nop 1"); else MCD_TM##N("v_mul_f32_dpp", "=&v", ""); } \
+                       else { if constexpr (PAD) MCD_TM##N("v_fmac_f32_dpp", "+v", "s_nop 1"); else MCD_TM##N("v_fmac_f32_dpp", "+v", ""); } } while (0)
+template <int QC, int L, bool INIT, bool PAD>
+__device__ __forceinline__ void tm_step(float (&y)[QC], const float (&c)[QC], float x) {
+    static_assert(QC == 1 || QC == 2 || QC == 3 || QC == 6, "time-mix group sizes");
+    if constexpr (QC == 1) {
+        if constexpr (INIT) y[0] = mul_bc<L, PAD>(c[0], x);
+        else fmac_bc<L, PAD>(y[0], c[0], x);
+    } else if constexpr (QC == 2) {
+        MCD_TM(2);
+    } else if constexpr (QC == 3) {
+        MCD_TM(3);
+    } else {
+        MCD_TM(6);
+    }
+}
 template <int... Is, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -451,7 +482,9 @@ struct MixCoef {
 
 // init functor of a mix whose accumulators start at zero (x + 0.f is not folded away: -0.0)
 struct ZeroInit { __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; } };
-template <int CIN, int V, int T, int NB, class Init, class Store>
+// FORCE (kernels without a register cap): the unit's X reads are pinned in front of its arithmetic (the scheduler otherwise
+// sinks each k-step's reads to their first use and the wave pays an LDS round trip per k-step)
+template <int CIN, int V, int T, int NB, bool FORCE = false, class Init, class Store>
 __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const MixCoef<CIN, V, T, NB>& pre,
                                           const float* __restrict__ tqd, const float* __restrict__ af, int wave, int lane,
                                           Init&& init, Store&& store) {
@@ -500,18 +533,22 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
             const float (&x)[T] = xs[ks];
+            // y[qi] = sum_t X[t, v] * T[v, t, q0 + qi]   (coefficient (ks,t) = lane ks*T+t of the DPP row): the QC chains advance
+            // together, one time step per asm statement (tm_step)
+            float y[QC];
+            static_for<T>([&](auto ti) {
+                constexpr int t = decltype(ti)::value;
+                float c[QC];
+#pragma unroll
+                for (int qi = 0; qi < QC; ++qi) c[qi] = cur.tq[qi][(ks * T + t) / 16];
+                tm_step<QC, (ks * T + t) % 16, t == 0, t == T - 1>(y, c, x[t]);
+            });
             static_for<QC>([&](auto qq) {
                 constexpr int qi = decltype(qq)::value;
-                // y = sum_t X[t, v] * T[v, t, q]   (coefficient (ks,t) = lane ks*T+t of this DPP row)
-                float y = mul_bc<(ks * T) % 16, T == 1>(cur.tq[qi][(ks * T) / 16], x[0]);
-                static_for<T - 1>([&](auto ti) {
-                    constexpr int t = decltype(ti)::value + 1;
-                    fmac_bc<(ks * T + t) % 16, t == T - 1>(y, cur.tq[qi][(ks * T + t) / 16], x[t]);
-                });
 #pragma unroll
                 for (int mt = 0; mt < MTM; ++mt)
-                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aop[qi][mt][ks], y, acc[qi][mt], 0, 0, 0);
-                if constexpr (J16) part[qi] = fmaf(cur.aop[qi][1][ks], y, part[qi]);
+                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aop[qi][mt][ks], y[qi], acc[qi][mt], 0, 0, 0);
+                if constexpr (J16) part[qi] = fmaf(cur.aop[qi][1][ks], y[qi], part[qi]);
             });
         });
 #pragma unroll
@@ -551,6 +588,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             const int u = M::unit_of(wave, rnd);
             float xs[KS][T];
             load_x(u < 0 ? 0 : u, xs);
+            if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
             MixCoef<CIN, V, T, NB> nxt;
             if constexpr (rnd + 1 < PER && !M::SAMEQ) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
             if (u >= 0) unit(cur, u, xs);
@@ -724,10 +762,15 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
 // scheduler otherwise sinks every read to its use; with the 128-VGPR cap pinning costs spills and loses)
 // cinit: what a tile's accumulators start from when the layer has no identity residual -- the folded bias of the lane's 4
 // output channels (two packed adds per tile less in the epilogue), or zero
-template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, class Epi>
+// `pre(tile slot, col, ng)`: optional values the epilogue needs from LDS (the embedding row of the tile's chain), fetched in
+// FRONT of the tile's MFMA chain and handed to epi as a 7th argument -- read inside the epilogue they put an LDS round trip
+// between the tile's last MFMA and its store
+struct NoPre { static constexpr bool none = true; };
+template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, bool DUAL = FORCE, class Epi, class Pre = NoPre>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
                                            const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0,
-                                           const float4 cinit = make_float4(0.f, 0.f, 0.f, 0.f)) {
+                                           const float4 cinit = make_float4(0.f, 0.f, 0.f, 0.f), Pre&& pre = Pre{}) {
+    constexpr bool HASPRE = !std::is_same_v<std::decay_t<Pre>, NoPre>;
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
     const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
@@ -738,42 +781,108 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
     const int col0 = ng * 16 + j;
     const float* const p1b = b1 + __mul24(col0, cs1) + 4 * g;
     const float* const p2b = b2 + __mul24(col0, cs2) + 4 * g;
-    static_for<MAXN>([&](auto ii) {
+    constexpr int KQ = KQ1 + KQ2;
+    constexpr int DEPTH = KQ < 3 ? KQ : 3;
+    // one 16x16 output tile: B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH reads ahead of the MFMAs that consume
+    // them -- read right before its use each fragment exposes an LDS round trip per 4 MFMAs on this wave's matrix-pipe stream
+    auto one_tile = [&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        const int nt = ng + i * NG;
-        if (nt < NT) {
-            const int col = col0 + i * NG * 16;
-            f32x4 c = {cinit.x, cinit.y, cinit.z, cinit.w};
-            const float* p1 = p1b + i * NG * 16 * cs1;
-            const float* p2 = p2b + i * NG * 16 * cs2;
-            if (IDRES) {
-                const float4 r = *reinterpret_cast<const float4*>(p2 - 4 * g + c0);
-                c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
-            }
-            // B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH reads ahead of the MFMAs that consume them: read
-            // right before its use each fragment exposes an LDS round trip per 4 MFMAs on this wave's matrix-pipe stream
-            constexpr int KQ = KQ1 + KQ2;
-            constexpr int DEPTH = KQ < 3 ? KQ : 3;
-            auto rd = [&](auto kk) {
-                constexpr int kq = decltype(kk)::value;
-                return *reinterpret_cast<const float4*>(kq < KQ1 ? p1 + kq * 16 : p2 + (kq - KQ1) * 16);
-            };
-            float4 buf[DEPTH];
-            static_for<DEPTH>([&](auto dd) { buf[decltype(dd)::value] = rd(dd); });
-            if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
-            static_for<KQ>([&](auto kk) {
-                constexpr int kq = decltype(kk)::value;
-                const float4 u = buf[kq % DEPTH];
-                if constexpr (kq + DEPTH < KQ) buf[kq % DEPTH] = rd(std::integral_constant<int, kq + DEPTH>{});
-                if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u.z, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u.w, c, 0, 0, 0);
-            });
-            epi(ii, col, c0, c, col0, ng);
+        const int col = col0 + i * NG * 16;
+        f32x4 c = {cinit.x, cinit.y, cinit.z, cinit.w};
+        const float* p1 = p1b + i * NG * 16 * cs1;
+        const float* p2 = p2b + i * NG * 16 * cs2;
+        if (IDRES) {
+            const float4 r = *reinterpret_cast<const float4*>(p2 - 4 * g + c0);
+            c[0] = r.x; c[1] = r.y; c[2] = r.z; c[3] = r.w;
         }
-    });
+        auto rd = [&](auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            return *reinterpret_cast<const float4*>(kq < KQ1 ? p1 + kq * 16 : p2 + (kq - KQ1) * 16);
+        };
+        float4 buf[DEPTH];
+        static_for<DEPTH>([&](auto dd) { buf[decltype(dd)::value] = rd(dd); });
+        float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (HASPRE) pe = pre(ii, col, ng);
+        if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
+        static_for<KQ>([&](auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            const float4 u = buf[kq % DEPTH];
+            if constexpr (kq + DEPTH < KQ) buf[kq % DEPTH] = rd(std::integral_constant<int, kq + DEPTH>{});
+            if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u.z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u.w, c, 0, 0, 0);
+        });
+        if constexpr (HASPRE) epi(ii, col, c0, c, col0, ng, pe);
+        else epi(ii, col, c0, c, col0, ng);
+    };
+    // DUAL (the kernels with two waves per SIMD): two of the wave's n-tiles at a time, their MFMA chains interleaved.  One
+    // tile is a chain of 4 KQ DEPENDENT MFMAs (40 cycles each against 32 of issue) behind an LDS round trip and in front of
+    // its epilogue; alone on its SIMD half of the time, a wave leaves the matrix pipe idle for all of that.  Two independent
+    // accumulators issue back to back, and the second tile's reads / the first one's epilogue overlap the other's MFMAs.
+    auto two_tiles = [&](auto ia, auto ib) {
+        constexpr int i0 = decltype(ia)::value, i1 = decltype(ib)::value;
+        const float* p1[2] = {p1b + i0 * NG * 16 * cs1, p1b + i1 * NG * 16 * cs1};
+        const float* p2[2] = {p2b + i0 * NG * 16 * cs2, p2b + i1 * NG * 16 * cs2};
+        f32x4 c[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            c[h] = f32x4{cinit.x, cinit.y, cinit.z, cinit.w};
+            if (IDRES) {
+                const float4 r = *reinterpret_cast<const float4*>(p2[h] - 4 * g + c0);
+                c[h][0] = r.x; c[h][1] = r.y; c[h][2] = r.z; c[h][3] = r.w;
+            }
+        }
+        auto rd = [&](int h, auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            return *reinterpret_cast<const float4*>(kq < KQ1 ? p1[h] + kq * 16 : p2[h] + (kq - KQ1) * 16);
+        };
+        float4 buf[2][DEPTH];
+        static_for<DEPTH>([&](auto dd) { buf[0][decltype(dd)::value] = rd(0, dd); buf[1][decltype(dd)::value] = rd(1, dd); });
+        float4 pe0 = make_float4(0.f, 0.f, 0.f, 0.f), pe1 = pe0;
+        if constexpr (HASPRE) { pe0 = pre(ia, col0 + i0 * NG * 16, ng); pe1 = pre(ib, col0 + i1 * NG * 16, ng); }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KQ>([&](auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            const float4 u0 = buf[0][kq % DEPTH], u1 = buf[1][kq % DEPTH];
+            if constexpr (kq + DEPTH < KQ) {
+                buf[0][kq % DEPTH] = rd(0, std::integral_constant<int, kq + DEPTH>{});
+                buf[1][kq % DEPTH] = rd(1, std::integral_constant<int, kq + DEPTH>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u0.x, c[0], 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u1.x, c[1], 0, 0, 0);
+            c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u0.y, c[0], 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u1.y, c[1], 0, 0, 0);
+            c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u0.z, c[0], 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u1.z, c[1], 0, 0, 0);
+            c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u0.w, c[0], 0, 0, 0);
+            c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u1.w, c[1], 0, 0, 0);
+        });
+        if constexpr (HASPRE) {
+            epi(ia, col0 + i0 * NG * 16, c0, c[0], col0, ng, pe0);
+            epi(ib, col0 + i1 * NG * 16, c0, c[1], col0, ng, pe1);
+        } else {
+            epi(ia, col0 + i0 * NG * 16, c0, c[0], col0, ng);
+            epi(ib, col0 + i1 * NG * 16, c0, c[1], col0, ng);
+        }
+    };
+    if constexpr (DUAL && MAXN >= 2) {
+        static_for<(MAXN + 1) / 2>([&](auto pp) {
+            constexpr int i0 = 2 * decltype(pp)::value, i1 = i0 + 1;
+            if constexpr (i1 < MAXN) {
+                if (ng + i1 * NG < NT) two_tiles(std::integral_constant<int, i0>{}, std::integral_constant<int, i1>{});
+                else if (ng + i0 * NG < NT) one_tile(std::integral_constant<int, i0>{});
+            } else {
+                if (ng + i0 * NG < NT) one_tile(std::integral_constant<int, i0>{});
+            }
+        });
+    } else {
+        static_for<MAXN>([&](auto ii) {
+            if (ng + decltype(ii)::value * NG < NT) one_tile(ii);
+        });
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -892,7 +1001,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     // (the folded bias starts the first tile's accumulators: fetched here, with the weight fragments, so that its L2 latency
     // hides behind the mix as well)
     float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
-    mix_stage<CIN, V, T, NB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
+    mix_stage<CIN, V, T, NB, FORCE>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
                              [&](int n, int q, int w0, int c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
@@ -930,31 +1039,44 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
         asm volatile("" : "+v"(oaddr), "+v"(eaddr));
     };
     set_bases(0);
-    auto epi = [&](auto ti, int col, int c0, f32x4 acc, int, int ng) {
+    // One chain per workgroup: the embedding values of a lane's 4 output channels are the same for every tile of the GEMM
+    // call.  Read once up front (kernels without a register cap): inside the tile epilogue the read sits between the tile's
+    // last MFMA and its store -- an LDS round trip on the wave's critical path per tile (the compiler cannot hoist it itself:
+    // the epilogue's LDS stores may alias it)
+    constexpr bool EHOIST = HASEMB && NB == 1 && FORCE;
+    float4 e_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EHOIST) e_pre = lds_load4(eaddr);
+    // the embedding values of this lane's 4 output channels for the chain of a tile's column
+    auto emb_of = [&](auto ti, int col, int ng) -> float4 {
+        // Two chains: a tile lies on one side of the chain boundary (wave-uniform: picked on the scalar unit) except the one
+        // tile that straddles it
+        if constexpr (NB == 2) {
+            const int tile_lo = (ng + decltype(ti)::value * Tiling<MT, NT>::NG) * 16;
+            unsigned eo = tile_lo >= TV ? 4u * EMB_STRIDE : 0u;                          // scalar unit
+            if (tile_lo < TV && tile_lo + 16 > TV) {                                      // the straddling tile: per lane
+                eo = col >= TV ? 4u * EMB_STRIDE : 0u;
+                asm volatile("" : "+v"(eo));       // (keeps this a scalar branch: if-converted it costs every tile 5 VALU instructions)
+            }
+            return lds_load4(eaddr + eo);
+        } else if constexpr (NB > 2) {
+            const int n = col / TV;
+            return lds_load4(eaddr + 4u * (unsigned)((n < NB ? n : NB - 1) * EMB_STRIDE));
+        } else if constexpr (EHOIST) {
+            return e_pre;
+        } else {
+            return lds_load4(eaddr);
+        }
+    };
+    constexpr bool EPRE = HASEMB && NB > 1 && FORCE;       // several chains, no register cap: fetched in front of the tile's MFMAs
+    auto epi = [&](auto ti, int col, int c0, f32x4 acc, int, int ng, auto... pe) {
         // pad columns (col >= COLS) are computed and stored like the others: every region has ceil16(COLS) rows, nobody reads
         // them, and no per-tile bounds check runs on the VALU.  Output channels: only COUT not a multiple of 16 needs the check.
         // (the split-bf16 path keeps the check: its pad rows hold bf16 planes of stale fp32 data, which can read as NaN, and a
         // NaN written to a pad row would meet the zero weights of the resamplers' K padding: NaN x 0)
         if ((COUT % 16 == 0 || c0 < COUT) && (!BF3 || col < COLS)) {
             float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (HASEMB) {
-                // this column's chain.  Two chains: a tile lies on one side of the chain boundary (wave-uniform: picked on the
-                // scalar unit) except the one tile that straddles it
-                if constexpr (NB == 2) {
-                    const int tile_lo = (ng + decltype(ti)::value * Tiling<MT, NT>::NG) * 16;
-                    unsigned eo = tile_lo >= TV ? 4u * EMB_STRIDE : 0u;                          // scalar unit
-                    if (tile_lo < TV && tile_lo + 16 > TV) {                                      // the straddling tile: per lane
-                        eo = col >= TV ? 4u * EMB_STRIDE : 0u;
-                        asm volatile("" : "+v"(eo));       // (keeps this a scalar branch: if-converted it costs every tile 5 VALU instructions)
-                    }
-                    e = lds_load4(eaddr + eo);
-                } else if constexpr (NB > 2) {
-                    const int n = col / TV;
-                    e = lds_load4(eaddr + 4u * (unsigned)((n < NB ? n : NB - 1) * EMB_STRIDE));
-                } else {
-                    e = lds_load4(eaddr);
-                }
-            }
+            if constexpr (sizeof...(pe) > 0) e = (pe, ...);
+            else if constexpr (HASEMB) e = emb_of(ti, col, ng);
             // packed adds / multiply on channel pairs (v_pk_add_f32, v_pk_mul_f32) around the four v_med3_f32 of the PReLU
             f32x2 t0 = f32x2{acc[0], acc[1]}, t1 = f32x2{acc[2], acc[3]};
             if constexpr (!FOLD) { t0 += f32x2{bcur.x, bcur.y}; t1 += f32x2{bcur.z, bcur.w}; }
@@ -967,6 +1089,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
         }
     };
     if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi);
+    else if constexpr (EPRE) gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, 0, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f), emb_of);
     else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, 0, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
     for (int mi = 1; mi < Tiling<MT, NT>::MW; ++mi) {     // workgroups with fewer waves than m-tiles: next m-tile(s)
@@ -974,7 +1097,9 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
         else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
         bcur = load_global4(bias + ((wave + mi * NWAVES) % MT) * 16 + 4 * (lane >> 4));
         set_bases(mi);
+        if constexpr (EHOIST) e_pre = lds_load4(eaddr);
         if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi, mi);
+        else if constexpr (EPRE) gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f), emb_of);
         else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     pre_barrier();
@@ -1544,7 +1669,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(10);
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);
-            mix_stage<64, 10, T, NB>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
+            mix_stage<64, 10, T, NB, (MINW <= 2)>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w0, int c, std::true_type) {   // the fragment's 4 joints at once
                                          const float* pp = Pb + __mul24((n * T + q) * 10 + w0, 132) + 64 + c;
                                          // joints >= 10 read the next frame's rows (inside the 64-column region): an MFMA's D rows
@@ -1664,7 +1789,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope10 = lw.slope;
             const bool single = P.mode == 1, zadd = sidx > 1;
             const int e10_off = (sidx & 1) * 16;
-            mix_stage<16, 17, T, NB>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
+            mix_stage<16, 17, T, NB, (MINW <= 2)>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      ZeroInit{},
                                      [&](int n, int t, int w0, int c, auto val) {     // whole 4-joint fragments: one address, 4 stores
                                          if (c < C0) {
@@ -2626,8 +2751,15 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
     // opt-in split-bf16 channel GEMMs (layers 2..9) for 3, 6 and 12 U-Net frames (see gemm_tiles_bf3); everything measured and
     // reported by bench.py uses the fp32 path
     const bool bf3 = w->opt[MCD_OPT_BF16X3] != 0;
-#ifdef MCD_FAST_T6      // developer builds: one instantiation
-    return launch_score_t<6, 1, 4>(P, st, fused);
+#if defined(MCD_FAST_T)     // developer builds (-DMCD_FAST_T=3|6|12 [-DMCD_FAST_NB= -DMCD_FAST_MINW=]): one instantiation only
+#ifndef MCD_FAST_NB
+#define MCD_FAST_NB (MCD_FAST_T == 3 ? 2 : 1)
+#endif
+#ifndef MCD_FAST_MINW
+#define MCD_FAST_MINW (MCD_FAST_T >= 8 ? 2 : 4)
+#endif
+    if (T != MCD_FAST_T) return fail(MCD_EUNSUPPORTED, "fast build");
+    return launch_score_t<MCD_FAST_T, MCD_FAST_NB, MCD_FAST_MINW>(P, st, fused);
 #elif defined(MCD_FAST_BUILD)   // developer builds: only the two default-shape instantiations
     if (T == 3 && bf3) return launch_score_t<3, 2, 4, true>(P, st, fused);
     if (T == 3) return variant == 2 ? launch_score_t<3, 2, 2>(P, st, fused) : launch_score_t<3, 2, 4>(P, st, fused);
@@ -3066,7 +3198,7 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
     P.mode = 1; P.step_single = 0; P.n_chains = n_windows;
     P.lt_stage = stage; P.lt_in = x; P.lt_out = out;
     P.x_in = stage == 0 ? x : nullptr;     // layer 0 reads the chain state itself; the other stages start from x = 0
-#ifdef MCD_FAST_BUILD
+#if defined(MCD_FAST_BUILD) || defined(MCD_FAST_T)
     return fail(MCD_EUNSUPPORTED, "fast build");
 #else
     switch (w->cfg.t_unet) {
