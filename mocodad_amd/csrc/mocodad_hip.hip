@@ -653,7 +653,10 @@ struct RsCoef {
     }
 };
 
-template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, int NSK>
+// ILP (kernels with two waves per SIMD): the wave's units advance together, k-step by k-step -- PER independent
+// accumulator chains instead of PER dependent 4-5-MFMA chains one after the other (40 cycles of latency per link against 32
+// of issue, and nothing else on the SIMD half of the time)
+template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, bool ILP = false, int NSK>
 __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int cs_in, float* __restrict__ out, int cs_out,
                                                const RsCoef<C, VIN, VOUT, T, NB, CAPTURE>& rc,
                                                float (&skip)[NSK], int wave, int lane) {
@@ -666,7 +669,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     const auto& bias = rc.bias;
     // all the X reads of this wave's units first (for the down-samplers they ARE the skip registers): a unit's stores
     // may alias the next unit's reads, so reading inside the unit loop would serialise the units on LDS latency
-    float xr[CAPTURE ? 1 : PER][CAPTURE ? 1 : KS];      // (the down-samplers read straight into `skip`)
+    float xr[CAPTURE ? 1 : PER][CAPTURE ? 1 : KS] = {};      // (the down-samplers read straight into `skip`)
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
@@ -683,49 +686,78 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             });
         }
     });
-    static_for<PER>([&](auto pi) {
+    constexpr bool J16 = VOUT == 17;     // output joint 16 on the VALU (partial sums per lane group, permlane-swap reduction)
+    constexpr int MTM = J16 ? 1 : MT;   // instead of a second m-tile with one useful row -- same trade as in mix_stage
+    // the stores of one unit (+ the skip tensor of the up-samplers)
+    auto finish = [&](auto pi, f32x4 (&acc)[MTM], float part) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
-        if (u < UNITS) {
-            const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
-            // VOUT = 17: output joint 16 on the VALU (partial sums per lane group, permlane-swap reduction) instead of a
-            // second m-tile with one useful row -- same trade as in mix_stage
-            constexpr bool J16 = VOUT == 17;
-            constexpr int MTM = J16 ? 1 : MT;
-            f32x4 acc[MTM];
-            float part = 0.f;
+        const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
+        if constexpr (ADD) {
 #pragma unroll
-            for (int mt = 0; mt < MTM; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
-            static_for<KS>([&](auto si) {
-                constexpr int ks = decltype(si)::value;
+            for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
+            if constexpr (SK == 5 && !J16) acc[MT - 1][0] += skip[i * SK + 4];   // joint 16: lane group g = 0, row 0 of m-tile 1
+        }
+        float* zo = out + __mul24(nt * VOUT + 4 * g, cs_out) + cb * 16 + j;
+#pragma unroll
+        for (int mt = 0; mt < MTM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mt * 16 + 4 * g + r < VOUT) zo[(mt * 16 + r) * cs_out] = acc[mt][r];
+        if constexpr (J16) {
+            const unsigned pu = __float_as_uint(part);
+            const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+            const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+            const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+            float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]) + bias[1][0];
+            if constexpr (ADD && SK == 5) z16 += skip[i * SK + 4];          // captured by lane group g = 0 (k-step 4: joint 16 + g)
+            if (g == 0) out[__mul24(nt * VOUT + 16, cs_out) + cb * 16 + j] = z16;
+        }
+    };
+    if constexpr (ILP) {
+        f32x4 acc[PER][MTM];
+        float part[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            part[i] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt) acc[i][mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+        }
+        static_for<KS>([&](auto si) {
+            constexpr int ks = decltype(si)::value;
+            static_for<PER>([&](auto pi) {            // (a wave without a unit in the last round computes on zeros)
+                constexpr int i = decltype(pi)::value;
                 float x;
                 if constexpr (CAPTURE) x = skip[i * SK + ks]; else x = xr[i][ks];
 #pragma unroll
-                for (int mt = 0; mt < MTM; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
-                if constexpr (J16) part = fmaf(aop[1][ks], x, part);
+                for (int mt = 0; mt < MTM; ++mt) acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[i][mt], 0, 0, 0);
+                if constexpr (J16) part[i] = fmaf(aop[1][ks], x, part[i]);
             });
-            if constexpr (ADD) {
+        });
+        static_for<PER>([&](auto pi) {
+            if (wave + decltype(pi)::value * NWAVES < UNITS) finish(pi, acc[decltype(pi)::value], part[decltype(pi)::value]);
+        });
+    } else {
+        static_for<PER>([&](auto pi) {
+            constexpr int i = decltype(pi)::value;
+            const int u = wave + i * NWAVES;
+            if (u < UNITS) {
+                f32x4 acc[MTM];
+                float part = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
-                if constexpr (SK == 5 && !J16) acc[MT - 1][0] += skip[i * SK + 4];   // joint 16: lane group g = 0, row 0 of m-tile 1
+                for (int mt = 0; mt < MTM; ++mt) acc[mt] = f32x4{bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+                static_for<KS>([&](auto si) {
+                    constexpr int ks = decltype(si)::value;
+                    float x;
+                    if constexpr (CAPTURE) x = skip[i * SK + ks]; else x = xr[i][ks];
+#pragma unroll
+                    for (int mt = 0; mt < MTM; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[mt][ks], x, acc[mt], 0, 0, 0);
+                    if constexpr (J16) part = fmaf(aop[1][ks], x, part);
+                });
+                finish(pi, acc, part);
             }
-            float* zo = out + __mul24(nt * VOUT + 4 * g, cs_out) + cb * 16 + j;
-#pragma unroll
-            for (int mt = 0; mt < MTM; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (mt * 16 + 4 * g + r < VOUT) zo[(mt * 16 + r) * cs_out] = acc[mt][r];
-            if constexpr (J16) {
-                const unsigned pu = __float_as_uint(part);
-                const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
-                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
-                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
-                float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]) + bias[1][0];
-                if constexpr (ADD && SK == 5) z16 += skip[i * SK + 4];          // captured by lane group g = 0 (k-step 4: joint 16 + g)
-                if (g == 0) out[__mul24(nt * VOUT + 16, cs_out) + cb * 16 + j] = z16;
-            }
-        }
-    });
+        });
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1285,12 +1317,22 @@ __device__ __forceinline__ void cond_fast_body(const float* wbuf, const DataView
     gfloat* bb = as_global(wb + tab_i(wb, TABC + TABC_LB));
     for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
         const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
-        // (c, tv) loops instead of k % TV, k / TV per element; the 16 parts of an output are the 16 lanes of a DPP row
+        // (c, tv) loops instead of k % TV, k / TV per element; the 16 parts of an output are the 16 lanes of a DPP row.
+        // Compile-time trip counts (the ragged last 16-block is predicated): the loops unroll and the weight loads of several
+        // channels are in flight together -- with the data-dependent bound `tv + part < TV` every load waited for the FMA
+        // before it (one L2 round trip per element: 100 .. 400 of them per thread, the whole encoder's time)
+        constexpr int NT16 = (TV + 15) / 16;
         float a = 0.f;
         gfloat* wr = W + jo * F + part;
         const float* hr = H + (n * TV + part) * 36;
-        for (int c = 0; c < 32; ++c)
-            for (int tv = 0; tv + part < TV; tv += 16) a = fmaf(wr[c * TV + tv], hr[tv * 36 + c], a);
+#pragma unroll 4
+        for (int c = 0; c < 32; ++c) {
+            float wv[NT16];
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) wv[i] = (i * 16 + part < TV) ? wr[c * TV + i * 16] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) a = fmaf(wv[i], (i * 16 + part < TV) ? hr[i * 16 * 36 + c] : 0.f, a);
+        }
         a = row16_sum(a);
         if (part == 0) {
             const float e = a + bb[jo];
@@ -1594,7 +1636,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
         LMix<3, T, NB> mc3;
         mix_early(mc3, 3);
-        resample_stage<32, 17, 12, T, NB, true, false>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
+        resample_stage<32, 17, 12, T, NB, true, false, (MINW <= 2)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         if constexpr (STASH1) {
             priv_float* sp = (priv_float*)stash1_mem;
             asm volatile("" : "+v"(sp));
@@ -1619,7 +1661,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_inject(12, RG + PL::L4_out, 68, 64, 12);
         LMix<5, T, NB> mc5;
         mix_early(mc5, 5);
-        resample_stage<64, 12, 10, T, NB, true, false>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
+        resample_stage<64, 12, 10, T, NB, true, false, (MINW <= 2)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         if constexpr (STASH2) {
             priv_float* sp = (priv_float*)stash2_mem;
             asm volatile("" : "+v"(sp));            // opaque: the array stays in memory, plain (cached) scratch accesses
@@ -1706,7 +1748,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // ---- up path
         LMix<7, T, NB> mc7;
         mix_early(mc7, 7);
-        resample_stage<64, 10, 12, T, NB, false, true>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
+        resample_stage<64, 10, 12, T, NB, false, true, (MINW <= 2)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         bsync();
         STAGE(12);
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
@@ -1733,7 +1775,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
         LMix<9, T, NB> mc9;
         mix_early(mc9, 9);
-        resample_stage<32, 12, 17, T, NB, false, true>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+        resample_stage<32, 12, 17, T, NB, false, true, (MINW <= 2)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         bsync();
         STAGE(15);
         lt_dump(14, RG + PL::UP2_out, 36, 32, 17);
@@ -1999,8 +2041,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
     for (int u = tid; u < NB * EDIM * 16; u += NTHREADS) {
         const int part = u & 15, jo = (u >> 4) % EDIM, n = u / (16 * EDIM);
         float a = 0.f;
-        for (int c = 0; c < CU_OUT; ++c)
-            for (int tv = part; tv < TV10; tv += 16) a = fmaf(W[jo * F + c * TV10 + tv], H[(n * TV10 + tv) * 20 + c], a);
+        constexpr int NT16 = (TV10 + 15) / 16;      // compile-time trip counts: the weight loads are issued together (see cond_fast_body)
+#pragma unroll
+        for (int c = 0; c < CU_OUT; ++c) {
+            float wv[NT16];
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) wv[i] = (i * 16 + part < TV10) ? W[jo * F + c * TV10 + i * 16 + part] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NT16; ++i) a = fmaf(wv[i], (i * 16 + part < TV10) ? H[(n * TV10 + i * 16 + part) * 20 + c] : 0.f, a);
+        }
         a = row16_sum(a);
         if (part == 0 && b0 + n < B) emb_out[(size_t)(b0 + n) * EDIM + jo] = a + bb[jo];
     }
@@ -2672,7 +2721,7 @@ struct mcd_weights {
     bool has_cond;
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
     bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
-    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3, 4, 6, 8, 12); otherwise the runtime-shape kernel
+    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3, 4, 5, 6, 8, 10, 12); otherwise the runtime-shape kernel
     GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
     GenCond gcond;    // ... and of the 'E_unet' condition encoder
     int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
@@ -2778,8 +2827,10 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
             return launch_score_t<6, 1, 4>(P, st, fused);                     // 1 chain / WG, 2 WGs per CU
         case 12: return bf3 ? launch_score_t<12, 1, 2, true>(P, st, fused) : launch_score_t<12, 1, 2>(P, st, fused);
         case 4: return launch_score_t<4, 1, 4>(P, st, fused);                 // e.g. seg_len 8 split in halves
+        case 5: return launch_score_t<5, 2, 2>(P, st, fused);                 // e.g. seg_len 10 split in halves (2 chains / WG, 1 WG per CU)
         case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
-        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 6, 8, 12)");
+        case 10: return launch_score_t<10, 1, 2>(P, st, fused);               // e.g. seg_len 20 split in halves / seg_len 10 concat
+        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 5, 6, 8, 10, 12)");
     }
 #endif
 }
@@ -2799,7 +2850,9 @@ int launch_cond_fast_t(const mcd_weights* w, const DataView& data, const FrameId
 int launch_cond_fast(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     switch (w->cond.Tc) {
         case 3: return launch_cond_fast_t<3, 2>(w, data, fi, seg_len, emb, B, st);
+        case 5: return launch_cond_fast_t<5, 2>(w, data, fi, seg_len, emb, B, st);
         case 6: return launch_cond_fast_t<6, 2>(w, data, fi, seg_len, emb, B, st);
+        case 10: return launch_cond_fast_t<10, 1>(w, data, fi, seg_len, emb, B, st);
         case 12: return launch_cond_fast_t<12, 1>(w, data, fi, seg_len, emb, B, st);
         default: return fail(MCD_EUNSUPPORTED, "cond_fast: frame count not instantiated");
     }
@@ -2865,7 +2918,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (cfg->emb_dim != EDIM) return fail(MCD_EUNSUPPORTED, "embedding_dim must be 16");
     const int T = cfg->t_unet;
     if (T < 1 || T > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "U-Net frame count must be in 1.." + std::to_string(MCD_MAX_FRAMES));
-    const bool fast_unet = T == 3 || T == 4 || T == 6 || T == 8 || T == 12;     // the instantiated score_kernel<T,...>
+    const bool fast_unet = T == 3 || T == 4 || T == 5 || T == 6 || T == 8 || T == 10 || T == 12;     // the instantiated score_kernel<T,...>
     GenNet G;
     memset(&G, 0, sizeof(G));
     GenCond GC;
@@ -3064,7 +3117,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         Cw.lb = B.alloc(EDIM); memcpy(&B.buf[Cw.lb], lb, sizeof(float) * EDIM);
         // fast path (cond_fast_kernel): the shipped architecture at a frame count the MFMA stages are instantiated for
         cond_fast = Cw.n_layers == 4 && Cw.cout[0] == 32 && Cw.cout[1] == 16 && Cw.cout[2] == 32 && Cw.cout[3] == 32 &&
-                    (Cw.Tc == 3 || Cw.Tc == 6 || Cw.Tc == 12);
+                    (Cw.Tc == 3 || Cw.Tc == 5 || Cw.Tc == 6 || Cw.Tc == 10 || Cw.Tc == 12);
         if (cond_fast) {
             int cinr = C0;
             for (int l = 0; l < 4; ++l) {
