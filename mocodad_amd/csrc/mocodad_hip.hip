@@ -130,6 +130,7 @@ constexpr int PROF_STAGE = 72;                           // stage-time slots
 constexpr int PROF_BAR = 30;                             // barriers of one pass that get a slot
 constexpr int PROF_NW = NWAVES;                         // (small on purpose: the 3-frame plan has 1.3 KB to spare below 2 workgroups per CU)
 constexpr int PROF_SLOTS = PROF_STAGE + PROF_NW + PROF_BAR * PROF_NW;   // stage times | (unused) | wait[barrier][wave]
+constexpr int PROF_TRACE = 128;                          // time-stamp slots of the traced pass (after the PROF_SLOTS accumulators)
 #endif
 // Everything the instrumentation needs lives in registers of the profiled workgroup (block 0): the timing adds are
 // fire-and-forget LDS atomics, no global memory access, no LDS round trip on the waves' paths.
@@ -141,6 +142,11 @@ struct Prof {
     bool won;                    // lane 0 of every wave of block 0: barrier waits
     int bidx;                    // barrier index inside the pass (wave-uniform)
     int wv;
+    unsigned* tr;                // LDS: per-wave time stamps (low 32 bits) of the traced pass, tr[slot * NWAVES + wave]; null: none
+    bool tr_on;                  // lane 0 of every wave of block 0, during the traced pass only
+    __device__ __forceinline__ void trace(int slot) {
+        if (tr_on) tr[slot * PROF_NW + wv] = (unsigned)__builtin_readcyclecounter();
+    }
     __device__ __forceinline__ void mark(int id) {
         if (on) {
             const unsigned long long t = __builtin_readcyclecounter();
@@ -157,8 +163,9 @@ struct Prof {
             __hip_atomic_fetch_add(acc + PROF_STAGE + PROF_NW + bidx * PROF_NW + wv, (unsigned)(t1 - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++bidx;
     }
-    __device__ __forceinline__ void off() { on = false; won = false; acc = nullptr; tlast = 0; bidx = 0; wv = 0; }
+    __device__ __forceinline__ void off() { on = false; won = false; acc = nullptr; tlast = 0; bidx = 0; wv = 0; tr = nullptr; tr_on = false; }
 #else
+    __device__ __forceinline__ void trace(int) {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ void off() {}
@@ -1027,6 +1034,8 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     constexpr int KQ1 = CIN / 16, KQ2 = RES ? CIN / 16 : 0;
     float4 afr[KQ1 + KQ2];
     static_assert(!BF3 || KQ1 % 2 == 0, "split-bf16 path: K a multiple of 32 per operand buffer");
+    const int trs = 8 + 8 * ((prof_id - 32) / 3);      // trace slots of this layer (profile builds)
+    prof.trace(trs + 0);
     if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr);
     else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     const float* bias = wb + lw.bias;
@@ -1051,9 +1060,18 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                                      else *zp = v;
                                  }
                              });
+    prof.trace(trs + 1);
+    // The NEXT stage's coefficient loads.  The vector-memory path accepts ~1 wave-wide load per 10 cycles and all eight waves
+    // issue 10 .. 40 of them at the same point of the stage: in front of the GEMM tiles (where they used to be) the last
+    // wave's first MFMA waited ~2 k cycles for its loads to be accepted (profiles/r03c_seq24_trace.txt).  The kernels with
+    // two waves per SIMD issue them HERE instead, behind the wave's mix and in front of the barrier: the older wave of
+    // each SIMD reaches this point 1 - 2 k cycles before the younger one and would only wait.
+    constexpr bool PREBAR = FORCE && !BF3;
+    if constexpr (PREBAR) pre_gemm();
     bsync();
+    prof.trace(trs + 2);
     prof.mark(prof_id);
-    pre_gemm();
+    if constexpr (!PREBAR) pre_gemm();
     const float slope = lw.slope;
     const float pinf = prelu_bound(slope);     // see prelu()
     constexpr int TILE_STEP = Tiling<MT, NT>::NG * 16;      // columns between a wave's consecutive n-tiles
@@ -1120,6 +1138,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
             else lds_store4(oaddr + tile_bytes, r0[0], r0[1], r1[0], r1[1]);
         }
     };
+    prof.trace(trs + 3);
     if constexpr (BF3) gemm_tiles_bf3<MT, NT, KQ1 / 2, KQ2 / 2, !RES, true, false>(afr, z, CSI, in, CSX, wave, lane, epi);
     else if constexpr (EPRE) gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, 0, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f), emb_of);
     else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, 0, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1134,8 +1153,14 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
         else if constexpr (EPRE) gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f), emb_of);
         else gemm_tiles<MT, NT, KQ1, KQ2, !RES, FORCE>(afr, z, CSI, in, CSX, wave, lane, epi, mi, FOLD ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
     }
+    prof.trace(trs + 4);
     pre_barrier();
+#ifdef MCD_PROFILE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (stamp 5 = this wave's stores have landed)
+#endif
+    prof.trace(trs + 5);
     bsync();
+    prof.trace(trs + 6);
     prof.mark(prof_id + 1);
 }
 // self-contained form (condition encoder): coefficients loaded at the top of the layer
@@ -1256,7 +1281,8 @@ struct Plan {
     static constexpr int LOSS = NB * 64;        // per-sample losses of the workgroup's windows [NB][S <= 64] (in-kernel aggregation)
     static constexpr int EXW = EMB_EXTRA * 20;  // embedding rows beyond the first NTHREADS: [row][16 weights, bias, pad]
 #ifdef MCD_PROFILE
-    static constexpr int PROF = PROF_SLOTS;
+    static constexpr int PROFTR = NB * T >= 10 ? PROF_TRACE * PROF_NW : 0;      // time stamps: the one-workgroup-per-CU shapes have the room
+    static constexpr int PROF = PROF_SLOTS + PROFTR;
 #else
     static constexpr int PROF = 0;
 #endif
@@ -1446,6 +1472,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     for (int i = tid0; i < PROF_SLOTS; i += NTHREADS) prof.acc[i] = 0u;     // a barrier follows before the first mark
     prof.on = (tid0 == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.tlast = __builtin_readcyclecounter();
     prof.won = ((tid0 & 63) == 0 && blockIdx.x == 0 && P.prof != nullptr); prof.wv = tid0 >> 6;
+    prof.tr = (P.prof && PL::PROFTR) ? prof.acc + PROF_SLOTS : nullptr;
+    for (int i = tid0; i < PL::PROFTR; i += NTHREADS) prof.acc[PROF_SLOTS + i] = 0u;
     __syncthreads();
 #endif
     // layer test: (B,C,T,V) global tensor <-> LDS region [col = (n,t,v)][channel]
@@ -1601,6 +1629,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(1);
 #ifdef MCD_PROFILE
         prof.bidx = 0;                                         // barrier slots count from the top of the pass
+        prof.tr_on = prof.won && prof.tr && s == part && sidx == i_first - 1;      // time stamps: the second pass of the first trajectory
+        prof.trace(0);
 #endif
         // Every stage issues the coefficient loads of the stage after it (mcN = mix rows / fragments of layer N,
         // rcX = resampler fragments) before its own closing barrier, so no stage starts with an L2 round trip.
@@ -1609,6 +1639,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         auto mix_early = mixload;
         auto rs_early = rsload;
         NoHook nohook;
+        // EARLY2 (kernels with two waves per SIMD): the mix coefficients of the layer BEHIND a joint resampler are fetched two
+        // stages ahead, at the end of the GEMM in front of the resampler (before its closing barrier, where the older wave of
+        // each SIMD only waits): the resampler is too short to cover 36 loads per wave, and issued at its top they delayed its
+        // MFMAs by ~2 k cycles
+        constexpr bool EARLY2 = MINW <= 2 && !BF3;
         LMix<1, T, NB> mc1;
         // layer 0 reads the chain state XT[col][4] in place (x in channels 0,1): its lanes' channels 2..15 are then other
         // columns' coordinates -- finite, and multiplied by the zero-padded K rows of the layer's weights -- so no 16-channel
@@ -1629,13 +1664,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(1, RG + PL::L1_out, 36, 32, 17);
         lt_inject(2, RG + PL::L2_in, 36, 32, 17);
         RsCoef<32, 17, 12, T, NB, true> rc1;
+        LMix<3, T, NB> mc3;
         layer_std<2, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
-                            [&] { rs_early(rc1, 0); }, nohook);                                            // sd1.1 -> d1
+                            [&] { rs_early(rc1, 0); }, [&] { if constexpr (EARLY2) mix_early(mc3, 3); });      // sd1.1 -> d1
         STAGE(4);
         lt_dump(2, RG + PL::L2_out, 36, 32, 17);
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
-        LMix<3, T, NB> mc3;
-        mix_early(mc3, 3);
+        if constexpr (!EARLY2) mix_early(mc3, 3);
         resample_stage<32, 17, 12, T, NB, true, false, (MINW <= 2)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         if constexpr (STASH1) {
             priv_float* sp = (priv_float*)stash1_mem;
@@ -1654,13 +1689,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(3, RG + PL::L3_out, 68, 64, 12);
         lt_inject(4, RG + PL::L4_in, 68, 64, 12);
         RsCoef<64, 12, 10, T, NB, true> rc2;
+        LMix<5, T, NB> mc5;
         layer_std<4, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
-                            [&] { rs_early(rc2, 1); }, nohook);                                            // sd2.1 -> d2
+                            [&] { rs_early(rc2, 1); }, [&] { if constexpr (EARLY2) mix_early(mc5, 5); });      // sd2.1 -> d2
         STAGE(7);
         lt_dump(4, RG + PL::L4_out, 68, 64, 12);
         lt_inject(12, RG + PL::L4_out, 68, 64, 12);
-        LMix<5, T, NB> mc5;
-        mix_early(mc5, 5);
+        if constexpr (!EARLY2) mix_early(mc5, 5);
         resample_stage<64, 12, 10, T, NB, true, false, (MINW <= 2)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         if constexpr (STASH2) {
             priv_float* sp = (priv_float*)stash2_mem;
@@ -1675,22 +1710,25 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(12, RG + PL::DN2_out, 68, 64, 10);
         lt_inject(5, RG + PL::L5_in, 68, 64, 10);
         // ---- sd3.0, then sd3.1 (128 -> 64) W-first: P = [W_t; W_r] G, then out = PReLU(mix(P_t) + P_r + b) + e in place of P_r
+        RsCoef<64, 10, 12, T, NB, false> rc3;
+        LMix<7, T, NB> mc7;
         {
             constexpr int NT = PL::P10 / 16;
             constexpr int COLS = NB * T * 10;
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
+            MixCoef<64, 10, T, NB> mc6;
             layer_std<5, T, NB, (MINW <= 2), cs_of(64), BF3, BF3>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
                                 [&] {
                                     if constexpr (BF3) load_afrags_bf3<8, 4>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, 0);
                                     else load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
+                                    if constexpr (EARLY2) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
                                 });  // sd3.0
             STAGE(9);
             lt_dump(5, RG + PL::L5_out, 132, 128, 10);
             lt_inject(6, RG + PL::L6_in, 132, 128, 10);
             float* Pb = RG + PL::L6_p;
-            MixCoef<64, 10, T, NB> mc6;
-            mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
+            if constexpr (!EARLY2) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             auto epi6 = [&](auto ti, int col, int c0, f32x4 acc, int col0, int) {
                 constexpr int STEP = Tiling<8, NT>::NG * 16 * 132;
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + __mul24(col0, 132) + c0 + decltype(ti)::value * STEP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -1707,6 +1745,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                     gemm_tiles<8, NT, 8, 0, false, (MINW <= 2)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
                 }
             }
+            if constexpr (EARLY2) { rs_early(rc3, 2); mix_early(mc7, 7); }      // up3's fragments, layer 7's mix coefficients
             bsync();
             STAGE(10);
             const float slope6 = lw.slope;
@@ -1735,8 +1774,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS2::PER * RS2::SK; ++i) skip2[i] = sp[i];
         }
-        RsCoef<64, 10, 12, T, NB, false> rc3;
-        rs_early(rc3, 2);
+        if constexpr (!EARLY2) rs_early(rc3, 2);
         if constexpr (!FUSE64) bsync();     // aligned: up3 reads only this wave's own layer-6 output block
         STAGE(11);
         lt_dump(6, RG + PL::L6_p + 64, 132, 64, 10);
@@ -1746,8 +1784,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             if (P.lt_stage == 14) for (float& f : skip1) f = 0.f;
         }
         // ---- up path
-        LMix<7, T, NB> mc7;
-        mix_early(mc7, 7);
+        if constexpr (!EARLY2) mix_early(mc7, 7);
         resample_stage<64, 10, 12, T, NB, false, true, (MINW <= 2)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         bsync();
         STAGE(12);
@@ -1760,9 +1797,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(7, RG + PL::L7_out, 68, 64, 12);
         lt_inject(8, RG + PL::L8_in, 68, 64, 12);
         RsCoef<32, 12, 17, T, NB, false> rc4;
+        LMix<9, T, NB> mc9;
         layer_std<8, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); },
                             [&] {
+                                if constexpr (EARLY2) mix_early(mc9, 9);
                                 if constexpr (STASH1) {
                                     const priv_float* sp = (const priv_float*)stash1_mem;
                                     asm volatile("" : "+v"(sp));
@@ -1773,8 +1812,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         STAGE(14);
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
-        LMix<9, T, NB> mc9;
-        mix_early(mc9, 9);
+        if constexpr (!EARLY2) mix_early(mc9, 9);
         resample_stage<32, 12, 17, T, NB, false, true, (MINW <= 2)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         bsync();
         STAGE(15);
@@ -1958,7 +1996,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }   // samples
 #ifdef MCD_PROFILE
     __syncthreads();
-    if (prof.on) { for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i]; }
+    if (prof.on) {
+        for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];
+        for (int i = 0; i < PL::PROFTR; ++i) P.prof[PROF_SLOTS + i] = prof.acc[PROF_SLOTS + i];
+    }
 #endif
     // ---- aggregation over the samples (mocodad.py:454-520; loss-based strategies), when this workgroup has seen them all
     int te = tid0;
