@@ -805,7 +805,10 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
 // FRONT of the tile's MFMA chain and handed to epi as a 7th argument -- read inside the epilogue they put an LDS round trip
 // between the tile's last MFMA and its store
 struct NoPre { static constexpr bool none = true; };
-template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, bool DUAL = FORCE, class Epi, class Pre = NoPre>
+#ifndef MCD_X_DUAL
+#define MCD_X_DUAL 0
+#endif
+template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, bool DUAL = (FORCE || MCD_X_DUAL), class Epi, class Pre = NoPre>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
                                            const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0,
                                            const float4 cinit = make_float4(0.f, 0.f, 0.f, 0.f), Pre&& pre = Pre{}) {
@@ -1063,10 +1066,11 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     prof.trace(trs + 1);
     // The NEXT stage's coefficient loads.  The vector-memory path accepts ~1 wave-wide load per 10 cycles and all eight waves
     // issue 10 .. 40 of them at the same point of the stage: in front of the GEMM tiles (where they used to be) the last
-    // wave's first MFMA waited ~2 k cycles for its loads to be accepted (profiles/r03c_seq24_trace.txt).  The kernels with
-    // two waves per SIMD issue them HERE instead, behind the wave's mix and in front of the barrier: the older wave of
-    // each SIMD reaches this point 1 - 2 k cycles before the younger one and would only wait.
-    constexpr bool PREBAR = FORCE && !BF3;
+    // wave's first MFMA waited ~2 k cycles for its loads to be accepted (profiles/r03c_seq24_trace.txt).  They are issued
+    // HERE instead, behind the wave's mix and in front of the barrier: the older wave of each SIMD reaches this point
+    // 1 - 2 k cycles before the younger one and would only wait (12 frames +3 % together with EARLY2, 6 frames +1.9 %,
+    // 3 frames +1.1 %: profiles/r03k_prebar_ab.txt).
+    constexpr bool PREBAR = !BF3;
     if constexpr (PREBAR) pre_gemm();
     bsync();
     prof.trace(trs + 2);
@@ -1639,11 +1643,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         auto mix_early = mixload;
         auto rs_early = rsload;
         NoHook nohook;
-        // EARLY2 (kernels with two waves per SIMD): the mix coefficients of the layer BEHIND a joint resampler are fetched two
+        // EARLY2 (kernels with two waves per SIMD, and the 6-frame one): the mix coefficients of the layer BEHIND a joint resampler are fetched two
         // stages ahead, at the end of the GEMM in front of the resampler (before its closing barrier, where the older wave of
         // each SIMD only waits): the resampler is too short to cover 36 loads per wave, and issued at its top they delayed its
         // MFMAs by ~2 k cycles
-        constexpr bool EARLY2 = MINW <= 2 && !BF3;
+        // (6 frames: +1 % on top of the pre-barrier placement; 3 frames: -0.3 %, the 128-register budget has no room for it)
+        constexpr bool EARLY2 = (MINW <= 2 || T == 6) && !BF3;
         LMix<1, T, NB> mc1;
         // layer 0 reads the chain state XT[col][4] in place (x in channels 0,1): its lanes' channels 2..15 are then other
         // columns' coordinates -- finite, and multiplied by the zero-padded K rows of the layer's weights -- so no 16-channel

@@ -227,13 +227,16 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
 
 @pytest.mark.parametrize("strategy,seg_len,ci,arch", [
     ("inject", 8, 2, "AE"), ("concat", 8, [0, 1, 2, 3], "AE"), ("inject", 12, 3, "AE"),          # 4 and 8 U-Net frames: specialised kernels
+    # 5 and 10 U-Net frames (seg_len 10 / 20 split in halves, seg_len 10 with every frame in the U-Net): specialised since round 3
+    ("inject", 10, 2, "AE"), ("no_condition", 5, None, "AE"), ("inject", 10, 2, "E_unet"), ("inbetween_imp", 10, 2, "AE"),
+    ("inject", 20, 2, "AE"), ("concat", 10, [0, 1, 2], "AE"),
     # frame counts WITHOUT a specialised instantiation -> the runtime-shape kernel (the reference is generic in n_frames)
-    ("inject", 10, 2, "AE"), ("concat", 7, [0, 1, 2], "AE"), ("no_condition", 5, None, "AE"), ("inject", 10, 2, "E_unet"),
-    ("inbetween_imp", 10, 2, "AE"), ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE")])
+    ("concat", 7, [0, 1, 2], "AE"), ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE")])
 def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
-    """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 4 / 8 frames on the specialised
-    kernels; 5, 7, 10, 16 and 24 frames (seg_len 10 split 5 + 5, concat over 7 or 24 frames, the longest window the ABI
-    takes: 32 = 16 + 16, ...) on the runtime-shape fallback, including the 'E_unet' encoder."""
+    """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 4 / 5 / 8 / 10 frames on the specialised
+    kernels (seg_len 10 split 5 + 5, seg_len 20 split 10 + 10, concat over 10 frames, ...; cross-checked against the
+    runtime-shape kernel); 7, 16 and 24 frames (concat over 7 or 24 frames, the longest window the ABI takes: 32 = 16 + 16)
+    on the runtime-shape fallback, including the 'E_unet' encoder."""
     from oracle import mocodad_oracle as O
     m, sd, gen = _random_model(strategy, seg_len, ci, arch)
     m = m.to("cuda:0")
@@ -254,6 +257,12 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     z = sc.philox_noise(B, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
     b, _ = sc.score(data, n_samples=S, noise_steps=ns, noise=z)
     assert torch.equal(a, b)
+    # frame counts with a specialised kernel (4, 5, 8, 10 here): the runtime-shape kernel forced on the same call agrees
+    if m.input_n_frames in (4, 5, 8, 10):
+        sc.set_option("generic_unet", 1)
+        c, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
+        sc.set_option("generic_unet", 0)
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), atol=ATOL, rtol=0)
 
 
 @pytest.mark.parametrize("variant,ns,S", [("inject", 10, 5), ("concat", 10, 5), ("T12", 10, 2), ("injtail", 10, 2)])
