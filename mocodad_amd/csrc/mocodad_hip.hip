@@ -1022,13 +1022,29 @@ __device__ __forceinline__ void gemm_tiles_bf3(const float4 (&a)[2 * (CH1 + CH2)
 // HASEMB = false: no embedding term (condition-encoder layers get t = None, components.py:56-63).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
+// weight fragments of a wave's m-tile for one layer's GEMM + the folded bias of its 4 output channels, fetched by the CALLER
+// at the end of the stage before the layer (in front of that stage's closing barrier, where the older wave of each SIMD only
+// waits): at the layer's top the 3 .. 9 KB-wide loads per wave of all waves queued in front of the mix's first LDS reads
+template <int KQ>
+struct LayerAfr {
+    float4 a[KQ];
+    float4 bcur;
+    template <int MT>
+    __device__ __forceinline__ void load(const float* wb, const LayerW& lw, int wave, int lane) {
+        load_afrags<MT, KQ>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, a);
+        bcur = load_global4(wb + lw.bias + (wave % MT) * 16 + 4 * (lane >> 4));
+    }
+};
+
 // `mc`: this layer's mix coefficients (already loaded); `pre_gemm` runs between the mix barrier and the GEMM, `pre_barrier`
 // between the GEMM and the closing barrier -- the callers use them to issue the NEXT stage's coefficient loads.
+// `pre_afr`: the layer's weight fragments when the caller fetched them ahead (null: fetched here).
 template <int CIN, int COUT, int V, bool RES, bool HASEMB, int T, int NB, bool FORCE = false, int CSX = cs_of(CIN), bool BF3 = false, bool OUTP = false, class H1, class H2>
 __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, const MixCoef<CIN, V, T, NB>& mc,
                                               const float* __restrict__ in, float* __restrict__ z, float* __restrict__ out,
                                               const float* __restrict__ embl, int wave, int lane, Prof& prof, int prof_id,
-                                              H1&& pre_gemm, H2&& pre_barrier) {
+                                              H1&& pre_gemm, H2&& pre_barrier,
+                                              const LayerAfr<(CIN / 16) * (RES ? 2 : 1)>* pre_afr = nullptr) {
     constexpr int MT = ceil16(COUT) / 16;
     constexpr int COLS = NB * T * V;
     constexpr int NT = ceil16(COLS) / 16;
@@ -1039,12 +1055,19 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     static_assert(!BF3 || KQ1 % 2 == 0, "split-bf16 path: K a multiple of 32 per operand buffer");
     const int trs = 8 + 8 * ((prof_id - 32) / 3);      // trace slots of this layer (profile builds)
     prof.trace(trs + 0);
-    if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr);
-    else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
     const float* bias = wb + lw.bias;
-    // (the folded bias starts the first tile's accumulators: fetched here, with the weight fragments, so that its L2 latency
-    // hides behind the mix as well)
-    float4 bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
+    float4 bcur;
+    if (pre_afr != nullptr && !BF3) {
+#pragma unroll
+        for (int k = 0; k < KQ1 + KQ2; ++k) afr[k] = pre_afr->a[k];
+        bcur = pre_afr->bcur;
+    } else {
+        if constexpr (BF3) load_afrags_bf3<MT, (KQ1 + KQ2) / 2>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr);
+        else load_afrags<MT, KQ1 + KQ2>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr);
+        // (the folded bias starts the first tile's accumulators: fetched here, with the weight fragments, so that its L2
+        // latency hides behind the mix as well)
+        bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
+    }
     mix_stage<CIN, V, T, NB, FORCE>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
                              [&](int n, int q, int w0, int c, auto v) {
@@ -1180,12 +1203,19 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 // U-Net layer L of the fixed channel plan
 template <int L, int T, int NB>
 using LMix = MixCoef<layer_desc(L).cin, layer_desc(L).V, T, NB>;
+template <int L>
+using LAfr = LayerAfr<(layer_desc(L).cin / 16) * (layer_desc(L).res ? 2 : 1)>;
+template <int L>
+__device__ __forceinline__ void load_lafr(LAfr<L>& A, const float* wb, int wave, int lane) {
+    A.template load<ceil16(layer_desc(L).cout) / 16>(wb, layer_w(wb, L), wave, lane);
+}
 template <int L, int T, int NB, bool FORCE = false, int CSX = cs_of(layer_desc(L).cin), bool BF3 = false, bool OUTP = false, class H1, class H2>
 __device__ __forceinline__ void layer_std(const float* wb, const LMix<L, T, NB>& mc, const float* in, float* z, float* out,
-                                          const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier) {
+                                          const float* emb, int wave, int lane, Prof& prof, H1&& pre_gemm, H2&& pre_barrier,
+                                          const LAfr<L>* pre_afr = nullptr) {
     constexpr LDesc D = layer_desc(L);
     layer_generic<D.cin, D.cout, D.V, D.res != 0, true, T, NB, FORCE, CSX, BF3, OUTP>(wb, layer_w(wb, L), mc, in, z, out, emb + emb_off(L), wave, lane,
-                                                               prof, 32 + 3 * L, pre_gemm, pre_barrier);
+                                                               prof, 32 + 3 * L, pre_gemm, pre_barrier, pre_afr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1585,6 +1615,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }
     LMix<0, T, NB> mc0;                              // layer 0's mix coefficients: fetched one stage ahead like all the others,
     mc0.load(P.wbuf + tab_i(P.wbuf, F_TQ), P.wbuf + tab_i(P.wbuf, F_AM), wave, lane);   // i.e. in the last stage of the previous pass
+    // WEARLY: every layer's GEMM weight fragments are fetched at the end of the stage in front of the layer (see LayerAfr).
+    // 3 / 4 frames only: +0.5 % there, nothing at 6 frames, -0.9 % at 12 (profiles/r03l_wearly_ab.txt) -- the larger shapes'
+    // GEMM stages end with the other prefetches (EARLY2) already
+    constexpr bool WEARLY = !BF3 && T <= 4;
+    LAfr<0> A0;
+    if constexpr (WEARLY) load_lafr<0>(A0, P.wbuf, wave, lane);
     for (int sidx = i_first; sidx >= i_last; --sidx) {
         const float* srow = P.step_table + sidx * (4 + EDIM);
         const float* wb = P.wbuf;
@@ -1653,8 +1689,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // layer 0 reads the chain state XT[col][4] in place (x in channels 0,1): its lanes' channels 2..15 are then other
         // columns' coordinates -- finite, and multiplied by the zero-padded K rows of the layer's weights -- so no 16-channel
         // copy of x has to be zeroed and rewritten every pass
+        LAfr<1> A1; LAfr<2> A2; LAfr<3> A3; LAfr<4> A4; LAfr<5> A5; LAfr<7> A7; LAfr<8> A8; LAfr<9> A9;
+        auto wearly = [&](auto& A, auto lc) { if constexpr (WEARLY) load_lafr<decltype(lc)::value>(A, wb, wave, lane); };
+#define MCD_LC(l) std::integral_constant<int, l>{}
         layer_std<0, T, NB, (MINW <= 2), 4>(wb, mc0, XT, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
-                            [&] { mix_early(mc1, 1); }, nohook);                                           // sp1a (2 -> 16)
+                            [&] { mix_early(mc1, 1); }, [&] { wearly(A1, MCD_LC(1)); }, WEARLY ? &A0 : nullptr);     // sp1a (2 -> 16)
         STAGE(2);
         lt_dump(0, RG + PL::L0_out, 20, 16, 17);
         lt_inject(1, RG + PL::L1_in, 20, 16, 17);
@@ -1664,14 +1703,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // exp -- by the idle waves too, not on wave 0's path at the top of the pass
         silu_row(sidx > 0 ? sidx - 1 : 0, tid - NZ_T0);
         layer_std<1, T, NB, (MINW <= 2)>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
-                            [&] { mix_early(mc2, 2); }, nohook);                                           // sd1.0
+                            [&] { mix_early(mc2, 2); }, [&] { wearly(A2, MCD_LC(2)); }, WEARLY ? &A1 : nullptr);     // sd1.0
         STAGE(3);
         lt_dump(1, RG + PL::L1_out, 36, 32, 17);
         lt_inject(2, RG + PL::L2_in, 36, 32, 17);
         RsCoef<32, 17, 12, T, NB, true> rc1;
         LMix<3, T, NB> mc3;
         layer_std<2, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
-                            [&] { rs_early(rc1, 0); }, [&] { if constexpr (EARLY2) mix_early(mc3, 3); });      // sd1.1 -> d1
+                            [&] { rs_early(rc1, 0); }, [&] { if constexpr (EARLY2) mix_early(mc3, 3); }, WEARLY ? &A2 : nullptr);      // sd1.1 -> d1
         STAGE(4);
         lt_dump(2, RG + PL::L2_out, 36, 32, 17);
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
@@ -1683,20 +1722,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS1::PER * RS1::SK; ++i) sp[i] = skip1[i];
         }
+        wearly(A3, MCD_LC(3));
         bsync();
         STAGE(5);
         lt_dump(11, RG + PL::DN1_out, 36, 32, 12);
         lt_inject(3, RG + PL::L3_in, 36, 32, 12);
         LMix<4, T, NB> mc4;
         layer_std<3, T, NB, (MINW <= 2), cs_of(32), BF3>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
-                            [&] { mix_early(mc4, 4); }, nohook);                                           // sd2.0
+                            [&] { mix_early(mc4, 4); }, [&] { wearly(A4, MCD_LC(4)); }, WEARLY ? &A3 : nullptr);     // sd2.0
         STAGE(6);
         lt_dump(3, RG + PL::L3_out, 68, 64, 12);
         lt_inject(4, RG + PL::L4_in, 68, 64, 12);
         RsCoef<64, 12, 10, T, NB, true> rc2;
         LMix<5, T, NB> mc5;
         layer_std<4, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
-                            [&] { rs_early(rc2, 1); }, [&] { if constexpr (EARLY2) mix_early(mc5, 5); });      // sd2.1 -> d2
+                            [&] { rs_early(rc2, 1); }, [&] { if constexpr (EARLY2) mix_early(mc5, 5); }, WEARLY ? &A4 : nullptr);      // sd2.1 -> d2
         STAGE(7);
         lt_dump(4, RG + PL::L4_out, 68, 64, 12);
         lt_inject(12, RG + PL::L4_out, 68, 64, 12);
@@ -1710,6 +1750,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
+        wearly(A5, MCD_LC(5));
         if constexpr (!FUSE64) bsync();
         STAGE(8);
         lt_dump(12, RG + PL::DN2_out, 68, 64, 10);
@@ -1728,7 +1769,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                     if constexpr (BF3) load_afrags_bf3<8, 4>(reinterpret_cast<const float4*>(wb + lw.wpb), wave, lane, afr, 0);
                                     else load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
                                     if constexpr (EARLY2) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
-                                });  // sd3.0
+                                }, WEARLY ? &A5 : nullptr);  // sd3.0
             STAGE(9);
             lt_dump(5, RG + PL::L5_out, 132, 128, 10);
             lt_inject(6, RG + PL::L6_in, 132, 128, 10);
@@ -1791,13 +1832,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // ---- up path
         if constexpr (!EARLY2) mix_early(mc7, 7);
         resample_stage<64, 10, 12, T, NB, false, true, (MINW <= 2)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
+        wearly(A7, MCD_LC(7));
         bsync();
         STAGE(12);
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
         lt_inject(7, RG + PL::L7_in, 68, 64, 12);
         LMix<8, T, NB> mc8;
         layer_std<7, T, NB, (MINW <= 2), cs_of(64), BF3>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
-                            [&] { mix_early(mc8, 8); }, nohook);                                           // su4.0
+                            [&] { mix_early(mc8, 8); }, [&] { wearly(A8, MCD_LC(8)); }, WEARLY ? &A7 : nullptr);     // su4.0
         STAGE(13);
         lt_dump(7, RG + PL::L7_out, 68, 64, 12);
         lt_inject(8, RG + PL::L8_in, 68, 64, 12);
@@ -1813,12 +1855,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
                                     for (int i = 0; i < RS1::PER * RS1::SK; ++i) skip1[i] = sp[i];
                                 }
-                            });                                            // su4.1
+                            }, WEARLY ? &A8 : nullptr);                                            // su4.1
         STAGE(14);
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
         if constexpr (!EARLY2) mix_early(mc9, 9);
         resample_stage<32, 12, 17, T, NB, false, true, (MINW <= 2)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+        wearly(A9, MCD_LC(9));
         bsync();
         STAGE(15);
         lt_dump(14, RG + PL::UP2_out, 36, 32, 17);
@@ -1836,7 +1879,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                 [&] {
                                     mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
                                     ef_load();
-                                }, nohook);                                                              // su3.0
+                                }, nohook, WEARLY ? &A9 : nullptr);                                      // su3.0
             STAGE(16);
             lt_dump(9, RG + PL::L9_out, 36, 32, 17);
             lt_inject(10, RG + PL::L10_in, 36, 32, 17);
@@ -1933,6 +1976,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             for (int it = 0; it < TAIL_IT; ++it)
                 if (dst_t[it] >= 0) XT[dst_t[it]] = xn_t[it];
             mc0.load(wb + tab_i(wb, F_TQ), wb + tab_i(wb, F_AM), wave, lane);      // for the next pass
+            wearly(A0, MCD_LC(0));
             STAGE(21);
             bsync();
             STAGE(17);
