@@ -52,11 +52,11 @@ def f_cond(T, chans=(32, 16, 32, 32), E=16):
 assert (f_unet(3), f_unet(12), f_cond(3)) == (4_290_352, 18_524_464, 545_904)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
 PEAK_HBM_GBS = 8000.0
-# rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/r02_profile.sh): per-launch counter averages
+# rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/profile_set.sh): per-launch counter averages
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
-PMC_PROFILES = {"avenue": ("profiles/r02i_avenue_pmc.txt", 1024, 10, 5), "ubnormal_concat": ("profiles/r02i_ubnormal_concat_pmc.txt", 1024, 10, 5),
-                "seq24": ("profiles/r02i_seq24_pmc.txt", 1024, 50, 8)}
+PMC_PROFILES = {"avenue": ("profiles/r03m_avenue_pmc.txt", 1024, 10, 5), "ubnormal_concat": ("profiles/r03m_ubnormal_concat_pmc.txt", 1024, 10, 5),
+                "seq24": ("profiles/r03m_seq24_pmc.txt", 1024, 50, 8)}
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
 
 

@@ -1,7 +1,7 @@
-# Round-2 profile set of the final kernels: bench lines, kernel traces and PMC passes of the three trajectory-kernel shapes,
-# the one-launch (window-major) variant of the default workload, and the split A/B.   usage: gpurun -- bash tools/r02_profile.sh <tag> ["<configs>"]
+# Profile set of the shipped kernels (rounds 2+): bench lines, kernel traces and PMC passes of the three trajectory-kernel shapes,
+# the one-launch (window-major) variant of the default workload, and the split A/B.   usage: gpurun -- bash tools/profile_set.sh <tag> ["<configs>"]
 set -x
-TAG=${1:-r02e}
+TAG=${1:-r03m}
 CFGS=${2:-"avenue stc ubnormal_concat seq24"}
 PCFGS=${2:-"avenue avenue_onelaunch ubnormal_concat seq24"}
 R=$GRAFT_REPO_ROOT
