@@ -276,6 +276,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="tuning / A-B: alternative workgroup shape of the trajectory kernel (MCD_OPT_VARIANT)")
     ap.add_argument("--ref-value", type=float, default=None, help="the 1-GPU `value` of the same configuration: the line then carries "
                     "scaling_efficiency = value / (n_gpus x ref) (weak) or value / ref / n_gpus (strong); tools/scale_check.sh passes it")
+    ap.add_argument("--cond-generic", action="store_true", help="tuning / A-B: condition encoder as its own (runtime-channel-list) launch even "
+                    "when the workgroups own whole windows (MCD_OPT_COND_GENERIC)")
     ap.add_argument("--phase", type=int, default=0, help="tuning experiment: start offset of the second half of the grid, x 1024 cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational H2D-inclusive and opt-in legs")
@@ -325,7 +327,8 @@ def main():
     ci, xi = frame_split(seg_len, cfg["conditioning_indices"], strat)
     sc = HipScorer(sd, strategy=strat, seg_len=seg_len, cond_idx=ci, corrupt_idx=xi,
                    cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev,
-                   options=dict({"bf16x3": 1} if args.bf16x3 else {}, split=args.split, phase=args.phase, variant=args.variant))
+                   options=dict({"bf16x3": 1} if args.bf16x3 else {}, split=args.split, phase=args.phase, variant=args.variant,
+                                **({"cond_generic": 1} if args.cond_generic else {})))
     if args.scaling == "weak":
         # every rank owns its own shard of B windows per step (global window ids keep the Philox streams distinct and
         # independent of the number of GPUs)

@@ -217,6 +217,7 @@ struct ScoreParams {
     int loss_out_optional;    // host only: loss_out is the library's own scratch, not wanted when the aggregation is fused
     int plan_only;            // host only: choose `split`, do not launch
     int phase;                // tuning experiment (MCD_OPT_PHASE): the second half of the grid starts `phase` x 1024 cycles late
+    int prio_shift;           // host: log2 of the priority time slice in 100 MHz ticks (see the top of the step loop); 0 = off
     float aggr_q;
     float* loss_agg;          // (B,) aggregated loss, or null
     int cond_idx[12];         // cond_inkernel: data frames the condition encoder reads
@@ -1442,9 +1443,17 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Prof prof;
     prof.off();
+#ifdef MCD_PROFILE
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();     // (100 MHz constant clock, the same on every CU)
+#endif
     if (P.phase > 0 && blockIdx.x * 2 >= gridDim.x) {
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)P.phase * 1024ull) __builtin_amdgcn_s_sleep(32);
+    }
+    if (P.phase < 0) {      // tuning experiment: every workgroup starts at its own (hashed) offset of 0 .. 63 x |phase| x 16 cycles
+        const unsigned h = (blockIdx.x * 2654435761u) >> 26;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)h * (unsigned long long)(-P.phase) * 16ull) __builtin_amdgcn_s_sleep(32);
     }
     // this workgroup: windows win0 .. win0 + NB - 1, samples part, part + split, ...
     const int grp = blockIdx.x / P.split, part = blockIdx.x - grp * P.split;
@@ -1631,6 +1640,25 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if constexpr (MINW >= 4) {
+            // Two workgroups share a CU, and the issue arbiter serves the OLDER one first on every SIMD: over a launch in which
+            // each runs several trajectories the older one finished 18 % earlier and the younger one ran its last 400 us alone, at
+            // half the CU's throughput (tools/wg_times.py: workgroup durations 1.90 / 2.31 ms at 1024 windows) -- the whole of
+            // what the one-launch form used to lose against a grid of one-trajectory workgroups.  Priority outranks age, so
+            // the two take turns: at the top of every pass a workgroup sets its waves' priority from a time slice of the
+            // constant 100 MHz clock XOR its workgroup slot on the CU (HW_ID.TG_ID: 0 / 1) -- opposite for the two, flipping
+            // together, independent of their progress.  About six slices per launch are best (the host sizes them,
+            // launch_score_t): short ones cost throughput (a pass per slice: -2.5 %), one or two leave the tail
+            // (profiles/r03s_prio_slices.txt).
+            const int sh = P.prio_shift;
+            if (sh > 0) {
+                unsigned hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                const unsigned slice = (unsigned)(__builtin_amdgcn_s_memrealtime() >> sh);
+                if (((hwid >> 16) ^ slice) & 1u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         // ---- step prologue: this step's noise z (layer 0's mix coefficients were fetched at the end of the previous pass)
         // this step's noise z: the Philox + Box-Muller cost is paid by the two waves that have no unit in the mixes of
         // layers 0 and 1 (6 units on 8 waves), half of the elements in each of those two stages; shapes whose layer-0 mix
@@ -2045,6 +2073,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }   // samples
 #ifdef MCD_PROFILE
     __syncthreads();
+    // per-workgroup start / end time (100 MHz ticks) and CU id: P.prof[4096 + 3 b + {0, 1, 2}]
+    if (P.prof && tid0 == 0 && blockIdx.x < 6000) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        P.prof[4096 + 3 * blockIdx.x] = wg_t0;
+        P.prof[4096 + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        P.prof[4096 + 3 * blockIdx.x + 2] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+    }
     if (prof.on) {
         for (int i = 0; i < PROF_SLOTS; ++i) P.prof[i] += prof.acc[i];
         for (int i = 0; i < PL::PROFTR; ++i) P.prof[PROF_SLOTS + i] = prof.acc[PROF_SLOTS + i];
@@ -2851,11 +2889,12 @@ int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64]) {
 // no workspace -- split = S (chain-major) is one trajectory per workgroup with the encoder and the aggregation as their own
 // small launches.
 int choose_split(int n_groups, int S, int slots) {
-    // estimated makespan in units of one trajectory: rounds of workgroups x trajectories per workgroup.  Window-major pays 2 %
-    // (measured, profiles/r02f_split_ab.txt: its static schedule cannot rebalance between faster and slower CUs the way a grid
-    // of many short workgroups does); chain-major pays its two extra launches (~0.05 trajectories).
+    // estimated makespan in units of one trajectory: rounds of workgroups x trajectories per workgroup; chain-major pays its
+    // two extra launches (~0.05 trajectories).  (Round 2 charged window-major 2 %: what it lost was the tail of the YOUNGER
+    // of the two co-resident workgroups, which the alternating wave priority of score_kernel removes -- the one-launch form is
+    // now the faster one at equal rounds, profiles/r03s_prio_slices.txt.)
     auto rounds = [&](long long wgs) { return (double)((wgs + slots - 1) / slots); };
-    const double window_major = rounds(n_groups) * S * 1.02;
+    const double window_major = rounds(n_groups) * S;
     const double chain_major = rounds((long long)n_groups * S) + 0.05;
     return S > 1 && chain_major < window_major ? S : 1;
 }
@@ -2878,6 +2917,16 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
     if (fused) *fused = P.loss_agg != nullptr;
     if (P.loss_agg && P.loss_out_optional) P.loss_out = nullptr;
     if (P.mode == 0 && !P.loss_agg && !P.loss_out) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes): per-sample losses of an unfused aggregation");
+    P.prio_shift = 0;
+    if (MINW >= 4 && P.mode == 0 && P.phase != -1) {
+        // priority time slice of the co-resident workgroups (see score_kernel): about 1/6 of the launch's expected duration --
+        // rounds of workgroups x trajectories per workgroup x passes x ~7.5 us per (chain, frame) of a pass
+        const double rounds = (double)(((long long)groups * P.split + slots - 1) / slots);
+        const double traj = (double)((P.S + P.split - 1) / P.split);
+        const double ticks = rounds * traj * (double)(P.ns > 2 ? P.ns - 1 : 1) * 7.5 * NB * T * 100.0;
+        int sh = (int)floor(log2(ticks / 6.0) + 0.5);
+        P.prio_shift = sh < 10 ? 10 : (sh > 26 ? 26 : sh);
+    }
     hipLaunchKernelGGL((score_kernel<T, NB, MINW, BF3, LT>), dim3(groups * P.split), dim3(NTHREADS), PL::BYTES, st, P);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
