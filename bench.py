@@ -2,8 +2,9 @@
 """bench.py — throughput of the MoCoDAD anomaly-scoring hot path on MI355X.
 
 A "step" = one MoCoDAD.forward-equivalent call of the HIP path (condition encoder + S*(ns-1) U-Net
-passes + DDPM updates + per-sample loss + 'best' aggregation: ONE kernel launch) over one batch of synthetic pose windows
-that is already resident in HBM.  Default workload = BASELINE.json configs[1]: HR-Avenue-shaped windows
+passes + DDPM updates + per-sample loss + 'best' aggregation; ONE kernel launch whenever the batch fills the device -- the
+JSON line says which form ran, `roofline.launches_per_step`) over one batch of synthetic pose windows that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: HR-Avenue-shaped windows
 (B=1024 per step as in config/Avenue/mocodad_test.yaml, seg_len 6 = 3 condition + 3 denoised frames,
 17 joints), noise_steps=10, 5 generated samples, inject conditioning, in-kernel Philox noise.
 
@@ -428,7 +429,9 @@ def main():
         flop_per_window = P * f_unet(sc.t_unet) + (f_cond(sc.t_cond) if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
-        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2"}.get(sc.t_unet, f"runtime-shape, T_u={sc.t_unet}")
+        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2"}.get(sc.t_unet, f"runtime-shape, T_u={sc.t_unet}")
+        split_used = sc.plan_split(B, S, ns) if B > 0 else 1         # what the library chose for this call (mcd_plan_split)
+        launches = 1 if split_used == 1 else (3 if strat == "inject" else 2)
         if args.variant:
             nb += f" variant {args.variant}"
         out = {
@@ -445,9 +448,10 @@ def main():
             "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
             "step_ms_first": [round(float(v), 4) for v in step_ms[:4]] if B > 0 else None,
             "step_ms_max": [round(float(np.max(step_ms)), 4), int(np.argmax(step_ms))] if B > 0 else None,    # [ms, step index]
-            "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (" (condition encoder and aggregation inside: one launch per step)" if args.split == 1
-                                    else (f" + cond_fast_kernel<{sc.t_cond}>" if strat == "inject" else "") + " + aggregate_kernel (the library's chain-major default: "
-                                         "3 small-to-large launches per step, 1-2 % faster than the one-launch form, profiles/r02i_split_ab.txt)"),
+            "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (" (condition encoder and aggregation inside: one launch per step)" if split_used == 1
+                                    else (f" + cond_fast_kernel<{sc.t_cond}>" if strat == "inject" else "") + " + aggregate_kernel (one trajectory per workgroup: "
+                                         f"{launches} launches per step)"),
+                         "split": split_used, "launches_per_step": launches,
                          "achieved": round(achieved, 3),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                          "flop_per_window": flop_per_window, "kernel_ms_per_step": round(kern_ms, 4),

@@ -11,7 +11,9 @@
  *   - the CALLER owns every buffer (device pointers unless stated "host"); the library owns only
  *     mcd_weights_t.  All tensors are dense row-major float32 in the reference's own layouts.
  *   - compute entry points are asynchronous on the caller's hipStream_t (passed as void*), perform no
- *     allocation and no host synchronisation, and are re-entrant across streams and devices.
+ *     allocation and no host synchronisation, and are re-entrant across streams and devices.  (Exceptions, both
+ *     test / diagnostic entries: mcd_unet_forward on a frame count without a specialised kernel takes its scratch
+ *     from the stream-ordered allocator, and mcd_debug_set_prof sets one process-wide pointer.)
  *   - there is NO CPU fallback: without a gfx950 device these calls fail with MCD_EDEVICE.
  */
 #ifndef MOCODAD_HIP_H
@@ -23,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCD_ABI_VERSION 2
+#define MCD_ABI_VERSION 3
 
 enum {
     MCD_OK = 0,
@@ -109,7 +111,7 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
  * sd2.0, sd2.1, sd3.0, sd3.1, su4.0, su4.1, su3.0, su3.1), 11..14 = CNN_layer over the joint axis as called at
  * stsae_unet.py:205,213,381,391 (down1, down2, up3, up2; without the skip add).
  * x (B,Cin,t_unet,Vin), emb (B,emb_dim) = the layer's `t` argument (the layer adds Linear(SiLU(emb)); required),
- * out (B,Cout,t_unet,Vout).  Instantiated for 3 and 6 U-Net frames. */
+ * out (B,Cout,t_unet,Vout).  Instantiated for 3, 6 and 12 U-Net frames. */
 int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* emb, int32_t n_windows,
                       float* out, void* stream);
 
@@ -121,11 +123,21 @@ int mcd_philox_noise(uint64_t seed, int64_t first_window_id, int32_t n_windows, 
                      int32_t n_corrupt, float* noise_out, void* stream);
 
 /* Bytes of caller-provided device scratch a scoring call may need: condition embeddings when the condition encoder runs
- * as its own launch, (B,S) losses when an aggregation cannot be fused, scratch slabs of the runtime-shape kernels.  With
- * the shipped architecture on a specialised frame count none of it is touched and workspace == NULL is accepted. */
+ * as its own launch, (B,S) losses when an aggregation cannot be fused, scratch slabs of the runtime-shape kernels.
+ * ALWAYS allocate it: workspace == NULL is accepted only by calls that end up as ONE launch (mcd_plan_split() == 1 with the
+ * shipped condition encoder on a specialised frame count and a loss-based aggregation); every other form -- one trajectory
+ * per workgroup for small or oddly sized batches, mcd_score without aggregation, another encoder architecture, a frame count
+ * on the runtime-shape kernel -- fails with MCD_EINVAL ("workspace required") without it. */
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
-/* Per-handle options (no environment variables, no process-wide state).  Set them before the calls they affect, from the
+/* How the library would cut this scoring call into workgroups (a pure function of the shapes, the device and MCD_OPT_SPLIT):
+ * 1 = a workgroup runs every sample of its windows -- condition encoder, trajectories and aggregation in ONE kernel launch,
+ * the default for batches that fill the device (1024 windows x 5 samples on 256 CUs); n_samples = one trajectory per
+ * workgroup with the encoder and the aggregation as their own launches (better fill for small batches); 0 = the call runs
+ * on the runtime-shape kernel (no specialised instantiation for this frame count).  Negative: MCD_E*. */
+int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
+
+/* Per-handle options (no environment variables; the only process-wide state is mcd_debug_set_prof's pointer).  Set them before the calls they affect, from the
  * thread that owns the handle; none is needed for normal use.
  *   MCD_OPT_BF16X3        1: channel GEMMs (3, 6 or 12 U-Net frames) on the bf16 matrix path with both operands split into
  *                         bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate).  OPT-IN, off by default: the shipped, measured

@@ -14,7 +14,7 @@ LOSS = {"smooth_l1": 0, "l1": 1, "mse": 2}
 COND_UNET = -1  # MCD_COND_UNET
 AGGR = {"all": 0, "best": 1, "worst": 2, "mean": 3, "median": 4, "mean_pose": 5, "median_pose": 6, "quantile": 7}
 OPT = {"bf16x3": 0, "variant": 1, "cond_generic": 2, "generic_unet": 3, "split": 4, "phase": 5}     # MCD_OPT_*
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Tensor(C.Structure):
@@ -55,6 +55,7 @@ _SIGS = {
     "mcd_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_score_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(ScoreCfg)]),
+    "mcd_plan_split": (C.c_int32, [C.c_void_p, C.POINTER(ScoreCfg)]),
     "mcd_score": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_score_view": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.POINTER(WindowView), C.c_void_p, C.c_uint64,

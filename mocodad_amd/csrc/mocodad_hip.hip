@@ -3445,6 +3445,17 @@ static int64_t ws_cond_bytes(const mcd_weights* w, int64_t B) {
     const int64_t raw = B * (EDIM + C0 * (w->cfg.t_cond > 0 ? w->cfg.t_cond : 0) * 17) * 4 + 256;
     return (raw + 255) / 256 * 256;
 }
+int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg) {
+    if (!w || !cfg) return fail(MCD_EINVAL, "null argument");
+    if (cfg->n_windows <= 0) return 1;
+    if (!w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET]) return 0;
+    ScoreParams P;
+    memset(&P, 0, sizeof(P));
+    P.B = cfg->n_windows; P.S = cfg->n_samples; P.ns = cfg->noise_steps; P.mode = 0; P.plan_only = 1;
+    const int rc = launch_score(w, w->cfg.t_unet, P, nullptr);
+    return rc != MCD_OK ? rc : P.split;
+}
+
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg) {
     if (!w || !cfg) return 0;
     // condition embeddings (B,16) + gathered condition frames (B,C,Tc,V); then the scratch slabs of the runtime-shape kernels

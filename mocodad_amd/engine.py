@@ -125,6 +125,17 @@ class HipScorer:
         c.loss_fn = _lib.LOSS[loss_fn]
         return c
 
+    def plan_split(self, n_windows: int, n_samples: int, noise_steps: int) -> int:
+        """How a scoring call of this size is cut into workgroups (mcd_plan_split): 1 = ONE launch (a workgroup runs all samples
+        of its windows, condition encoder and aggregation inside), n_samples = one trajectory per workgroup + the encoder and
+        the aggregation as their own launches, 0 = runtime-shape kernel."""
+        cfg = self._score_cfg(int(n_windows), int(n_samples), int(noise_steps), "smooth_l1")
+        with torch.cuda.device(self.device):
+            r = int(self.L.mcd_plan_split(self._h, C.byref(cfg)))
+        if r < 0:
+            _lib.check(r)
+        return r
+
     # ------------------------------------------------------------------ entry points
     def _check_shape(self, what: str, t: torch.Tensor, tail: Tuple[int, ...]) -> None:
         if t.dim() != len(tail) + 1 or tuple(t.shape[1:]) != tuple(tail):
