@@ -379,6 +379,9 @@ __device__ __forceinline__ float mul_bc(float coef, float y) {
                                   : MCD_TM_IN(0), MCD_TM_IN(1), [x] "v"(x), [L] "n"(L))
 #define MCD_TM3(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) NOP : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]) \
                                   : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), [x] "v"(x), [L] "n"(L))
+#define MCD_TM4(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) MCD_DPP(OP, 3) NOP \
+                                  : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]), [y3] CON(y[3]) \
+                                  : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), MCD_TM_IN(3), [x] "v"(x), [L] "n"(L))
 #define MCD_TM6(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) MCD_DPP(OP, 3) MCD_DPP(OP, 4) MCD_DPP(OP, 5) NOP \
                                   : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]), [y3] CON(y[3]), [y4] CON(y[4]), [y5] CON(y[5]) \
                                   : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), MCD_TM_IN(3), MCD_TM_IN(4), MCD_TM_IN(5), [x] "v"(x), [L] "n"(L))
@@ -386,7 +389,7 @@ __device__ __forceinline__ float mul_bc(float coef, float y) {
                        else { if constexpr (PAD) MCD_TM##N("v_fmac_f32_dpp", "+v", "s_nop 1"); else MCD_TM##N("v_fmac_f32_dpp", "+v", ""); } } while (0)
 template <int QC, int L, bool INIT, bool PAD>
 __device__ __forceinline__ void tm_step(float (&y)[QC], const float (&c)[QC], float x) {
-    static_assert(QC == 1 || QC == 2 || QC == 3 || QC == 6, "time-mix group sizes");
+    static_assert(QC == 1 || QC == 2 || QC == 3 || QC == 4 || QC == 6, "time-mix group sizes");
     if constexpr (QC == 1) {
         if constexpr (INIT) y[0] = mul_bc<L, PAD>(c[0], x);
         else fmac_bc<L, PAD>(y[0], c[0], x);
@@ -394,6 +397,8 @@ __device__ __forceinline__ void tm_step(float (&y)[QC], const float (&c)[QC], fl
         MCD_TM(2);
     } else if constexpr (QC == 3) {
         MCD_TM(3);
+    } else if constexpr (QC == 4) {
+        MCD_TM(4);
     } else {
         MCD_TM(6);
     }
@@ -2552,6 +2557,453 @@ __global__ __launch_bounds__(GEN_THREADS) void score_generic_kernel(const ScoreP
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA path for 12 < T_u <= 32 U-Net frames (concat over 24 frames, 16 + 16, ...): the activations of such a chain do not
+// fit LDS (257 KB at layer 5 of a 24-frame chain), so the chain lives in an L2-resident slab of global memory and every
+// stage is "slab -> LDS -> MFMA stage function -> slab", one 512-thread workgroup per chain at a time:
+//   mix    the time mix couples all frames: 32 channels of ALL frames are staged in LDS (<= 78 KB) and mixed by mix_long
+//          (the matrix-core joint mix of mix_stage with the time mix sliced over the frames); z goes to the slab
+//   GEMM   per chunk of 8 frames: z and x of the chunk -> LDS, gemm_tiles (two tiles in flight) -> epilogue -> slab
+//   joint resamplers per chunk of 8 frames through resample_stage; the U-Net skips d1 / d2 are slab buffers
+// The frame count is padded to TP = 16, 24 or 32 with zero mixing coefficients (a padded frame's activations are finite
+// garbage that no real frame ever reads).  Same noise keys, update, loss and strategies as score_kernel.
+// ------------------------------------------------------------------------------------------------
+struct TiledNet {
+    int tq[NLAYERS], am[NLAYERS], wp[NLAYERS], bias[NLAYERS];
+    float slope[NLAYERS];
+    int rsw[4];          // joint resamplers, non-capture fragment packs (RsCoef chunks: fragments then bias)
+    int we, be;
+};
+constexpr int TL_FC = 8;                                     // frames per GEMM / resampler chunk
+__host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
+__host__ __device__ constexpr long long tl_slab_floats(int TP) {
+    // A0, A1 (ping-pong, up to 128 ch x 10 joints), Zg, D1, D2 -- each with 16 rows of padding behind it
+    return (long long)2 * (TP * 10 + 16) * 132 + (long long)(TP * 12 + 16) * 68 + (long long)(TP * 17 + 16) * 36 + (long long)(TP * 12 + 16) * 68;
+}
+
+// cooperative copies between the slab and LDS, `ch` channels (multiple of 4) from channel ch0 of `rows` rows
+__device__ __forceinline__ void tl_g2l(float* dst, int ds, const float* src, int ss, int ch0, int ch, int rows) {
+    const int q = ch >> 2;
+    for (int u = threadIdx.x; u < rows * q; u += NTHREADS) {
+        const int r = u / q, c = (u - r * q) * 4;
+        *reinterpret_cast<float4*>(dst + r * ds + c) = load_global4(src + (size_t)r * ss + ch0 + c);
+    }
+}
+__device__ __forceinline__ void tl_l2g(float* dst, int ds, const float* src, int ss, int ch, int rows, const float* add) {
+    const int q = ch >> 2;
+    for (int u = threadIdx.x; u < rows * q; u += NTHREADS) {
+        const int r = u / q, c = (u - r * q) * 4;
+        float4 v = *reinterpret_cast<const float4*>(src + r * ss + c);
+        if (add) { const float4 a = load_global4(add + (size_t)r * ds + c); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        *reinterpret_cast<float4*>(dst + (size_t)r * ds + c) = v;
+    }
+}
+
+// zero start of a mix's accumulators: the 4-joint fragment form and the single-joint form (joint 16 of the V = 17 layers)
+struct ZeroInitL {
+    __device__ __forceinline__ f32x4 operator()(int, int, int, std::true_type) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ float operator()(int, int, int) const { return 0.f; }
+};
+// mix of CINV (16 or 32) channels over ALL TP frames: X (LDS, [frame * V + joint][channel], stride cs) -> store functor.
+// unit = (16-channel block, QC output frames); joint mix on the matrix cores exactly as in mix_stage, the time mix as
+// tm_step groups over one k-step's TP input frames at a time.
+template <int CINV, int V, int TP, class Init, class Store>
+__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const float* __restrict__ tqd, const float* __restrict__ af,
+                                         int wave, int lane, Init&& init, Store&& store) {
+    constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, KP = 2 * (KS / 2), MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
+    constexpr int UNITS = CB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
+    constexpr bool J16 = V == 17;
+    constexpr int MTM = J16 ? 1 : MT;
+    const int j = lane & 15, g = lane >> 4;
+    gfloat* tqd_g = as_global(tqd);
+    gfloat* af_g = as_global(af);
+    for (int rnd = 0; rnd < PER; ++rnd) {
+        const int u = wave + rnd * NWAVES;
+        if (u >= UNITS) break;
+        const int cb = u % CB, q0 = (u / CB) * QC;
+        float tq[QC][NR], aop[QC][MT][KS];
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) tq[qi][r] = tqd_g[((q0 + qi) * NR + r) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
+        }
+        f32x4 acc[QC][MTM];
+        float part[QC];
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+            part[qi] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt) acc[qi][mt] = init(q0 + qi, mt * 16 + 4 * g, cb * 16 + j, std::true_type{});
+        }
+        const float* xin_p = X + __mul24(4 * (g & 1) + (g >> 1), cs) + cb * 16 + j;
+        const float* xin_l = X + __mul24(g, cs) + cb * 16 + j;
+        static_for<KS>([&](auto si) {
+            constexpr int ks = decltype(si)::value;
+            constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
+            const float* xb = ks < KP ? xin_p : xin_l;
+            float x[TP];
+#pragma unroll
+            for (int t = 0; t < TP; ++t) x[t] = xb[(t * V + vbase) * cs];
+            __builtin_amdgcn_sched_barrier(0);
+            float y[QC];
+            static_for<TP>([&](auto ti) {
+                constexpr int t = decltype(ti)::value;
+                float c[QC];
+#pragma unroll
+                for (int qi = 0; qi < QC; ++qi) c[qi] = tq[qi][(ks * TP + t) / 16];
+                tm_step<QC, (ks * TP + t) % 16, t == 0, t == TP - 1>(y, c, x[t]);
+            });
+            static_for<QC>([&](auto qq) {
+                constexpr int qi = decltype(qq)::value;
+#pragma unroll
+                for (int mt = 0; mt < MTM; ++mt)
+                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y[qi], acc[qi][mt], 0, 0, 0);
+                if constexpr (J16) part[qi] = fmaf(aop[qi][1][ks], y[qi], part[qi]);
+            });
+        });
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt) store(q0 + qi, mt * 16 + 4 * g, cb * 16 + j, acc[qi][mt]);
+            if constexpr (J16) {
+                const unsigned pu = __float_as_uint(part[qi]);
+                const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                const float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                if (g == 0) store(q0 + qi, 16, cb * 16 + j, z16 + init(q0 + qi, 16, cb * 16 + j));
+            }
+        }
+    }
+}
+
+// channel GEMM + epilogue of one 8-frame chunk: z / x chunks in LDS ([col][ch], strides cs_of(CIN) / CSX), result rows to
+// the slab (row stride cs_of(COUT)); COLS = real columns of the chunk (the last tile's pad columns are not stored)
+template <int CIN, int COUT, int COLS, bool RES, int CSX, class AF>
+__device__ __forceinline__ void tl_gemm(const AF& A, float slope, const float* __restrict__ z, const float* __restrict__ x,
+                                        float* __restrict__ outg, const float* __restrict__ embl, int wave, int lane) {
+    constexpr int MT = ceil16(COUT) / 16, NT = ceil16(COLS) / 16, CSI = cs_of(CIN), CSO = cs_of(COUT);
+    constexpr int KQ1 = CIN / 16, KQ2 = RES ? CIN / 16 : 0;
+    const float pinf = prelu_bound(slope);
+    const int mt = wave % MT;
+    const float4 e = embl ? *reinterpret_cast<const float4*>(embl + mt * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bcur = A.bcur;
+    auto epi = [&](auto, int col, int c0, f32x4 acc, int, int) {
+        if (col < COLS && (COUT % 16 == 0 || c0 < COUT)) {
+            f32x2 t0 = f32x2{acc[0], acc[1]}, t1 = f32x2{acc[2], acc[3]};
+            if constexpr (!RES) { t0 += f32x2{bcur.x, bcur.y}; t1 += f32x2{bcur.z, bcur.w}; }
+            const f32x2 m0 = t0 * slope, m1 = t1 * slope;
+            const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf)} + f32x2{e.x, e.y};
+            const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf)} + f32x2{e.z, e.w};
+            *reinterpret_cast<float4*>(outg + (size_t)col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
+        }
+    };
+    gemm_tiles<MT, NT, KQ1, KQ2, !RES, true>(A.a, z, CSI, x, CSX, wave, lane, epi, 0, RES ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+template <int TP>
+__global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
+                                                                  float* __restrict__ slabs) {
+    constexpr int R17 = TP * 17, R12 = TP * 12, R10 = TP * 10;
+    constexpr int NFC = TP / TL_FC;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS: work region RA (mix: 32 channels of all frames; GEMM: z chunk + x chunk), chain state XT[col][4] (+ pad), tables
+    constexpr int RA_F = cmax((R17 + 16) * 36, 2 * 96 * 68);      // mix: 32 channels x all frames (+ pad rows); GEMM: z + x chunks
+    float* const RA = smem;
+    float* const XT = RA + RA_F;                    // [R17 + 16][4]
+    float* const EMB = XT + (R17 + 16) * 4;         // [EMB_TOTAL + 4]
+    float* const SE = EMB + EMB_TOTAL + 4;          // [16]
+    float* const ZN = SE + EDIM;                    // [R17][2]  this step's noise
+    float* const ZO = ZN + R17 * C0;                // [R17][2]  layer 10's mixed output
+    float* const P4 = ZO + R17 * C0;                // [R17][4]  layer 10's W-first product
+    float* const RED = P4 + R17 * 4;                // [NTHREADS]
+    const int tid0 = threadIdx.x;
+    int tid = tid0, lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* wb = P.wbuf;
+    float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TP);
+    const int Tx = P.n_corrupt, K = P.ns > 2 ? P.ns - 1 : 1, per = C0 * Tx * 17;
+    for (int u = tid; u < (int)tl_slab_floats(TP); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
+    for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
+    for (int u = tid; u < RA_F; u += NTHREADS) RA[u] = 0.f;           // pad rows meet zero coefficients: they must be finite
+
+    for (long long chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
+        const int b = (int)(chain / P.S), s = (int)(chain % P.S);
+        const unsigned fixed = (unsigned)(P.win_mask ? P.win_mask[b] : P.fixed_mask);
+        auto tx_of = [&](int t) { return P.win_mask ? __popc(~fixed & ((1u << t) - 1u)) : M.tx_of[t]; };
+        auto src_of = [&](int t) { return P.win_mask ? t : M.src_frame[t]; };
+        __syncthreads();
+        for (int u = tid; u < T * 17; u += NTHREADS) {
+            const int t = u / 17, v = u % 17;
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+                float x;
+                if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
+                else {
+                    const int e = (c * Tx + tx_of(t)) * 17 + v;
+                    x = P.noise ? P.noise[((size_t)(s * K + 0) * P.B + b) * per + e]
+                                : philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
+                }
+                XT[u * 4 + c] = x;
+            }
+        }
+        for (int sidx = P.ns - 1; sidx >= 1; --sidx) {
+            const float* srow = P.step_table + sidx * (4 + EDIM);
+            // opaque per step (see score_kernel): otherwise every per-lane address of every stage is hoisted out of the step
+            // loop as loop-invariant and the hundreds of resulting registers are spilled
+            tid = tid0;
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63;
+            wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            wb = P.wbuf;
+            asm volatile("" : "+s"(wb));
+            float* sl = slab;
+            asm volatile("" : "+s"(sl));
+            float* const A0 = sl;
+            float* const A1 = A0 + (R10 + 16) * 132;
+            float* const Zg = A1 + (R10 + 16) * 132;
+            float* const D1 = Zg + (R12 + 16) * 68;
+            float* const D2 = D1 + (R17 + 16) * 36;
+            __syncthreads();
+            if (tid < EDIM) {
+                float e = srow[4 + tid];
+                if (P.cond_emb) e += P.cond_emb[(size_t)b * EDIM + tid];
+                SE[tid] = e / (1.f + expf(-e));
+            }
+            if (sidx > 1) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
+                const int k = P.ns - sidx;
+                for (int gi = tid; gi < T * 9; gi += NTHREADS) {
+                    const int t = gi / 9, v0 = (gi % 9) * 2;
+                    float z[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (!((fixed >> t) & 1u)) {
+                        const int tx = tx_of(t);
+                        if (P.noise) {
+                            const float* zp = P.noise + ((size_t)(s * K + k) * P.B + b) * per + tx * 17 + v0;
+                            z[0] = zp[0]; z[1] = zp[Tx * 17];
+                            if (v0 + 1 < 17) { z[2] = zp[1]; z[3] = zp[Tx * 17 + 1]; }
+                        } else {
+                            philox_normal4(P.seed, (unsigned)(tx * 9 + (v0 >> 1)), (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b), z);
+                        }
+                    }
+                    float* zo = ZN + (t * 17 + v0) * C0;
+                    zo[0] = z[0]; zo[1] = z[1];
+                    if (v0 + 1 < 17) { zo[2] = z[2]; zo[3] = z[3]; }
+                }
+            }
+            __syncthreads();
+            for (int o = tid; o < EMB_TOTAL; o += NTHREADS) {
+                const float* we = wb + N.we + o * EDIM;
+                float a = wb[N.be + o];
+#pragma unroll
+                for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[k], a);
+                EMB[o] = a;
+            }
+            __syncthreads();
+
+            // ---- one mix-first ST-GCN layer: xin (slab or XT) -> xout (slab)
+            auto layer = [&](auto lc, const float* xin, bool xin_lds, float* xout) {
+                constexpr int L = decltype(lc)::value;
+                constexpr LDesc D = layer_desc(L);
+                constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
+                constexpr int CSX = L == 0 ? 4 : CSI;            // layer 0 reads the chain state in place (see score_kernel)
+                constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSV = L == 0 ? 4 : cs_of(CINV);
+                constexpr int ROWS = TP * V, CROWS = TL_FC * V, CPAD = ceil16(CROWS);
+                // mix: 32 channels of all frames at a time
+                for (int h = 0; h < NH; ++h) {
+                    const float* Xl = xin;
+                    if (!xin_lds) {
+                        __syncthreads();
+                        tl_g2l(RA, CSV, xin, CSI, h * CINV, CINV, ROWS);
+                        __syncthreads();
+                        Xl = RA;
+                    }
+                    float* zg = Zg + h * CINV;
+                    mix_long<CINV, V, TP>(Xl, CSV, wb + N.tq[L], wb + N.am[L], wave, lane, ZeroInitL{},
+                                          [&](int q, int w0, int c, auto v) {
+                                              float* zp = zg + (size_t)(q * V + w0) * CSI + c;
+                                              if constexpr (std::is_same_v<decltype(v), f32x4>) {
+#pragma unroll
+                                                  for (int r = 0; r < 4; ++r)
+                                                      if (w0 + r < V) zp[r * CSI] = v[r];
+                                              } else {
+                                                  *zp = v;
+                                              }
+                                          });
+                }
+                // GEMM + epilogue per chunk of 8 frames
+                LayerAfr<(CIN / 16) * (D.res ? 2 : 1)> A;
+                {
+                    LayerW lw;
+                    lw.wp = N.wp[L]; lw.bias = N.bias[L];
+                    A.template load<ceil16(COUT) / 16>(wb, lw, wave, lane);
+                }
+                float* const zc = RA;
+                float* const xc = RA + CPAD * CSI;
+                for (int fc = 0; fc < NFC; ++fc) {
+                    __syncthreads();
+                    tl_g2l(zc, CSI, Zg + (size_t)fc * CROWS * CSI, CSI, 0, CIN, CPAD);
+                    if (!xin_lds) tl_g2l(xc, CSI, xin + (size_t)fc * CROWS * CSI, CSI, 0, CIN, CPAD);
+                    __syncthreads();
+                    const float* xs = xin_lds ? xin + fc * CROWS * CSX : xc;
+                    tl_gemm<CIN, COUT, CROWS, D.res != 0, CSX>(A, N.slope[L], zc, xs, xout + (size_t)fc * CROWS * CSO, EMB + emb_off(L), wave, lane);
+                }
+                __syncthreads();
+            };
+            // ---- one joint resampler: xin (slab, C channels at VIN joints) -> xout (+ skip), per chunk of 8 frames
+            auto resample = [&](auto cc, auto vic, auto voc, int r, const float* xin, float* xout, const float* skip) {
+                constexpr int C = decltype(cc)::value, VIN = decltype(vic)::value, VOUT = decltype(voc)::value, CS = cs_of(C);
+                constexpr int IR = TL_FC * VIN, OR = TL_FC * VOUT;
+                RsCoef<C, VIN, VOUT, TL_FC, 1, false> rc;
+                rc.load(wb + N.rsw[r], wb + N.rsw[r] + ((VOUT + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                float* const ic = RA;
+                float* const oc = RA + ceil16(IR) * CS;
+                float nosk[1] = {0.f};
+                for (int fc = 0; fc < NFC; ++fc) {
+                    __syncthreads();
+                    tl_g2l(ic, CS, xin + (size_t)fc * IR * CS, CS, 0, C, IR);
+                    __syncthreads();
+                    resample_stage<C, VIN, VOUT, TL_FC, 1, false, false, true>(ic, CS, oc, CS, rc, nosk, wave, lane);
+                    __syncthreads();
+                    tl_l2g(xout + (size_t)fc * OR * CS, CS, oc, CS, C, OR, skip ? skip + (size_t)fc * OR * CS : nullptr);
+                }
+                __syncthreads();
+            };
+#define TL_C(x) std::integral_constant<int, x>{}
+            layer(TL_C(0), XT, true, A0);
+            layer(TL_C(1), A0, false, A1);
+            layer(TL_C(2), A1, false, D1);                                  // -> d1
+            resample(TL_C(32), TL_C(17), TL_C(12), 0, D1, A0, nullptr);     // down1
+            layer(TL_C(3), A0, false, A1);
+            layer(TL_C(4), A1, false, D2);                                  // -> d2
+            resample(TL_C(64), TL_C(12), TL_C(10), 1, D2, A0, nullptr);     // down2
+            layer(TL_C(5), A0, false, A1);                                  // 64 -> 128
+            {   // ---- layer 6 (128 -> 64) W-first: P = [W_t; W_r] x per chunk -> A0 (rows x 132: P_t | P_r), then the mix on P_t
+                constexpr int CROWS = TL_FC * 10;
+                LayerAfr<8> A;
+                { LayerW lw; lw.wp = N.wp[6]; lw.bias = N.bias[6]; A.template load<8>(wb, lw, wave, lane); }
+                auto epi6 = [&](float* pg) {
+                    return [pg](auto, int col, int c0, f32x4 acc, int, int) {
+                        if (col < CROWS) *reinterpret_cast<float4*>(pg + (size_t)col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    };
+                };
+                for (int fc = 0; fc < NFC; ++fc) {
+                    __syncthreads();
+                    tl_g2l(RA, 132, A1 + (size_t)fc * CROWS * 132, 132, 0, 128, CROWS);
+                    __syncthreads();
+                    gemm_tiles<8, CROWS / 16, 8, 0, false, true>(A.a, RA, 132, RA, 132, wave, lane, epi6(A0 + (size_t)fc * CROWS * 132), 0);
+                }
+                const float slope6 = N.slope[6], pinf6 = prelu_bound(slope6);
+                for (int h = 0; h < 2; ++h) {
+                    __syncthreads();
+                    tl_g2l(RA, 36, A0, 132, h * 32, 32, R10);
+                    __syncthreads();
+                    const float* pr = A0 + 64 + h * 32;
+                    float* og = A1 + h * 32;              // out6 (64 ch, stride 68) over the dead layer-5 output
+                    const float* bias = wb + N.bias[6] + h * 32;
+                    const float* e6 = EMB + emb_off(6) + h * 32;
+                    mix_long<32, 10, TP>(RA, 36, wb + N.tq[6], wb + N.am[6], wave, lane,
+                                         [&](int q, int w0, int c, std::true_type) {
+                                             const float* pp = pr + (size_t)(q * 10 + w0) * 132 + c;
+                                             return f32x4{pp[0], pp[132], pp[264], pp[396]};          // (rows >= 10 of the fragment: next frame's, never stored)
+                                         },
+                                         [&](int q, int w0, int c, f32x4 v) {
+                                             const float bb = bias[c], ee = e6[c];
+                                             float* op = og + (size_t)(q * 10 + w0) * 68 + c;
+#pragma unroll
+                                             for (int r = 0; r < 4; ++r)
+                                                 if (w0 + r < 10) op[r * 68] = __builtin_amdgcn_fmed3f(v[r] + bb, (v[r] + bb) * slope6, pinf6) + ee;
+                                         });
+                }
+                __syncthreads();
+            }
+            // (the layer-6 output was written with row stride 68 into A1; the P rows of A0 are dead)
+            resample(TL_C(64), TL_C(10), TL_C(12), 2, A1, A0, D2);          // up3 + d2
+            layer(TL_C(7), A0, false, A1);
+            layer(TL_C(8), A1, false, A0);
+            resample(TL_C(32), TL_C(12), TL_C(17), 3, A0, A1, D1);          // up2 + d1
+            layer(TL_C(9), A1, false, A0);
+            {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
+                const float* w4 = wb + N.wp[10];
+                for (int u = tid; u < R17 * 4; u += NTHREADS) {
+                    const int col = u >> 2, r = u & 3;
+                    const float* xp = A0 + (size_t)col * 36;
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 x = load_global4(xp + 4 * q);
+                        a = fmaf(w4[r * 32 + 4 * q + 0], x.x, a); a = fmaf(w4[r * 32 + 4 * q + 1], x.y, a);
+                        a = fmaf(w4[r * 32 + 4 * q + 2], x.z, a); a = fmaf(w4[r * 32 + 4 * q + 3], x.w, a);
+                    }
+                    P4[u] = a;
+                }
+                __syncthreads();
+                // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
+                mix_long<16, 17, TP>(P4, 4, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
+                                     [&](int q, int w0, int c, auto v) {
+                                         if (c < C0) {
+                                             float* zp = ZO + ((q * 17 + w0)) * C0 + c;
+                                             if constexpr (std::is_same_v<decltype(v), f32x4>) {
+#pragma unroll
+                                                 for (int r = 0; r < 4; ++r)
+                                                     if (w0 + r < 17) zp[r * C0] = v[r];
+                                             } else {
+                                                 *zp = v;
+                                             }
+                                         }
+                                     });
+                __syncthreads();
+                // eps = layer 10 + x; DDPM update of the frame each prediction drives (mocodad.py:172-178,829-838)
+                const float slope10 = N.slope[10], ca = srow[0], cb = srow[1], csg = srow[2];
+                const bool zadd = sidx > 1;
+                constexpr int NIT = (C0 * 32 * 17 + NTHREADS - 1) / NTHREADS;
+                float xn[NIT];
+                int dst[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int u = tid + it * NTHREADS;
+                    dst[it] = -1; xn[it] = 0.f;
+                    if (u < T * 17 * C0) {
+                        const int c = u % C0, col = u / C0, t = col / 17, v = col % 17;
+                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[N.bias[10] + c], slope10) + EMB[emb_off(10) + c];
+                        const float eps = l10 + XT[col * 4 + c];
+                        const int k = P.win_mask ? (((fixed >> t) & 1u) ? -1 : 0) : M.upd_of[t];
+                        if (k >= 0) {
+                            const int tp = P.win_mask ? t : M.pos_of[k];
+                            const int colp = tp * 17 + v;
+                            xn[it] = ca * (XT[colp * 4 + c] - cb * eps) + csg * (zadd ? ZN[colp * C0 + c] : 0.f);
+                            dst[it] = colp * 4 + c;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (dst[it] >= 0) XT[dst[it]] = xn[it];
+            }
+        }
+        __syncthreads();
+        // ---- loss over the corrupt frames (mocodad.py:484)
+        float part = 0.f;
+        for (int e = tid; e < per; e += NTHREADS) {
+            const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
+            int tu = M.pos_of[tx];
+            if (P.win_mask) { int cnt = 0; for (int t = 0; t < T; ++t) if (!((fixed >> t) & 1u)) { if (cnt == tx) tu = t; ++cnt; } }
+            const float x0 = XT[(tu * 17 + v) * 4 + c];
+            const float gt = load_coord(P.dv, b, c, src_of(tu), v, P.seg_len);
+            part += loss_elem(x0, gt, P.loss_fn);
+            if (P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
+        }
+        RED[tid] = part;
+        __syncthreads();
+        for (int o = NTHREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
+        if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
+    }
+}
+
 // 'E_unet' condition encoder at any frame count (the U-Net's down path without embeddings + to_time_dim), same scratch scheme
 struct GenCond { GLayer L[7]; int rs_w[2], rs_b[2], lw, lb; };
 __global__ __launch_bounds__(GEN_THREADS) void cond_unet_generic_kernel(const float* wb, const GenCond N, const DataView dv, const FrameIdx fi,
@@ -2775,17 +3227,19 @@ bool pack_mix(TensorMap& tm, const std::string& p, int T, int V, Builder& B, int
 }
 
 // fragment-order coefficients for the MFMA mix (see mix_stage)
-bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B, int& tqf, int& af) {
+// (TP > T: the tables of a frame count padded to TP -- score_tiled_kernel -- with zero coefficients for the pad frames)
+bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B, int& tqf, int& af, int TP = 0) {
     const float* Tm = tm.get(p + ".gcn.T", (int64_t)V * T * T);
     const float* A = tm.get(p + ".gcn.A", (int64_t)T * V * V);
     if (!Tm || !A) return false;
+    if (TP < T) TP = T;
     const int KS = (V + 3) / 4, MT = (V + 15) / 16;
-    const int NR = (KS * T + 15) / 16;
-    tqf = B.alloc((size_t)T * NR * 64);
-    af = B.alloc((size_t)T * MT * KS * 64);
+    const int NR = (KS * TP + 15) / 16;
+    tqf = B.alloc((size_t)TP * NR * 64);
+    af = B.alloc((size_t)TP * MT * KS * 64);
     for (int q = 0; q < T; ++q) for (int r = 0; r < NR; ++r) for (int lane = 0; lane < 64; ++lane) {
-        const int i = lane & 15, g = lane >> 4, idx = r * 16 + i, s = idx / T, t = idx % T, v = mix_vmap(V, s, g);
-        B.buf[tqf + (q * NR + r) * 64 + lane] = (idx < KS * T && v < V) ? Tm[(v * T + t) * T + q] : 0.f;
+        const int i = lane & 15, g = lane >> 4, idx = r * 16 + i, s = idx / TP, t = idx % TP, v = mix_vmap(V, s, g);
+        B.buf[tqf + (q * NR + r) * 64 + lane] = (idx < KS * TP && v < V && t < T) ? Tm[(v * T + t) * T + q] : 0.f;
     }
     for (int q = 0; q < T; ++q) for (int s = 0; s < KS; ++s) for (int lane = 0; lane < 64; ++lane) {
         const int j = lane & 15, g = lane >> 4, v = mix_vmap(V, s, g);
@@ -2850,6 +3304,8 @@ struct mcd_weights {
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
     bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
     bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3, 4, 5, 6, 8, 10, 12); otherwise the runtime-shape kernel
+    TiledNet tiled;   // tables of score_tiled_kernel (12 < t_unet <= 32), frame count padded to tiled_tp
+    int tiled_tp;     // 16, 24 or 32; 0 = none
     GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
     GenCond gcond;    // ... and of the 'E_unet' condition encoder
     int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
@@ -3025,6 +3481,30 @@ int launch_score_generic(const mcd_weights* w, const ScoreParams& P, const Frame
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
+// MFMA kernel of the long windows (12 < T <= 32); slabs: tl_slab_floats(TP) floats per workgroup
+template <int TP>
+int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
+    constexpr size_t lds = ((size_t)cmax((TP * 17 + 16) * 36, 2 * 96 * 68) + (TP * 17 + 16) * 4 + EMB_TOTAL + 4 + EDIM + TP * 17 * 2 * 2 + TP * 17 * 4 + NTHREADS) * 4;
+    LDS_LIMIT((&score_tiled_kernel<TP>), lds);
+    hipLaunchKernelGGL((score_tiled_kernel<TP>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
+int tiled_wgs(int64_t units) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return (int)(units < cus ? units : cus);         // one workgroup per CU (70 - 111 KB of LDS), persistent over the chains
+}
+int64_t tiled_scratch_bytes(int64_t units, int TP) { return (int64_t)tiled_wgs(units) * tl_slab_floats(TP) * 4; }
+int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st) {
+    const int wgs = tiled_wgs(P.n_chains);
+    switch (w->tiled_tp) {
+        case 16: return launch_score_tiled_t<16>(w, P, M, scratch, wgs, st);
+        case 24: return launch_score_tiled_t<24>(w, P, M, scratch, wgs, st);
+        case 32: return launch_score_tiled_t<32>(w, P, M, scratch, wgs, st);
+        default: return fail(MCD_EUNSUPPORTED, "tiled kernel: frame count");
+    }
+}
 // the condition encoders that read the condition frames straight from the window view: the MFMA kernels for the frame
 // counts they are instantiated for, the runtime-shape 'E_unet' kernel otherwise (scratch: gen_scratch_bytes(B, Tc))
 int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, float* scratch,
@@ -3149,6 +3629,32 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         for (int vo = 0; vo < vout; ++vo) B.buf[G.rs_b[r] + vo] = (float)f.b[vo];
     }
     G.we = U.we; G.be = U.be;
+    // tables of score_tiled_kernel (12 < T <= 32): mix coefficients for the padded frame count, non-capture resampler packs;
+    // GEMM fragments, biases, slopes and the embedding Linear are the specialised kernels' own
+    TiledNet TN;
+    memset(&TN, 0, sizeof(TN));
+    const int tiled_tp = (T > 12 && T <= 32) ? (T <= 16 ? 16 : T <= 24 ? 24 : 32) : 0;
+    if (tiled_tp) {
+        for (int l = 0; l < NLAYERS; ++l) {
+            const LDesc D = layer_desc(l);
+            if (!pack_mix_mfma(tm, std::string("model.") + names[l], T, D.V, B, TN.tq[l], TN.am[l], tiled_tp)) return fail(MCD_EMISSING, tm.missing);
+            TN.wp[l] = U.L[l].wp; TN.bias[l] = U.L[l].bias; TN.slope[l] = U.L[l].slope;
+        }
+        for (int r = 0; r < 4; ++r) {
+            Folded f;
+            if (!fold_conv_bn(tm, std::string("model.") + rs_names[r] + ".block.0", std::string("model.") + rs_names[r] + ".block.1", rs_out[r], rs_in[r], f))
+                return fail(MCD_EMISSING, tm.missing);
+            const int vin = rs_in[r], vout = rs_out[r], KS = (vin + 3) / 4, MTr = (vout + 15) / 16;
+            const int wf = B.alloc((size_t)MTr * KS * 64 + 32);
+            for (int mt = 0; mt < MTr; ++mt) for (int ks = 0; ks < KS; ++ks) for (int lane = 0; lane < 64; ++lane) {
+                const int vo = (vout == 17 && mt == 1) ? 16 : mt * 16 + (lane & 15), v = rs_vmap(false, vin, ks, lane >> 4);
+                B.buf[wf + (mt * KS + ks) * 64 + lane] = (vo < vout && v < vin) ? (float)f.w[(size_t)vo * vin + v] : 0.f;
+            }
+            for (int vo = 0; vo < vout; ++vo) B.buf[wf + MTr * KS * 64 + vo] = (float)f.b[vo];
+            TN.rsw[r] = wf;
+        }
+        TN.we = U.we; TN.be = U.be;
+    }
     // condition encoder
     CondW Cw;
     memset(&Cw, 0, sizeof(Cw));
@@ -3308,7 +3814,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev_dev};
     mcd_weights* w = new mcd_weights();
     memset(w->opt, 0, sizeof(w->opt));
-    w->zero_row = zero_row; w->fast_unet = fast_unet; w->gen = G; w->gcond = GC;
+    w->zero_row = zero_row; w->fast_unet = fast_unet; w->gen = G; w->gcond = GC; w->tiled = TN; w->tiled_tp = tiled_tp;
     w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast; w->cond_unet = cond_unet;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -3462,6 +3968,10 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
     // (frame counts without a specialised instantiation, or MCD_OPT_GENERIC_UNET / MCD_OPT_COND_GENERIC)
     int64_t gen = 0;
     if (!w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET]) gen = gen_scratch_bytes((int64_t)cfg->n_windows * cfg->n_samples, w->cfg.t_unet);
+    if (!w->fast_unet && w->tiled_tp) {
+        const int64_t g3 = tiled_scratch_bytes((int64_t)cfg->n_windows * cfg->n_samples, w->tiled_tp);
+        if (g3 > gen) gen = g3;
+    }
     if (w->cond_unet) { const int64_t g2 = gen_scratch_bytes(cfg->n_windows, w->cond.Tc); if (g2 > gen) gen = g2; }
     return ws_cond_bytes(w, cfg->n_windows) + ws_loss_bytes(cfg->n_windows, cfg->n_samples) + gen;
 }
@@ -3573,7 +4083,9 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
             rc = launch_score(w, Tu, P, st, &fused);
         } else {
             if (!workspace) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape kernel");
-            rc = launch_score_generic(w, P, M, gen_scratch, st);
+            // 12 < T <= 32: the MFMA kernel over an L2-resident slab; everything else (and MCD_OPT_GENERIC_UNET): plain FMAs
+            if (w->tiled_tp && !w->opt[MCD_OPT_GENERIC_UNET]) rc = launch_score_tiled(w, P, M, gen_scratch, st);
+            else rc = launch_score_generic(w, P, M, gen_scratch, st);
         }
         if (rc != MCD_OK || aggr == 0 || fused) return rc;
         AggrParams A;        // the workgroups did not see all samples of their windows: aggregate the (B,S) losses afterwards
