@@ -2574,7 +2574,15 @@ struct TiledNet {
     int rsw[4];          // joint resamplers, non-capture fragment packs (RsCoef chunks: fragments then bias)
     int we, be;
 };
-constexpr int TL_FC = 8;                                     // frames per GEMM / resampler chunk
+#ifndef MCD_X_TLFC
+#define MCD_X_TLFC 1
+#endif
+// frames per GEMM / resampler chunk: half the padded frame count at 24 / 32 frames, all 16 at 16 (fewer, longer stages:
+// every chunk costs two barriers that wait for the previous stage's slab stores to land)
+__host__ __device__ constexpr int tl_fc(int TP) { return MCD_X_TLFC ? (TP == 24 ? 12 : 16) : 8; }
+__host__ __device__ constexpr int tl_ra_floats(int TP) {          // LDS work region: mix (32 channels x all frames + pad rows) | GEMM (z + x chunks)
+    return cmax((TP * 17 + 16) * 36, 2 * ceil16(tl_fc(TP) * 12) * 68);
+}
 __host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
 __host__ __device__ constexpr long long tl_slab_floats(int TP) {
     // A0, A1 (ping-pong, up to 128 ch x 10 joints), Zg, D1, D2 -- each with 16 rows of padding behind it
@@ -2589,15 +2597,37 @@ __device__ __forceinline__ void tl_g2l(float* dst, int ds, const float* src, int
         *reinterpret_cast<float4*>(dst + r * ds + c) = load_global4(src + (size_t)r * ss + ch0 + c);
     }
 }
-__device__ __forceinline__ void tl_l2g(float* dst, int ds, const float* src, int ss, int ch, int rows, const float* add) {
+__device__ __forceinline__ void tl_l2g(int tid, float* dst, int ds, const float* src, int ss, int ch, int rows, const float* add) {
     const int q = ch >> 2;
-    for (int u = threadIdx.x; u < rows * q; u += NTHREADS) {
+    for (int u = tid; u < rows * q; u += NTHREADS) {
         const int r = u / q, c = (u - r * q) * 4;
         float4 v = *reinterpret_cast<const float4*>(src + r * ss + c);
         if (add) { const float4 a = load_global4(add + (size_t)r * ds + c); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
         *reinterpret_cast<float4*>(dst + (size_t)r * ds + c) = v;
     }
 }
+
+// slab -> LDS through registers, in two halves: issue() puts the global loads in flight (typically one stage ahead, so that
+// their L2 latency runs behind the stage's MFMAs), commit() writes them to LDS once the region is free
+template <int ROWS, int CH>
+struct TlStage {
+    static constexpr int Q = CH / 4, N = (ROWS * Q + NTHREADS - 1) / NTHREADS;
+    float4 v[N];
+    __device__ __forceinline__ void issue(int tid, const float* src, int ss, int ch0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (u < ROWS * Q) { const int r = u / Q, c = (u - r * Q) * 4; v[i] = load_global4(src + (size_t)r * ss + ch0 + c); }
+        }
+    }
+    __device__ __forceinline__ void commit(int tid, float* dst, int ds) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (u < ROWS * Q) { const int r = u / Q, c = (u - r * Q) * 4; *reinterpret_cast<float4*>(dst + r * ds + c) = v[i]; }
+        }
+    }
+};
 
 // zero start of a mix's accumulators: the 4-joint fragment form and the single-joint form (joint 16 of the V = 17 layers)
 struct ZeroInitL {
@@ -2607,21 +2637,15 @@ struct ZeroInitL {
 // mix of CINV (16 or 32) channels over ALL TP frames: X (LDS, [frame * V + joint][channel], stride cs) -> store functor.
 // unit = (16-channel block, QC output frames); joint mix on the matrix cores exactly as in mix_stage, the time mix as
 // tm_step groups over one k-step's TP input frames at a time.
-template <int CINV, int V, int TP, class Init, class Store>
-__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const float* __restrict__ tqd, const float* __restrict__ af,
-                                         int wave, int lane, Init&& init, Store&& store) {
-    constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, KP = 2 * (KS / 2), MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
-    constexpr int UNITS = CB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
-    constexpr bool J16 = V == 17;
-    constexpr int MTM = J16 ? 1 : MT;
-    const int j = lane & 15, g = lane >> 4;
-    gfloat* tqd_g = as_global(tqd);
-    gfloat* af_g = as_global(af);
-    for (int rnd = 0; rnd < PER; ++rnd) {
-        const int u = wave + rnd * NWAVES;
-        if (u >= UNITS) break;
-        const int cb = u % CB, q0 = (u / CB) * QC;
-        float tq[QC][NR], aop[QC][MT][KS];
+template <int CINV, int V, int TP>
+struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's QC output frames
+    static constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
+    static constexpr int UNITS = CB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
+    float tq[QC][NR], aop[QC][MT][KS];
+    __device__ __forceinline__ void load(const float* tqd, const float* af, int u, int lane) {
+        gfloat* tqd_g = as_global(tqd);
+        gfloat* af_g = as_global(af);
+        const int q0 = ((u < UNITS ? u : UNITS - 1) / CB) * QC;
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
@@ -2631,6 +2655,32 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
         }
+    }
+};
+// `first`: the coefficients of the wave's first unit, fetched by the caller before it waited for X to land in LDS
+template <int CINV, int V, int TP, class Init, class Store>
+__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP>& first,
+                                         const float* __restrict__ tqd, const float* __restrict__ af,
+                                         int wave, int lane, Init&& init, Store&& store) {
+    using MC = MixLongCoef<CINV, V, TP>;
+    constexpr int QC = MC::QC, KS = MC::KS, KP = 2 * (KS / 2), MT = MC::MT, CB = MC::CB;
+    constexpr int UNITS = MC::UNITS, PER = MC::PER;
+    constexpr bool J16 = V == 17;
+    constexpr int MTM = J16 ? 1 : MT;
+    const int j = lane & 15, g = lane >> 4;
+    static_for<PER>([&](auto rr) {
+        constexpr int rnd = decltype(rr)::value;
+        const int u = wave + rnd * NWAVES;
+        if (u >= UNITS) return;
+        const int cb = u % CB, q0 = (u / CB) * QC;
+        MC later;
+#ifndef MCD_X_TLFIRST
+#define MCD_X_TLFIRST 1
+#endif
+        if constexpr (rnd > 0 || !MCD_X_TLFIRST) later.load(tqd, af, u, lane);        // (a second live set of 50 .. 80 registers for a prefetch does not fit)
+        const MC& cur = (rnd > 0 || !MCD_X_TLFIRST) ? later : first;
+        const auto& tq = cur.tq;
+        const auto& aop = cur.aop;
         f32x4 acc[QC][MTM];
         float part[QC];
 #pragma unroll
@@ -2678,7 +2728,7 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
                 if (g == 0) store(q0 + qi, 16, cb * 16 + j, z16 + init(q0 + qi, 16, cb * 16 + j));
             }
         }
-    }
+    });
 }
 
 // channel GEMM + epilogue of one 8-frame chunk: z / x chunks in LDS ([col][ch], strides cs_of(CIN) / CSX), result rows to
@@ -2709,10 +2759,10 @@ template <int TP>
 __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
     constexpr int R17 = TP * 17, R12 = TP * 12, R10 = TP * 10;
-    constexpr int NFC = TP / TL_FC;
+    constexpr int TL_FC = tl_fc(TP), NFC = TP / TL_FC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS: work region RA (mix: 32 channels of all frames; GEMM: z chunk + x chunk), chain state XT[col][4] (+ pad), tables
-    constexpr int RA_F = cmax((R17 + 16) * 36, 2 * 96 * 68);      // mix: 32 channels x all frames (+ pad rows); GEMM: z + x chunks
+    constexpr int RA_F = tl_ra_floats(TP);
     float* const RA = smem;
     float* const XT = RA + RA_F;                    // [R17 + 16][4]
     float* const EMB = XT + (R17 + 16) * 4;         // [EMB_TOTAL + 4]
@@ -2812,17 +2862,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 constexpr int CSX = L == 0 ? 4 : CSI;            // layer 0 reads the chain state in place (see score_kernel)
                 constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSV = L == 0 ? 4 : cs_of(CINV);
                 constexpr int ROWS = TP * V, CROWS = TL_FC * V, CPAD = ceil16(CROWS);
-                // mix: 32 channels of all frames at a time
+                // (thread / wave ids opaque per LAYER: the per-lane addresses of a layer's copies and tiles are invariant across
+                // its chunk loops, and hoisted to the top of the pass for all eleven layers at once they spill)
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                // mix: 32 channels of all frames at a time (the next 32 on their way while these are mixed)
+                TlStage<ROWS, CINV> sx;
+                if (!xin_lds) sx.issue(tid, xin, CSI, 0);
+                MixLongCoef<CINV, V, TP> mc;
+                mc.load(wb + N.tq[L], wb + N.am[L], wave, lane);
                 for (int h = 0; h < NH; ++h) {
                     const float* Xl = xin;
                     if (!xin_lds) {
                         __syncthreads();
-                        tl_g2l(RA, CSV, xin, CSI, h * CINV, CINV, ROWS);
+                        sx.commit(tid, RA, CSV);
                         __syncthreads();
+                        if (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
                         Xl = RA;
                     }
                     float* zg = Zg + h * CINV;
-                    mix_long<CINV, V, TP>(Xl, CSV, wb + N.tq[L], wb + N.am[L], wave, lane, ZeroInitL{},
+                    mix_long<CINV, V, TP>(Xl, CSV, mc, wb + N.tq[L], wb + N.am[L], wave, lane, ZeroInitL{},
                                           [&](int q, int w0, int c, auto v) {
                                               float* zp = zg + (size_t)(q * V + w0) * CSI + c;
                                               if constexpr (std::is_same_v<decltype(v), f32x4>) {
@@ -2843,11 +2903,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 }
                 float* const zc = RA;
                 float* const xc = RA + CPAD * CSI;
+                TlStage<CPAD, CIN> sz, sxc;           // the next chunk's z / x rows ride in registers behind this chunk's GEMM
+                __syncthreads();                       // (every wave's z stores of the mix above are complete)
+                sz.issue(tid, Zg, CSI, 0);
+                if (!xin_lds) sxc.issue(tid, xin, CSI, 0);
                 for (int fc = 0; fc < NFC; ++fc) {
                     __syncthreads();
-                    tl_g2l(zc, CSI, Zg + (size_t)fc * CROWS * CSI, CSI, 0, CIN, CPAD);
-                    if (!xin_lds) tl_g2l(xc, CSI, xin + (size_t)fc * CROWS * CSI, CSI, 0, CIN, CPAD);
+                    sz.commit(tid, zc, CSI);
+                    if (!xin_lds) sxc.commit(tid, xc, CSI);
                     __syncthreads();
+                    if (fc + 1 < NFC) {
+                        sz.issue(tid, Zg + (size_t)(fc + 1) * CROWS * CSI, CSI, 0);
+                        if (!xin_lds) sxc.issue(tid, xin + (size_t)(fc + 1) * CROWS * CSI, CSI, 0);
+                    }
                     const float* xs = xin_lds ? xin + fc * CROWS * CSX : xc;
                     tl_gemm<CIN, COUT, CROWS, D.res != 0, CSX>(A, N.slope[L], zc, xs, xout + (size_t)fc * CROWS * CSO, EMB + emb_off(L), wave, lane);
                 }
@@ -2857,18 +2925,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             auto resample = [&](auto cc, auto vic, auto voc, int r, const float* xin, float* xout, const float* skip) {
                 constexpr int C = decltype(cc)::value, VIN = decltype(vic)::value, VOUT = decltype(voc)::value, CS = cs_of(C);
                 constexpr int IR = TL_FC * VIN, OR = TL_FC * VOUT;
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
                 RsCoef<C, VIN, VOUT, TL_FC, 1, false> rc;
                 rc.load(wb + N.rsw[r], wb + N.rsw[r] + ((VOUT + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                 float* const ic = RA;
                 float* const oc = RA + ceil16(IR) * CS;
                 float nosk[1] = {0.f};
+                TlStage<IR, C> si;
+                si.issue(tid, xin, CS, 0);
                 for (int fc = 0; fc < NFC; ++fc) {
                     __syncthreads();
-                    tl_g2l(ic, CS, xin + (size_t)fc * IR * CS, CS, 0, C, IR);
+                    si.commit(tid, ic, CS);
                     __syncthreads();
+                    if (fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CS, CS, 0);
                     resample_stage<C, VIN, VOUT, TL_FC, 1, false, false, true>(ic, CS, oc, CS, rc, nosk, wave, lane);
                     __syncthreads();
-                    tl_l2g(xout + (size_t)fc * OR * CS, CS, oc, CS, C, OR, skip ? skip + (size_t)fc * OR * CS : nullptr);
+                    tl_l2g(tid, xout + (size_t)fc * OR * CS, CS, oc, CS, C, OR, skip ? skip + (size_t)fc * OR * CS : nullptr);
                 }
                 __syncthreads();
             };
@@ -2883,6 +2957,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             layer(TL_C(5), A0, false, A1);                                  // 64 -> 128
             {   // ---- layer 6 (128 -> 64) W-first: P = [W_t; W_r] x per chunk -> A0 (rows x 132: P_t | P_r), then the mix on P_t
                 constexpr int CROWS = TL_FC * 10;
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
                 LayerAfr<8> A;
                 { LayerW lw; lw.wp = N.wp[6]; lw.bias = N.bias[6]; A.template load<8>(wb, lw, wave, lane); }
                 auto epi6 = [&](float* pg) {
@@ -2890,22 +2967,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         if (col < CROWS) *reinterpret_cast<float4*>(pg + (size_t)col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
                     };
                 };
+                constexpr int CPAD6 = ceil16(CROWS);
+                TlStage<CPAD6, 128> s5;
+                s5.issue(tid, A1, 132, 0);
                 for (int fc = 0; fc < NFC; ++fc) {
                     __syncthreads();
-                    tl_g2l(RA, 132, A1 + (size_t)fc * CROWS * 132, 132, 0, 128, CROWS);
+                    s5.commit(tid, RA, 132);
                     __syncthreads();
-                    gemm_tiles<8, CROWS / 16, 8, 0, false, true>(A.a, RA, 132, RA, 132, wave, lane, epi6(A0 + (size_t)fc * CROWS * 132), 0);
+                    if (fc + 1 < NFC) s5.issue(tid, A1 + (size_t)(fc + 1) * CROWS * 132, 132, 0);
+                    gemm_tiles<8, CPAD6 / 16, 8, 0, false, true>(A.a, RA, 132, RA, 132, wave, lane, epi6(A0 + (size_t)fc * CROWS * 132), 0);
                 }
                 const float slope6 = N.slope[6], pinf6 = prelu_bound(slope6);
+                TlStage<R10, 32> sp;
+                __syncthreads();                       // (phase A's P stores are complete)
+                sp.issue(tid, A0, 132, 0);
+                MixLongCoef<32, 10, TP> mc6;
+                mc6.load(wb + N.tq[6], wb + N.am[6], wave, lane);
                 for (int h = 0; h < 2; ++h) {
                     __syncthreads();
-                    tl_g2l(RA, 36, A0, 132, h * 32, 32, R10);
+                    sp.commit(tid, RA, 36);
                     __syncthreads();
+                    if (h == 0) sp.issue(tid, A0, 132, 32);
                     const float* pr = A0 + 64 + h * 32;
                     float* og = A1 + h * 32;              // out6 (64 ch, stride 68) over the dead layer-5 output
                     const float* bias = wb + N.bias[6] + h * 32;
                     const float* e6 = EMB + emb_off(6) + h * 32;
-                    mix_long<32, 10, TP>(RA, 36, wb + N.tq[6], wb + N.am[6], wave, lane,
+                    mix_long<32, 10, TP>(RA, 36, mc6, wb + N.tq[6], wb + N.am[6], wave, lane,
                                          [&](int q, int w0, int c, std::true_type) {
                                              const float* pp = pr + (size_t)(q * 10 + w0) * 132 + c;
                                              return f32x4{pp[0], pp[132], pp[264], pp[396]};          // (rows >= 10 of the fragment: next frame's, never stored)
@@ -2927,6 +3014,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             resample(TL_C(32), TL_C(12), TL_C(17), 3, A0, A1, D1);          // up2 + d1
             layer(TL_C(9), A1, false, A0);
             {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
                 const float* w4 = wb + N.wp[10];
                 for (int u = tid; u < R17 * 4; u += NTHREADS) {
                     const int col = u >> 2, r = u & 3;
@@ -2942,7 +3032,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 }
                 __syncthreads();
                 // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
-                mix_long<16, 17, TP>(P4, 4, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
+                MixLongCoef<16, 17, TP> mc10;
+                mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
+                mix_long<16, 17, TP>(P4, 4, mc10, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
                                      [&](int q, int w0, int c, auto v) {
                                          if (c < C0) {
                                              float* zp = ZO + ((q * 17 + w0)) * C0 + c;
@@ -3484,7 +3576,7 @@ int launch_score_generic(const mcd_weights* w, const ScoreParams& P, const Frame
 // MFMA kernel of the long windows (12 < T <= 32); slabs: tl_slab_floats(TP) floats per workgroup
 template <int TP>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
-    constexpr size_t lds = ((size_t)cmax((TP * 17 + 16) * 36, 2 * 96 * 68) + (TP * 17 + 16) * 4 + EMB_TOTAL + 4 + EDIM + TP * 17 * 2 * 2 + TP * 17 * 4 + NTHREADS) * 4;
+    constexpr size_t lds = ((size_t)tl_ra_floats(TP) + (TP * 17 + 16) * 4 + EMB_TOTAL + 4 + EDIM + TP * 17 * 2 * 2 + TP * 17 * 4 + NTHREADS) * 4;
     LDS_LIMIT((&score_tiled_kernel<TP>), lds);
     hipLaunchKernelGGL((score_tiled_kernel<TP>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
     HIP_TRY(hipGetLastError());
