@@ -245,6 +245,11 @@ int mcd_frame_scores(const mcd_frame_cfg_t* cfg, const float* scores, const int6
  * written by workgroup 0 of the trajectory kernel; NULL (the default) disables it.  A no-op in the shipped build. */
 void mcd_debug_set_prof(void* device_buffer);
 
+/* Test aid: fills the LDS of every CU with NaN bit patterns (4096 workgroups of 160 KB on `stream`), so that a later kernel
+ * that reads shared memory it never wrote yields NaNs instead of whatever the previous kernel left behind
+ * (tests/test_hip_parity.py::test_no_uninitialised_reads). */
+int mcd_debug_poison_lds(void* stream);
+
 const char* mcd_last_error(void);
 int32_t mcd_abi_version(void);
 

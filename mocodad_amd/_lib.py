@@ -52,6 +52,7 @@ _SIGS = {
     "mcd_layer_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_philox_noise": (C.c_int, [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_debug_set_prof": (None, [C.c_void_p]),
+    "mcd_debug_poison_lds": (C.c_int, [C.c_void_p]),
     "mcd_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_score_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(ScoreCfg)]),

@@ -2201,45 +2201,106 @@ struct CondW {
     int lw, lb;
 };
 
-__global__ __launch_bounds__(256) void cond_encode_kernel(const CondW W, const float* __restrict__ cond,
-                                                          float* __restrict__ emb_out, int B) {
+// Stages of a layer as wave tasks of (8 channels, 64 columns): the time mix (Y = X . Tq per joint, into the layer's output
+// buffer as scratch), the joint mix (Z = Y . A), the channel GEMM with 8 accumulators per thread whose weights are wave-uniform
+// scalar loads.  (The first version ran the two mixes as one 17 x (T + 1) loop per output element: 8x the multiplies, 0.45
+// TFLOP/s; at 16 condition frames it was a quarter of the whole scoring step.)
+constexpr int CE_THREADS = 512;
+__global__ __launch_bounds__(CE_THREADS) void cond_encode_kernel(const CondW W, const float* __restrict__ cond,
+                                                                 float* __restrict__ emb_out, int B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Tc = W.Tc, TV = Tc * 17;
+    const int Tc = W.Tc, TV = Tc * 17, nblk = (TV + 63) / 64;
     float* X = smem;
     float* Z = X + W.cmax * TV;
     float* O = Z + W.cmax * TV;
-    float* RED = O + W.cmax * TV;  // latent * 16 partial sums
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int u = tid; u < C0 * TV; u += 256) X[u] = cond[(size_t)b * C0 * TV + u];  // (c, t, v) row-major
+    float* RED = O + W.cmax * TV;  // CE_THREADS partial sums
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = CE_THREADS / 64;
+    for (int u = tid; u < C0 * TV; u += CE_THREADS) X[u] = cond[(size_t)b * C0 * TV + u];  // (c, t, v) row-major
     __syncthreads();
     for (int l = 0; l < W.n_layers; ++l) {
         const int cin = W.cin[l], cout = W.cout[l];
         const float* Tq = W.base + W.tq[l];
         const float* Am = W.base + W.am[l];
-        for (int u = tid; u < cin * TV; u += 256) {
-            const int c = u / TV, q = (u % TV) / 17, w = u % 17;
-            float z = 0.f;
-            for (int v = 0; v < 17; ++v) {
-                float y = 0.f;
-                for (int t = 0; t < Tc; ++t) y = fmaf(X[c * TV + t * 17 + v], Tq[(q * 17 + v) * Tc + t], y);
-                z = fmaf(y, Am[(q * 17 + v) * 17 + w], z);
+        const int ngi = (cin + 7) / 8, ngo = (cout + 7) / 8;
+        // time mix: Y[c][q, v] = sum_t X[c][t, v] Tq[q, v][t]   (Y in the output buffer)
+        for (int task = wave; task < ngi * nblk; task += NW) {
+            const int c0 = (task / nblk) * 8, p = (task % nblk) * 64 + lane;
+            if (p < TV) {
+                const float* tq = Tq + (size_t)p * Tc;
+                const float* xb = X + p % 17;
+                int co[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) co[i] = (c0 + i < cin ? c0 + i : cin - 1) * TV;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < Tc; ++t) {
+                    const float tv = tq[t];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(xb[co[i] + t * 17], tv, acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c0 + i < cin) O[(c0 + i) * TV + p] = acc[i];
             }
-            Z[u] = z;
         }
         __syncthreads();
+        // joint mix: Z[c][q, w] = sum_v Y[c][q, v] A[q, v][w]
+        for (int task = wave; task < ngi * nblk; task += NW) {
+            const int c0 = (task / nblk) * 8, p = (task % nblk) * 64 + lane;
+            if (p < TV) {
+                const int q = p / 17, w = p % 17;
+                const float* am = Am + (size_t)q * 289 + w;
+                const float* yb = O + q * 17;
+                int co[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) co[i] = (c0 + i < cin ? c0 + i : cin - 1) * TV;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 17; ++v) {
+                    const float a = am[v * 17];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(yb[co[i] + v], a, acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c0 + i < cin) Z[(c0 + i) * TV + p] = acc[i];
+            }
+        }
+        __syncthreads();
+        // channel GEMM + residual + PReLU: 8 output channels per thread, their weight rows wave-uniform
         const float* wt = W.base + W.wt[l];
         const float* wr = W.wr[l] >= 0 ? W.base + W.wr[l] : nullptr;
         const float* bias = W.base + W.bias[l];
-        for (int u = tid; u < cout * TV; u += 256) {
-            const int co = u / TV, p = u % TV;
-            float a = bias[co];
-            for (int c = 0; c < cin; ++c) a = fmaf(wt[co * cin + c], Z[c * TV + p], a);
-            if (wr) {
-                for (int c = 0; c < cin; ++c) a = fmaf(wr[co * cin + c], X[c * TV + p], a);
-            } else {
-                a += X[co * TV + p];
+        const float slope = W.slope[l];
+        for (int task = wave; task < ngo * nblk; task += NW) {
+            const int o0 = (task / nblk) * 8, p = (task % nblk) * 64 + lane;
+            int row[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) row[i] = o0 + i < cout ? o0 + i : cout - 1;
+            if (p < TV) {
+                float acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = bias[row[i]];
+                for (int c = 0; c < cin; ++c) {
+                    const float z = Z[c * TV + p];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wt[row[i] * cin + c], z, acc[i]);
+                }
+                if (wr) {
+                    for (int c = 0; c < cin; ++c) {
+                        const float x = X[c * TV + p];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = fmaf(wr[row[i] * cin + c], x, acc[i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += X[row[i] * TV + p];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (o0 + i < cout) O[(o0 + i) * TV + p] = prelu(acc[i], slope);
             }
-            O[u] = prelu(a, W.slope[l]);
         }
         __syncthreads();
         float* tmp = X; X = O; O = tmp;
@@ -2248,7 +2309,7 @@ __global__ __launch_bounds__(256) void cond_encode_kernel(const CondW W, const f
     const int hd = W.cout[W.n_layers - 1];
     const int F = hd * TV;
     const int jj = tid / 16, part = tid % 16;  // 16 partial sums per output
-    for (int j0 = 0; j0 < W.latent; j0 += 16) {
+    for (int j0 = 0; j0 < W.latent; j0 += CE_THREADS / 16) {
         const int jo = j0 + jj;
         float a = 0.f;
         if (jo < W.latent) {
@@ -2579,7 +2640,12 @@ struct TiledNet {
 #endif
 // frames per GEMM / resampler chunk: half the padded frame count at 24 / 32 frames, all 16 at 16 (fewer, longer stages:
 // every chunk costs two barriers that wait for the previous stage's slab stores to land)
-__host__ __device__ constexpr int tl_fc(int TP) { return MCD_X_TLFC ? (TP == 24 ? 12 : 16) : 8; }
+#ifndef MCD_X_FC16
+#define MCD_X_FC16 16
+#define MCD_X_FC24 12
+#define MCD_X_FC32 16
+#endif
+__host__ __device__ constexpr int tl_fc(int TP) { return TP == 16 ? MCD_X_FC16 : TP == 24 ? MCD_X_FC24 : MCD_X_FC32; }
 __host__ __device__ constexpr int tl_ra_floats(int TP) {          // LDS work region: mix (32 channels x all frames + pad rows) | GEMM (z + x chunks)
     return cmax((TP * 17 + 16) * 36, 2 * ceil16(tl_fc(TP) * 12) * 68);
 }
@@ -2637,15 +2703,15 @@ struct ZeroInitL {
 // mix of CINV (16 or 32) channels over ALL TP frames: X (LDS, [frame * V + joint][channel], stride cs) -> store functor.
 // unit = (16-channel block, QC output frames); joint mix on the matrix cores exactly as in mix_stage, the time mix as
 // tm_step groups over one k-step's TP input frames at a time.
-template <int CINV, int V, int TP>
-struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's QC output frames
+template <int CINV, int V, int TP, int NB = 1>
+struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's QC output frames (NB chains of TP frames each)
     static constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
-    static constexpr int UNITS = CB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
+    static constexpr int UNITS = CB * NB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
     float tq[QC][NR], aop[QC][MT][KS];
     __device__ __forceinline__ void load(const float* tqd, const float* af, int u, int lane) {
         gfloat* tqd_g = as_global(tqd);
         gfloat* af_g = as_global(af);
-        const int q0 = ((u < UNITS ? u : UNITS - 1) / CB) * QC;
+        const int q0 = (((u < UNITS ? u : UNITS - 1) / CB) % NQ) * QC;
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi) {
 #pragma unroll
@@ -2658,12 +2724,12 @@ struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's Q
     }
 };
 // `first`: the coefficients of the wave's first unit, fetched by the caller before it waited for X to land in LDS
-template <int CINV, int V, int TP, class Init, class Store>
-__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP>& first,
+template <int CINV, int V, int TP, int NB, class Init, class Store>
+__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP, NB>& first,
                                          const float* __restrict__ tqd, const float* __restrict__ af,
                                          int wave, int lane, Init&& init, Store&& store) {
-    using MC = MixLongCoef<CINV, V, TP>;
-    constexpr int QC = MC::QC, KS = MC::KS, KP = 2 * (KS / 2), MT = MC::MT, CB = MC::CB;
+    using MC = MixLongCoef<CINV, V, TP, NB>;
+    constexpr int QC = MC::QC, KS = MC::KS, KP = 2 * (KS / 2), MT = MC::MT, CB = MC::CB, NQ = MC::NQ;
     constexpr int UNITS = MC::UNITS, PER = MC::PER;
     constexpr bool J16 = V == 17;
     constexpr int MTM = J16 ? 1 : MT;
@@ -2672,7 +2738,8 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
         constexpr int rnd = decltype(rr)::value;
         const int u = wave + rnd * NWAVES;
         if (u >= UNITS) return;
-        const int cb = u % CB, q0 = (u / CB) * QC;
+        // (q0: first output frame of the unit in the flat list of NB * TP frames; its chain's frames start at row fo * V)
+        const int cb = u % CB, qg = u / CB, fo = NB > 1 ? (qg / NQ) * TP : 0, q0 = fo + (qg % NQ) * QC;
         MC later;
 #ifndef MCD_X_TLFIRST
 #define MCD_X_TLFIRST 1
@@ -2689,8 +2756,8 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt) acc[qi][mt] = init(q0 + qi, mt * 16 + 4 * g, cb * 16 + j, std::true_type{});
         }
-        const float* xin_p = X + __mul24(4 * (g & 1) + (g >> 1), cs) + cb * 16 + j;
-        const float* xin_l = X + __mul24(g, cs) + cb * 16 + j;
+        const float* xin_p = X + __mul24(fo * V + 4 * (g & 1) + (g >> 1), cs) + cb * 16 + j;
+        const float* xin_l = X + __mul24(fo * V + g, cs) + cb * 16 + j;
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
@@ -2755,50 +2822,62 @@ __device__ __forceinline__ void tl_gemm(const AF& A, float slope, const float* _
     gemm_tiles<MT, NT, KQ1, KQ2, !RES, true>(A.a, z, CSI, x, CSX, wave, lane, epi, 0, RES ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-template <int TP>
+// NB chains of TP (padded) frames each per workgroup, laid out as one flat list of TF = NB * TP frames: the channel GEMMs, the
+// resamplers and the slab copies see TF frames; the time mix stays inside a chain (mix_long's units).  <16, 2> gives the
+// 13 .. 16-frame shapes the stage lengths (and the matrix-pipe fill per barrier) of the 32-frame shape.
+template <int TP, int NB>
 __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
-    constexpr int R17 = TP * 17, R12 = TP * 12, R10 = TP * 10;
-    constexpr int TL_FC = tl_fc(TP), NFC = TP / TL_FC;
+    constexpr int TF = TP * NB;
+    constexpr int R17 = TF * 17, R12 = TF * 12, R10 = TF * 10;
+    constexpr int TL_FC = tl_fc(TF), NFC = TF / TL_FC;
+    static_assert(TP % TL_FC == 0, "a GEMM chunk lies inside one chain (its embedding rows are the chain's)");
+    constexpr int EMBS = EMB_TOTAL + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // LDS: work region RA (mix: 32 channels of all frames; GEMM: z chunk + x chunk), chain state XT[col][4] (+ pad), tables
-    constexpr int RA_F = tl_ra_floats(TP);
+    constexpr int RA_F = tl_ra_floats(TF);
     float* const RA = smem;
     float* const XT = RA + RA_F;                    // [R17 + 16][4]
-    float* const EMB = XT + (R17 + 16) * 4;         // [EMB_TOTAL + 4]
-    float* const SE = EMB + EMB_TOTAL + 4;          // [16]
-    float* const ZN = SE + EDIM;                    // [R17][2]  this step's noise
+    float* const EMB = XT + (R17 + 16) * 4;         // [NB][EMB_TOTAL + 4]
+    float* const SE = EMB + NB * EMBS;              // [NB][16]
+    float* const ZN = SE + NB * EDIM;               // [R17][2]  this step's noise
     float* const ZO = ZN + R17 * C0;                // [R17][2]  layer 10's mixed output
-    float* const P4 = ZO + R17 * C0;                // [R17][4]  layer 10's W-first product
-    float* const RED = P4 + R17 * 4;                // [NTHREADS]
+    float* const P4 = ZO + R17 * C0;                // [R17 + 16][4]  layer 10's W-first product (+ zero pad rows: its mix reads 16-channel blocks)
+    float* const RED = P4 + (R17 + 16) * 4;         // [NTHREADS]
     const int tid0 = threadIdx.x;
     int tid = tid0, lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* wb = P.wbuf;
-    float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TP);
+    float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TF);
     const int Tx = P.n_corrupt, K = P.ns > 2 ? P.ns - 1 : 1, per = C0 * Tx * 17;
-    for (int u = tid; u < (int)tl_slab_floats(TP); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
+    for (int u = tid; u < (int)tl_slab_floats(TF); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
     for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
+    if (tid < 64) P4[R17 * 4 + tid] = 0.f;
     for (int u = tid; u < RA_F; u += NTHREADS) RA[u] = 0.f;           // pad rows meet zero coefficients: they must be finite
 
-    for (long long chain = blockIdx.x; chain < P.n_chains; chain += gridDim.x) {
-        const int b = (int)(chain / P.S), s = (int)(chain % P.S);
-        const unsigned fixed = (unsigned)(P.win_mask ? P.win_mask[b] : P.fixed_mask);
-        auto tx_of = [&](int t) { return P.win_mask ? __popc(~fixed & ((1u << t) - 1u)) : M.tx_of[t]; };
+    for (long long grp = blockIdx.x; grp * NB < P.n_chains; grp += gridDim.x) {
+        // chain i of the group (the last group of an odd count runs its last chain twice and writes it once)
+        auto chain_of = [&](int i) { const long long c = grp * NB + i; return c < P.n_chains ? c : P.n_chains - 1; };
+        auto b_of = [&](int i) { return (int)(chain_of(i) / P.S); };
+        auto s_of = [&](int i) { return (int)(chain_of(i) % P.S); };
+        auto fixed_of = [&](int i) { return (unsigned)(P.win_mask ? P.win_mask[b_of(i)] : P.fixed_mask); };
+        auto tx_of = [&](unsigned fixed, int t) { return P.win_mask ? __popc(~fixed & ((1u << t) - 1u)) : M.tx_of[t]; };
         auto src_of = [&](int t) { return P.win_mask ? t : M.src_frame[t]; };
         __syncthreads();
-        for (int u = tid; u < T * 17; u += NTHREADS) {
-            const int t = u / 17, v = u % 17;
+        for (int u = tid; u < NB * T * 17; u += NTHREADS) {
+            const int i = u / (T * 17), t = (u / 17) % T, v = u % 17;
+            const int b = b_of(i), s = s_of(i);
+            const unsigned fixed = fixed_of(i);
 #pragma unroll
             for (int c = 0; c < C0; ++c) {
                 float x;
                 if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
                 else {
-                    const int e = (c * Tx + tx_of(t)) * 17 + v;
+                    const int e = (c * Tx + tx_of(fixed, t)) * 17 + v;
                     x = P.noise ? P.noise[((size_t)(s * K + 0) * P.B + b) * per + e]
                                 : philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
                 }
-                XT[u * 4 + c] = x;
+                XT[((i * TP + t) * 17 + v) * 4 + c] = x;
             }
         }
         for (int sidx = P.ns - 1; sidx >= 1; --sidx) {
@@ -2819,18 +2898,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             float* const D1 = Zg + (R12 + 16) * 68;
             float* const D2 = D1 + (R17 + 16) * 36;
             __syncthreads();
-            if (tid < EDIM) {
-                float e = srow[4 + tid];
-                if (P.cond_emb) e += P.cond_emb[(size_t)b * EDIM + tid];
+            if (tid < NB * EDIM) {
+                float e = srow[4 + tid % EDIM];
+                if (P.cond_emb) e += P.cond_emb[(size_t)b_of(tid / EDIM) * EDIM + tid % EDIM];
                 SE[tid] = e / (1.f + expf(-e));
             }
             if (sidx > 1) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
                 const int k = P.ns - sidx;
-                for (int gi = tid; gi < T * 9; gi += NTHREADS) {
-                    const int t = gi / 9, v0 = (gi % 9) * 2;
+                for (int gi = tid; gi < NB * T * 9; gi += NTHREADS) {
+                    const int i = gi / (T * 9), t = (gi / 9) % T, v0 = (gi % 9) * 2;
+                    const int b = b_of(i), s = s_of(i);
+                    const unsigned fixed = fixed_of(i);
                     float z[4] = {0.f, 0.f, 0.f, 0.f};
                     if (!((fixed >> t) & 1u)) {
-                        const int tx = tx_of(t);
+                        const int tx = tx_of(fixed, t);
                         if (P.noise) {
                             const float* zp = P.noise + ((size_t)(s * K + k) * P.B + b) * per + tx * 17 + v0;
                             z[0] = zp[0]; z[1] = zp[Tx * 17];
@@ -2839,18 +2920,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                             philox_normal4(P.seed, (unsigned)(tx * 9 + (v0 >> 1)), (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b), z);
                         }
                     }
-                    float* zo = ZN + (t * 17 + v0) * C0;
+                    float* zo = ZN + ((i * TP + t) * 17 + v0) * C0;
                     zo[0] = z[0]; zo[1] = z[1];
                     if (v0 + 1 < 17) { zo[2] = z[2]; zo[3] = z[3]; }
                 }
             }
             __syncthreads();
-            for (int o = tid; o < EMB_TOTAL; o += NTHREADS) {
+            for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
+                const int i = u / EMB_TOTAL, o = u % EMB_TOTAL;
                 const float* we = wb + N.we + o * EDIM;
                 float a = wb[N.be + o];
 #pragma unroll
-                for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[k], a);
-                EMB[o] = a;
+                for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[i * EDIM + k], a);
+                EMB[i * EMBS + o] = a;
             }
             __syncthreads();
 
@@ -2861,7 +2943,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr int CSX = L == 0 ? 4 : CSI;            // layer 0 reads the chain state in place (see score_kernel)
                 constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSV = L == 0 ? 4 : cs_of(CINV);
-                constexpr int ROWS = TP * V, CROWS = TL_FC * V, CPAD = ceil16(CROWS);
+                constexpr int ROWS = TF * V, CROWS = TL_FC * V, CPAD = ceil16(CROWS);
                 // (thread / wave ids opaque per LAYER: the per-lane addresses of a layer's copies and tiles are invariant across
                 // its chunk loops, and hoisted to the top of the pass for all eleven layers at once they spill)
                 int tid = tid0;
@@ -2870,7 +2952,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 // mix: 32 channels of all frames at a time (the next 32 on their way while these are mixed)
                 TlStage<ROWS, CINV> sx;
                 if (!xin_lds) sx.issue(tid, xin, CSI, 0);
-                MixLongCoef<CINV, V, TP> mc;
+                MixLongCoef<CINV, V, TP, NB> mc;
                 mc.load(wb + N.tq[L], wb + N.am[L], wave, lane);
                 for (int h = 0; h < NH; ++h) {
                     const float* Xl = xin;
@@ -2882,7 +2964,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         Xl = RA;
                     }
                     float* zg = Zg + h * CINV;
-                    mix_long<CINV, V, TP>(Xl, CSV, mc, wb + N.tq[L], wb + N.am[L], wave, lane, ZeroInitL{},
+                    mix_long<CINV, V, TP, NB>(Xl, CSV, mc, wb + N.tq[L], wb + N.am[L], wave, lane, ZeroInitL{},
                                           [&](int q, int w0, int c, auto v) {
                                               float* zp = zg + (size_t)(q * V + w0) * CSI + c;
                                               if constexpr (std::is_same_v<decltype(v), f32x4>) {
@@ -2917,7 +2999,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         if (!xin_lds) sxc.issue(tid, xin + (size_t)(fc + 1) * CROWS * CSI, CSI, 0);
                     }
                     const float* xs = xin_lds ? xin + fc * CROWS * CSX : xc;
-                    tl_gemm<CIN, COUT, CROWS, D.res != 0, CSX>(A, N.slope[L], zc, xs, xout + (size_t)fc * CROWS * CSO, EMB + emb_off(L), wave, lane);
+                    tl_gemm<CIN, COUT, CROWS, D.res != 0, CSX>(A, N.slope[L], zc, xs, xout + (size_t)fc * CROWS * CSO, EMB + (fc * TL_FC / TP) * EMBS + emb_off(L), wave, lane);
                 }
                 __syncthreads();
             };
@@ -2981,7 +3063,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 TlStage<R10, 32> sp;
                 __syncthreads();                       // (phase A's P stores are complete)
                 sp.issue(tid, A0, 132, 0);
-                MixLongCoef<32, 10, TP> mc6;
+                MixLongCoef<32, 10, TP, NB> mc6;
                 mc6.load(wb + N.tq[6], wb + N.am[6], wave, lane);
                 for (int h = 0; h < 2; ++h) {
                     __syncthreads();
@@ -2992,13 +3074,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                     float* og = A1 + h * 32;              // out6 (64 ch, stride 68) over the dead layer-5 output
                     const float* bias = wb + N.bias[6] + h * 32;
                     const float* e6 = EMB + emb_off(6) + h * 32;
-                    mix_long<32, 10, TP>(RA, 36, mc6, wb + N.tq[6], wb + N.am[6], wave, lane,
+                    mix_long<32, 10, TP, NB>(RA, 36, mc6, wb + N.tq[6], wb + N.am[6], wave, lane,
                                          [&](int q, int w0, int c, std::true_type) {
                                              const float* pp = pr + (size_t)(q * 10 + w0) * 132 + c;
                                              return f32x4{pp[0], pp[132], pp[264], pp[396]};          // (rows >= 10 of the fragment: next frame's, never stored)
                                          },
                                          [&](int q, int w0, int c, f32x4 v) {
-                                             const float bb = bias[c], ee = e6[c];
+                                             const float bb = bias[c], ee = e6[(NB > 1 ? (q / TP) * EMBS : 0) + c];
                                              float* op = og + (size_t)(q * 10 + w0) * 68 + c;
 #pragma unroll
                                              for (int r = 0; r < 4; ++r)
@@ -3032,9 +3114,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 }
                 __syncthreads();
                 // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
-                MixLongCoef<16, 17, TP> mc10;
+                MixLongCoef<16, 17, TP, NB> mc10;
                 mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
-                mix_long<16, 17, TP>(P4, 4, mc10, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
+                mix_long<16, 17, TP, NB>(P4, 4, mc10, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
                                      [&](int q, int w0, int c, auto v) {
                                          if (c < C0) {
                                              float* zp = ZO + ((q * 17 + w0)) * C0 + c;
@@ -3051,21 +3133,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 // eps = layer 10 + x; DDPM update of the frame each prediction drives (mocodad.py:172-178,829-838)
                 const float slope10 = N.slope[10], ca = srow[0], cb = srow[1], csg = srow[2];
                 const bool zadd = sidx > 1;
-                constexpr int NIT = (C0 * 32 * 17 + NTHREADS - 1) / NTHREADS;
+                constexpr int NIT = (C0 * TF * 17 + NTHREADS - 1) / NTHREADS;
                 float xn[NIT];
                 int dst[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int u = tid + it * NTHREADS;
                     dst[it] = -1; xn[it] = 0.f;
-                    if (u < T * 17 * C0) {
-                        const int c = u % C0, col = u / C0, t = col / 17, v = col % 17;
-                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[N.bias[10] + c], slope10) + EMB[emb_off(10) + c];
+                    if (u < TF * 17 * C0) {
+                        const int c = u % C0, col = u / C0, f = col / 17, i = f / TP, t = f % TP, v = col % 17;
+                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[N.bias[10] + c], slope10) + EMB[i * EMBS + emb_off(10) + c];
                         const float eps = l10 + XT[col * 4 + c];
-                        const int k = P.win_mask ? (((fixed >> t) & 1u) ? -1 : 0) : M.upd_of[t];
+                        const int k = t >= T ? -1 : P.win_mask ? (((fixed_of(i) >> t) & 1u) ? -1 : 0) : M.upd_of[t];
                         if (k >= 0) {
                             const int tp = P.win_mask ? t : M.pos_of[k];
-                            const int colp = tp * 17 + v;
+                            const int colp = (i * TP + tp) * 17 + v;
                             xn[it] = ca * (XT[colp * 4 + c] - cb * eps) + csg * (zadd ? ZN[colp * C0 + c] : 0.f);
                             dst[it] = colp * 4 + c;
                         }
@@ -3079,20 +3161,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
         }
         __syncthreads();
         // ---- loss over the corrupt frames (mocodad.py:484)
-        float part = 0.f;
-        for (int e = tid; e < per; e += NTHREADS) {
-            const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
-            int tu = M.pos_of[tx];
-            if (P.win_mask) { int cnt = 0; for (int t = 0; t < T; ++t) if (!((fixed >> t) & 1u)) { if (cnt == tx) tu = t; ++cnt; } }
-            const float x0 = XT[(tu * 17 + v) * 4 + c];
-            const float gt = load_coord(P.dv, b, c, src_of(tu), v, P.seg_len);
-            part += loss_elem(x0, gt, P.loss_fn);
-            if (P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
+        for (int i = 0; i < NB; ++i) {
+            if (grp * NB + i >= P.n_chains) break;
+            const long long chain = grp * NB + i;
+            const int b = b_of(i), s = s_of(i);
+            const unsigned fixed = fixed_of(i);
+            float part = 0.f;
+            for (int e = tid; e < per; e += NTHREADS) {
+                const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
+                int tu = M.pos_of[tx];
+                if (P.win_mask) { int cnt = 0; for (int t = 0; t < T; ++t) if (!((fixed >> t) & 1u)) { if (cnt == tx) tu = t; ++cnt; } }
+                const float x0 = XT[((i * TP + tu) * 17 + v) * 4 + c];
+                const float gt = load_coord(P.dv, b, c, src_of(tu), v, P.seg_len);
+                part += loss_elem(x0, gt, P.loss_fn);
+                if (P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
+            }
+            RED[tid] = part;
+            __syncthreads();
+            for (int o = NTHREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
+            if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
+            __syncthreads();
         }
-        RED[tid] = part;
-        __syncthreads();
-        for (int o = NTHREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
-        if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
     }
 }
 
@@ -3574,26 +3663,30 @@ int launch_score_generic(const mcd_weights* w, const ScoreParams& P, const Frame
     return MCD_OK;
 }
 // MFMA kernel of the long windows (12 < T <= 32); slabs: tl_slab_floats(TP) floats per workgroup
-template <int TP>
+// chains per workgroup of the slab-tiled kernel: two 16-frame chains share one (see score_tiled_kernel)
+constexpr int tl_nb(int TP) { return TP == 16 ? 2 : 1; }
+template <int TP, int NB>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
-    constexpr size_t lds = ((size_t)tl_ra_floats(TP) + (TP * 17 + 16) * 4 + EMB_TOTAL + 4 + EDIM + TP * 17 * 2 * 2 + TP * 17 * 4 + NTHREADS) * 4;
-    LDS_LIMIT((&score_tiled_kernel<TP>), lds);
-    hipLaunchKernelGGL((score_tiled_kernel<TP>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
+    constexpr int TF = TP * NB;
+    constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS) * 4;
+    LDS_LIMIT((&score_tiled_kernel<TP, NB>), lds);
+    hipLaunchKernelGGL((score_tiled_kernel<TP, NB>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
-int tiled_wgs(int64_t units) {
+int tiled_wgs(int64_t chains, int TP) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return (int)(units < cus ? units : cus);         // one workgroup per CU (70 - 111 KB of LDS), persistent over the chains
+    const int64_t units = (chains + tl_nb(TP) - 1) / tl_nb(TP);
+    return (int)(units < cus ? units : cus);         // one workgroup per CU (110 - 135 KB of LDS), persistent over the chains
 }
-int64_t tiled_scratch_bytes(int64_t units, int TP) { return (int64_t)tiled_wgs(units) * tl_slab_floats(TP) * 4; }
+int64_t tiled_scratch_bytes(int64_t chains, int TP) { return (int64_t)tiled_wgs(chains, TP) * tl_slab_floats(TP * tl_nb(TP)) * 4; }
 int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st) {
-    const int wgs = tiled_wgs(P.n_chains);
+    const int wgs = tiled_wgs(P.n_chains, w->tiled_tp);
     switch (w->tiled_tp) {
-        case 16: return launch_score_tiled_t<16>(w, P, M, scratch, wgs, st);
-        case 24: return launch_score_tiled_t<24>(w, P, M, scratch, wgs, st);
-        case 32: return launch_score_tiled_t<32>(w, P, M, scratch, wgs, st);
+        case 16: return launch_score_tiled_t<16, tl_nb(16)>(w, P, M, scratch, wgs, st);
+        case 24: return launch_score_tiled_t<24, tl_nb(24)>(w, P, M, scratch, wgs, st);
+        case 32: return launch_score_tiled_t<32, tl_nb(32)>(w, P, M, scratch, wgs, st);
         default: return fail(MCD_EUNSUPPORTED, "tiled kernel: frame count");
     }
 }
@@ -3614,9 +3707,28 @@ int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx&
 
 static unsigned long long* g_prof = nullptr;  // MCD_PROFILE builds: device buffer of 32 accumulators
 
+// test aid (mcd_debug_poison_lds): every CU's LDS filled with signalling garbage (NaN bit patterns), so that a kernel reading
+// shared memory it never wrote produces NaNs instead of depending on what the previous kernel happened to leave there
+__global__ __launch_bounds__(NTHREADS) void poison_lds_kernel(unsigned* sink, int words) {
+    extern __shared__ unsigned psm[];
+    for (int u = threadIdx.x; u < words; u += NTHREADS) psm[u] = 0x7fc00000u | (unsigned)u;
+    __syncthreads();
+    if (threadIdx.x == 0 && sink) atomicOr(sink, psm[(blockIdx.x * 7919) % words] & 1u);      // (keeps the stores alive)
+    __builtin_amdgcn_s_sleep(64);
+}
+
 extern "C" {
 
 void mcd_debug_set_prof(void* p) { g_prof = reinterpret_cast<unsigned long long*>(p); }
+
+int mcd_debug_poison_lds(void* stream) {
+    constexpr size_t lds = 160 * 1024;
+    LDS_LIMIT(poison_lds_kernel, lds);
+    // one 160 KB workgroup per CU at a time; several waves of them so that every CU of every XCD takes at least one
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(4096), dim3(NTHREADS), lds, static_cast<hipStream_t>(stream), (unsigned*)nullptr, (int)(lds / 4));
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
 
 const char* mcd_last_error(void) { return g_err.c_str(); }
 int32_t mcd_abi_version(void) { return MCD_ABI_VERSION; }
@@ -3879,7 +3991,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
                 cinr = cout;
             }
         }
-        const size_t lds = ((size_t)3 * Cw.cmax * Cw.Tc * 17 + 256) * 4;
+        const size_t lds = ((size_t)3 * Cw.cmax * Cw.Tc * 17 + CE_THREADS) * 4;
         if (lds > 160 * 1024) return fail(MCD_EUNSUPPORTED, "condition encoder activations exceed LDS");
     }
     {
@@ -3946,9 +4058,9 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
             return fail(MCD_EUNSUPPORTED, "mcd_cond_encode: the 'E_unet' encoder at this frame count needs scratch memory; use mcd_score");
         return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, nullptr, (hipStream_t)stream);
     }
-    const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + 256) * 4;
+    const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + CE_THREADS) * 4;
     LDS_LIMIT(&cond_encode_kernel, (size_t)160 * 1024);
-    hipLaunchKernelGGL(cond_encode_kernel, dim3(n_windows), dim3(256), lds, (hipStream_t)stream, w->cond, cond_data, emb_out, n_windows);
+    hipLaunchKernelGGL(cond_encode_kernel, dim3(n_windows), dim3(CE_THREADS), lds, (hipStream_t)stream, w->cond, cond_data, emb_out, n_windows);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }

@@ -271,6 +271,44 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
         np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), atol=ATOL, rtol=0)
 
 
+@pytest.mark.parametrize("strategy,seg_len,ci,arch,generic", [
+    ("inject", 6, 3, "AE", 0), ("inject", 12, 3, "E_unet", 0), ("concat", 12, [0, 1, 2], "AE", 0), ("inject", 24, 2, "AE", 0),
+    ("inject", 10, 2, "AE", 0), ("inject", 20, 2, "E_unet", 0), ("concat", 8, [0, 1, 2, 3], "AE", 0), ("inject", 8, 2, "AE", 0),
+    ("inject", 32, 2, "E_unet", 0), ("concat", 24, [0, 1, 2, 3], "AE", 0), ("concat", 13, [0, 1, 2], "AE", 0),
+    ("inbetween_imp", 30, 3, "AE", 0), ("no_condition", 17, None, "AE", 0), ("concat", 7, [0, 1, 2], "AE", 0),
+    ("inject", 6, 3, "E_unet", 1), ("concat", 24, [0, 1, 2, 3], "AE", 1)])
+def test_no_uninitialised_reads(strategy, seg_len, ci, arch, generic):
+    """Every kernel family with the memory it does not own turned hostile: the LDS of every CU filled with NaN patterns
+    (mcd_debug_poison_lds) and the allocator's free blocks -- which the scorer's workspace is carved from -- filled with NaNs,
+    before the FIRST call of a fresh scorer.  A kernel that reads shared memory or scratch it never wrote (a pad row met by a
+    zero coefficient is enough: 0 * NaN) then returns NaNs or differs from the clean second call; both are checked.
+    (Found one in round 3: the slab-tiled kernel's last layer read 16-channel blocks past its 4-channel product buffer.)"""
+    from mocodad_amd import _lib
+    m, sd, gen = _random_model(strategy, seg_len, ci, arch)
+    m = m.to("cuda:0")
+    sc = m.scorer()
+    if generic:
+        sc.set_option("generic_unet", 1)
+        sc.set_option("cond_generic", 1)
+    B, S, ns = 7, 3, 4                  # (21 trajectories: an odd count for the kernels that take them in pairs)
+    data = torch.randn(B, 2, seg_len, 17, generator=gen).clamp_(-3, 3)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = torch.full((96 << 20,), float("nan"), device="cuda:0")          # 384 MB of NaNs handed back to the caching allocator
+    del junk
+    L = _lib.lib()
+    assert L.mcd_debug_poison_lds(None) == 0
+    torch.cuda.synchronize()
+    a, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=11, first_window_id=2)
+    a = a.cpu().numpy()
+    assert np.isfinite(a).all()
+    b, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=11, first_window_id=2)
+    assert np.array_equal(a, b.cpu().numpy())
+    assert L.mcd_debug_poison_lds(None) == 0
+    c, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=11, first_window_id=2)
+    assert np.array_equal(a, c.cpu().numpy())
+
+
 @pytest.mark.parametrize("variant,ns,S", [("inject", 10, 5), ("concat", 10, 5), ("T12", 10, 2), ("injtail", 10, 2)])
 def test_runtime_shape_kernel_vs_golden_and_specialised(variant, ns, S):
     """The runtime-shape fallback forced (option 'generic_unet') on shapes the specialised kernels serve: it reproduces the

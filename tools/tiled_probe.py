@@ -7,7 +7,7 @@ from mocodad_amd.models.mocodad import MoCoDAD
 def run(strategy, seg_len, ci):
     _, cfg = golden_weights("inject")
     torch.manual_seed(5)
-    m = MoCoDAD(make_args(cfg, conditioning_strategy=strategy, seg_len=seg_len, conditioning_indices=ci, noise_steps=4, n_generated_samples=2))
+    m = MoCoDAD(make_args(cfg, conditioning_strategy=strategy, seg_len=seg_len, conditioning_indices=ci, noise_steps=4, n_generated_samples=3))
     gen = torch.Generator().manual_seed(17)
     with torch.no_grad():
         for mod in m.modules():
@@ -20,7 +20,7 @@ def run(strategy, seg_len, ci):
         last.tcn[0].weight.mul_(0.25); last.residual[0].weight.mul_(0.25)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.to("cuda:0")
-    B, S, ns = 5, 2, 4
+    B, S, ns = 5, 3, 4
     data = torch.randn(B, 2, seg_len, 17, generator=gen).clamp_(-3, 3)
     Tx = m.n_frames_corrupt
     noise = torch.randn(S, ns - 1, B, 2, Tx, 17, generator=gen)
