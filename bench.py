@@ -114,20 +114,25 @@ CONFIGS = {
     # (no reference-generated fixture holds these frame counts): ("rand:<strategy>:<seg_len>:<conditioning_indices>", ...)
     "seg10": ("rand:inject:10:2", 1024, 10, 5, "seg_len 10 = 5 cond + 5 denoised frames (inject), Avenue-shaped windows"),
     "seg20": ("rand:inject:20:2", 1024, 10, 5, "seg_len 20 = 10 cond + 10 denoised frames (inject), Avenue-shaped windows"),
+    "seg14": ("rand:inject:14:2", 1024, 10, 5, "seg_len 14 = 7 cond + 7 denoised frames (inject; U-Net on 7 frames: the slab-tiled kernel, padded to 12)"),
+    "seg22": ("rand:inject:22:2", 1024, 10, 5, "seg_len 22 = 11 cond + 11 denoised frames (inject; U-Net on 11 frames: the slab-tiled kernel, padded to 12)"),
     "concat12": ("rand:concat:12:2", 1024, 10, 5, "seg_len 12, concat conditioning (U-Net on 12 frames, 6 of them denoised)"),
     "concat24": ("rand:concat:24:2", 1024, 10, 5, "seg_len 24, concat conditioning (U-Net on 24 frames: the slab-tiled MFMA kernel)"),
     "seg32": ("rand:inject:32:2", 1024, 10, 5, "seg_len 32 = 16 cond + 16 denoised frames (inject; U-Net on 16 frames: the slab-tiled MFMA kernel)"),
     "concat32": ("rand:concat:32:2", 1024, 10, 5, "seg_len 32, concat conditioning (U-Net on 32 frames: the slab-tiled MFMA kernel)"),
+    # the 'E_unet' condition encoder (the U-Net's down path per window) at frame counts other than 3 / 6 / 12
+    "seg10_eunet": ("rand:inject:10:2:E_unet", 1024, 10, 5, "seg_len 10 = 5 + 5 frames, 'E_unet' condition encoder"),
+    "seg32_eunet": ("rand:inject:32:2:E_unet", 1024, 10, 5, "seg_len 32 = 16 + 16 frames, 'E_unet' condition encoder"),
 }
 
 
-def random_weights(strategy, seg_len, ci):
+def random_weights(strategy, seg_len, ci, arch="AE"):
     """Seeded random-init state_dict (the reference's key layout) for a shape without a fixture: BatchNorm statistics perturbed,
     last layer scaled so that the chain stays O(1) -- the recipe of tests/golden/gen_golden.py's benign fixtures."""
     import argparse
     from mocodad_amd.models.mocodad import MoCoDAD
     _, cfg = load_weights("inject")
-    cfg = dict(cfg, conditioning_strategy=strategy, seg_len=seg_len, conditioning_indices=ci)
+    cfg = dict(cfg, conditioning_strategy=strategy, seg_len=seg_len, conditioning_indices=ci, conditioning_architecture=arch)
     cfg.setdefault("gt_path", cfg.get("test_path"))
     cfg.setdefault("ckpt_dir", "/tmp/mocodad_amd_ckpt")
     torch.manual_seed(1234)
@@ -148,8 +153,8 @@ def random_weights(strategy, seg_len, ci):
 
 def load_weights(variant="inject"):
     if variant.startswith("rand:"):
-        _, strategy, seg_len, ci = variant.split(":")
-        return random_weights(strategy, int(seg_len), int(ci))
+        _, strategy, seg_len, ci, *arch = variant.split(":")
+        return random_weights(strategy, int(seg_len), int(ci), *arch)
     d = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{variant}.npz"))
     w = {k: d[k] for k in d.files}
     cfg = json.loads(bytes(w.pop("__cfg__")).decode())
@@ -329,8 +334,8 @@ def main():
     seg_len, strat = cfg["seg_len"], cfg["conditioning_strategy"]
     ci, xi = frame_split(seg_len, cfg["conditioning_indices"], strat)
     sc = HipScorer(sd, strategy=strat, seg_len=seg_len, cond_idx=ci, corrupt_idx=xi,
-                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device=dev,
-                   options=dict({"bf16x3": 1} if args.bf16x3 else {}, split=args.split, phase=args.phase, variant=args.variant,
+                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], cond_unet=cfg.get("conditioning_architecture") == "E_unet",
+                   device=dev, options=dict({"bf16x3": 1} if args.bf16x3 else {}, split=args.split, phase=args.phase, variant=args.variant,
                                 **({"cond_generic": 1} if args.cond_generic else {})))
     if args.scaling == "weak":
         # every rank owns its own shard of B windows per step (global window ids keep the Philox streams distinct and
@@ -432,7 +437,7 @@ def main():
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
         nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2"}.get(
-            sc.t_unet, f"slab-tiled, T_u={sc.t_unet}" if 12 < sc.t_unet <= 32 else f"runtime-shape, T_u={sc.t_unet}")
+            sc.t_unet, f"slab-tiled, T_u={sc.t_unet}" if 12 < sc.t_unet <= 32 or sc.t_unet in (7, 9, 11) else f"runtime-shape, T_u={sc.t_unet}")
         split_used = sc.plan_split(B, S, ns) if B > 0 else 1         # what the library chose for this call (mcd_plan_split)
         launches = 1 if split_used == 1 else (3 if strat == "inject" else 2)
         if args.variant:

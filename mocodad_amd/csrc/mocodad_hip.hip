@@ -2428,40 +2428,89 @@ constexpr int GEN_SLAB = 3 * GEN_BUF + GEN_D1 + GEN_D2;      // per frame and wo
 
 // one ST-GCN layer (stsgcn.py:94-116, BatchNorm folded): X [cin][T][V] -> O [cout][T][V]; Y (>= cin T V floats, may be O) and
 // Z are scratch.  emb: the pass's embedding outputs (LDS) or null.
+// Each stage as wave tasks of (8 channels, 64 columns) with 8 accumulators per thread: a column's activation (or coefficient)
+// is loaded once for 8 multiply-adds, and the GEMM's weight rows are wave-uniform scalar loads (see cond_encode_kernel).
 __device__ void g_layer(const float* wb, const GLayer& L, int T, const float* X, float* Y, float* Z, float* O, const float* emb) {
-    const int V = L.V, TV = T * V, tid = threadIdx.x;
+    const int V = L.V, TV = T * V, cin = L.cin, cout = L.cout, nblk = (TV + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    constexpr int NW = GEN_THREADS / 64;
     const float* Tq = wb + L.tq;      // [q][v][t]
     const float* Am = wb + L.am;      // [q][v][w]
-    for (int u = tid; u < L.cin * TV; u += GEN_THREADS) {
-        const int c = u / TV, q = (u % TV) / V, v = u % V;
-        const float* x = X + c * TV + v;
-        const float* tq = Tq + (q * V + v) * T;
-        float y = 0.f;
-        for (int t = 0; t < T; ++t) y = fmaf(x[t * V], tq[t], y);
-        Y[u] = y;
+    const int ngi = (cin + 7) / 8, ngo = (cout + 7) / 8;
+    for (int task = wave; task < ngi * nblk; task += NW) {          // time mix: Y[c][q, v] = sum_t X[c][t, v] Tq[q, v][t]
+        const int c0 = (task / nblk) * 8, p = (task % nblk) * 64 + lane;
+        if (p < TV) {
+            const float* tq = Tq + (size_t)p * T;
+            const float* xb = X + p % V;
+            int co[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) co[i] = (c0 + i < cin ? c0 + i : cin - 1) * TV;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < T; ++t) {
+                const float tv = tq[t];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(xb[co[i] + t * V], tv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c0 + i < cin) Y[(c0 + i) * TV + p] = acc[i];
+        }
     }
     __syncthreads();
-    for (int u = tid; u < L.cin * TV; u += GEN_THREADS) {
-        const int c = u / TV, q = (u % TV) / V, w = u % V;
-        const float* y = Y + c * TV + q * V;
-        const float* a = Am + q * V * V + w;
-        float z = 0.f;
-        for (int v = 0; v < V; ++v) z = fmaf(y[v], a[v * V], z);
-        Z[u] = z;
+    for (int task = wave; task < ngi * nblk; task += NW) {          // joint mix: Z[c][q, w] = sum_v Y[c][q, v] A[q, v][w]
+        const int c0 = (task / nblk) * 8, p = (task % nblk) * 64 + lane;
+        if (p < TV) {
+            const int q = p / V, w = p % V;
+            const float* am = Am + (size_t)q * V * V + w;
+            const float* yb = Y + q * V;
+            int co[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) co[i] = (c0 + i < cin ? c0 + i : cin - 1) * TV;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < V; ++v) {
+                const float a = am[v * V];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(yb[co[i] + v], a, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c0 + i < cin) Z[(c0 + i) * TV + p] = acc[i];
+        }
     }
     __syncthreads();
     const float* wt = wb + L.wt;
     const float* wr = L.wr >= 0 ? wb + L.wr : nullptr;
     const float* bias = wb + L.bias;
-    for (int u = tid; u < L.cout * TV; u += GEN_THREADS) {
-        const int co = u / TV, p = u % TV;
-        float a = bias[co];
-        for (int c = 0; c < L.cin; ++c) a = fmaf(wt[co * L.cin + c], Z[c * TV + p], a);
-        if (wr) { for (int c = 0; c < L.cin; ++c) a = fmaf(wr[co * L.cin + c], X[c * TV + p], a); }
-        else a += X[co * TV + p];
-        a = prelu(a, L.slope);
-        if (emb && L.embo >= 0) a += emb[L.embo + co];
-        O[u] = a;
+    const float slope = L.slope;
+    const bool has_emb = emb && L.embo >= 0;
+    for (int task = wave; task < ngo * nblk; task += NW) {          // channel GEMM + residual + PReLU (+ embedding)
+        const int o0 = (task / nblk) * 8, p = (task % nblk) * 64 + lane;
+        int row[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = o0 + i < cout ? o0 + i : cout - 1;
+        if (p < TV) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = bias[row[i]];
+            for (int c = 0; c < cin; ++c) {
+                const float z = Z[c * TV + p];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(wt[row[i] * cin + c], z, acc[i]);
+            }
+            if (wr) {
+                for (int c = 0; c < cin; ++c) {
+                    const float x = X[c * TV + p];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(wr[row[i] * cin + c], x, acc[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += X[row[i] * TV + p];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (o0 + i < cout) O[(o0 + i) * TV + p] = prelu(acc[i], slope) + (has_emb ? emb[L.embo + row[i]] : 0.f);
+        }
     }
     __syncthreads();
 }
@@ -3641,12 +3690,26 @@ int launch_cond_unet_t(const mcd_weights* w, const DataView& data, const FrameId
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
+// frame counts the MFMA 'E_unet' encoder is instantiated for (the trajectory kernel's LDS plans)
+bool cond_unet_has_kernel(int Tc) {
+#ifdef MCD_FAST_T
+    return Tc == 3 || Tc == 6 || Tc == 12;
+#else
+    return Tc == 3 || Tc == 4 || Tc == 5 || Tc == 6 || Tc == 8 || Tc == 10 || Tc == 12;
+#endif
+}
 int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     switch (w->cond.Tc) {
         case 3: return launch_cond_unet_t<3, 2>(w, data, fi, seg_len, emb, B, st);
         case 6: return launch_cond_unet_t<6, 1>(w, data, fi, seg_len, emb, B, st);
         case 12: return launch_cond_unet_t<12, 1>(w, data, fi, seg_len, emb, B, st);
-        default: return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated (supported: 3, 6, 12)");
+#ifndef MCD_FAST_T
+        case 4: return launch_cond_unet_t<4, 2>(w, data, fi, seg_len, emb, B, st);
+        case 5: return launch_cond_unet_t<5, 2>(w, data, fi, seg_len, emb, B, st);
+        case 8: return launch_cond_unet_t<8, 1>(w, data, fi, seg_len, emb, B, st);
+        case 10: return launch_cond_unet_t<10, 1>(w, data, fi, seg_len, emb, B, st);
+#endif
+        default: return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated");
     }
 }
 constexpr int GEN_MAX_WGS = 2048;       // persistent grid of the runtime-shape kernels (8 workgroups of 4 waves per CU)
@@ -3664,7 +3727,7 @@ int launch_score_generic(const mcd_weights* w, const ScoreParams& P, const Frame
 }
 // MFMA kernel of the long windows (12 < T <= 32); slabs: tl_slab_floats(TP) floats per workgroup
 // chains per workgroup of the slab-tiled kernel: two 16-frame chains share one (see score_tiled_kernel)
-constexpr int tl_nb(int TP) { return TP == 16 ? 2 : 1; }
+constexpr int tl_nb(int TP) { return TP <= 16 ? 2 : 1; }
 template <int TP, int NB>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
     constexpr int TF = TP * NB;
@@ -3684,6 +3747,7 @@ int64_t tiled_scratch_bytes(int64_t chains, int TP) { return (int64_t)tiled_wgs(
 int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st) {
     const int wgs = tiled_wgs(P.n_chains, w->tiled_tp);
     switch (w->tiled_tp) {
+        case 12: return launch_score_tiled_t<12, tl_nb(12)>(w, P, M, scratch, wgs, st);
         case 16: return launch_score_tiled_t<16, tl_nb(16)>(w, P, M, scratch, wgs, st);
         case 24: return launch_score_tiled_t<24, tl_nb(24)>(w, P, M, scratch, wgs, st);
         case 32: return launch_score_tiled_t<32, tl_nb(32)>(w, P, M, scratch, wgs, st);
@@ -3696,7 +3760,7 @@ int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx&
                      hipStream_t st) {
     if (!w->cond_unet) return launch_cond_fast(w, data, fi, seg_len, emb, B, st);
     const int Tc = w->cond.Tc;
-    if ((Tc == 3 || Tc == 6 || Tc == 12) && !w->opt[MCD_OPT_COND_GENERIC]) return launch_cond_unet(w, data, fi, seg_len, emb, B, st);
+    if (cond_unet_has_kernel(Tc) && !w->opt[MCD_OPT_COND_GENERIC]) return launch_cond_unet(w, data, fi, seg_len, emb, B, st);
     if (!scratch) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape condition encoder");
     const int wgs = B < GEN_MAX_WGS ? B : GEN_MAX_WGS;
     hipLaunchKernelGGL(cond_unet_generic_kernel, dim3(wgs), dim3(GEN_THREADS), 0, st, w->dbuf, w->gcond, data, fi, seg_len, Tc, B, emb, scratch);
@@ -3837,7 +3901,9 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     // GEMM fragments, biases, slopes and the embedding Linear are the specialised kernels' own
     TiledNet TN;
     memset(&TN, 0, sizeof(TN));
-    const int tiled_tp = (T > 12 && T <= 32) ? (T <= 16 ? 16 : T <= 24 ? 24 : 32) : 0;
+    // slab-tiled kernel: 13 .. 32 frames padded to 16 / 24 / 32; 7, 9 and 11 frames (no specialised kernel) padded to 12, two
+    // chains per workgroup
+    const int tiled_tp = (T > 12 && T <= 32) ? (T <= 16 ? 16 : T <= 24 ? 24 : 32) : (T == 7 || T == 9 || T == 11) ? 12 : 0;
     if (tiled_tp) {
         for (int l = 0; l < NLAYERS; ++l) {
             const LDesc D = layer_desc(l);
@@ -4054,7 +4120,7 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
         DataView dv;
         memset(&dv, 0, sizeof(dv));
         dv.data = cond_data;
-        if (w->cond_unet && !(w->cond.Tc == 3 || w->cond.Tc == 6 || w->cond.Tc == 12))
+        if (w->cond_unet && !cond_unet_has_kernel(w->cond.Tc))
             return fail(MCD_EUNSUPPORTED, "mcd_cond_encode: the 'E_unet' encoder at this frame count needs scratch memory; use mcd_score");
         return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, nullptr, (hipStream_t)stream);
     }

@@ -230,8 +230,10 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     # 5 and 10 U-Net frames (seg_len 10 / 20 split in halves, seg_len 10 with every frame in the U-Net): specialised since round 3
     ("inject", 10, 2, "AE"), ("no_condition", 5, None, "AE"), ("inject", 10, 2, "E_unet"), ("inbetween_imp", 10, 2, "AE"),
     ("inject", 20, 2, "AE"), ("concat", 10, [0, 1, 2], "AE"),
-    # frame counts WITHOUT a specialised instantiation -> the runtime-shape kernel (the reference is generic in n_frames)
-    ("concat", 7, [0, 1, 2], "AE"),
+    # 7, 9 and 11 U-Net frames: the slab-tiled kernel with the frame count padded to 12, two chains per workgroup
+    ("concat", 7, [0, 1, 2], "AE"), ("inject", 18, 2, "AE"), ("inject", 22, 2, "E_unet"), ("inbetween_imp", 9, 3, "AE"),
+    # frame counts WITHOUT any MFMA kernel -> the runtime-shape kernel (the reference is generic in n_frames)
+    ("inject", 4, 2, "AE"), ("inject", 2, 2, "E_unet"),
     # 13 .. 32 U-Net frames: the slab-tiled MFMA kernel (frame count padded to 16 / 24 / 32), cross-checked with the plain-FMA kernel
     ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE"), ("concat", 13, [0, 1, 2], "AE"), ("inject", 26, 2, "E_unet"),
     ("concat", 20, [0, 1], "AE"), ("inbetween_imp", 30, 3, "AE"), ("no_condition", 17, None, "AE"), ("concat", 32, [28, 29, 30, 31], "AE")])
@@ -262,9 +264,9 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     z = sc.philox_noise(B, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
     b, _ = sc.score(data, n_samples=S, noise_steps=ns, noise=z)
     assert torch.equal(a, b)
-    # frame counts with an MFMA kernel (4, 5, 8, 10 specialised; 13 .. 32 slab-tiled): the plain-FMA runtime-shape kernel forced
-    # on the same call agrees
-    if m.input_n_frames in (4, 5, 8, 10) or m.input_n_frames > 12:
+    # frame counts with an MFMA kernel (4, 5, 8, 10 specialised; 7, 9, 11 and 13 .. 32 slab-tiled): the plain-FMA runtime-shape
+    # kernel forced on the same call agrees
+    if m.input_n_frames in (4, 5, 7, 8, 9, 10, 11) or m.input_n_frames > 12:
         sc.set_option("generic_unet", 1)
         c, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
         sc.set_option("generic_unet", 0)
@@ -276,6 +278,7 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     ("inject", 10, 2, "AE", 0), ("inject", 20, 2, "E_unet", 0), ("concat", 8, [0, 1, 2, 3], "AE", 0), ("inject", 8, 2, "AE", 0),
     ("inject", 32, 2, "E_unet", 0), ("concat", 24, [0, 1, 2, 3], "AE", 0), ("concat", 13, [0, 1, 2], "AE", 0),
     ("inbetween_imp", 30, 3, "AE", 0), ("no_condition", 17, None, "AE", 0), ("concat", 7, [0, 1, 2], "AE", 0),
+    ("inject", 22, 2, "E_unet", 0), ("inject", 4, 2, "AE", 0),
     ("inject", 6, 3, "E_unet", 1), ("concat", 24, [0, 1, 2, 3], "AE", 1)])
 def test_no_uninitialised_reads(strategy, seg_len, ci, arch, generic):
     """Every kernel family with the memory it does not own turned hostile: the LDS of every CU filled with NaN patterns
