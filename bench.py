@@ -114,8 +114,8 @@ CONFIGS = {
     # (no reference-generated fixture holds these frame counts): ("rand:<strategy>:<seg_len>:<conditioning_indices>", ...)
     "seg10": ("rand:inject:10:2", 1024, 10, 5, "seg_len 10 = 5 cond + 5 denoised frames (inject), Avenue-shaped windows"),
     "seg20": ("rand:inject:20:2", 1024, 10, 5, "seg_len 20 = 10 cond + 10 denoised frames (inject), Avenue-shaped windows"),
-    "seg14": ("rand:inject:14:2", 1024, 10, 5, "seg_len 14 = 7 cond + 7 denoised frames (inject; U-Net on 7 frames: the slab-tiled kernel, padded to 12)"),
-    "seg22": ("rand:inject:22:2", 1024, 10, 5, "seg_len 22 = 11 cond + 11 denoised frames (inject; U-Net on 11 frames: the slab-tiled kernel, padded to 12)"),
+    "seg14": ("rand:inject:14:2", 1024, 10, 5, "seg_len 14 = 7 cond + 7 denoised frames (inject; U-Net on 7 frames)"),
+    "seg22": ("rand:inject:22:2", 1024, 10, 5, "seg_len 22 = 11 cond + 11 denoised frames (inject; U-Net on 11 frames)"),
     "concat12": ("rand:concat:12:2", 1024, 10, 5, "seg_len 12, concat conditioning (U-Net on 12 frames, 6 of them denoised)"),
     "concat24": ("rand:concat:24:2", 1024, 10, 5, "seg_len 24, concat conditioning (U-Net on 24 frames: the slab-tiled MFMA kernel)"),
     "seg32": ("rand:inject:32:2", 1024, 10, 5, "seg_len 32 = 16 cond + 16 denoised frames (inject; U-Net on 16 frames: the slab-tiled MFMA kernel)"),
@@ -436,8 +436,8 @@ def main():
         flop_per_window = P * f_unet(sc.t_unet) + (f_cond(sc.t_cond) if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
-        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2"}.get(
-            sc.t_unet, f"slab-tiled, T_u={sc.t_unet}" if 12 < sc.t_unet <= 32 or sc.t_unet in (7, 9, 11) else f"runtime-shape, T_u={sc.t_unet}")
+        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2"}.get(
+            sc.t_unet, f"slab-tiled, T_u={sc.t_unet}" if 12 < sc.t_unet <= 32 else f"runtime-shape, T_u={sc.t_unet}")
         split_used = sc.plan_split(B, S, ns) if B > 0 else 1         # what the library chose for this call (mcd_plan_split)
         launches = 1 if split_used == 1 else (3 if strat == "inject" else 2)
         if args.variant:

@@ -3533,7 +3533,7 @@ struct mcd_weights {
     bool has_cond;
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
     bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
-    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3, 4, 5, 6, 8, 10, 12); otherwise the runtime-shape kernel
+    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3 .. 12); otherwise the slab-tiled (13 .. 32) or the runtime-shape kernel
     TiledNet tiled;   // tables of score_tiled_kernel (12 < t_unet <= 32), frame count padded to tiled_tp
     int tiled_tp;     // 16, 24 or 32; 0 = none
     GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
@@ -3655,7 +3655,10 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
         case 5: return launch_score_t<5, 2, 2>(P, st, fused);                 // e.g. seg_len 10 split in halves (2 chains / WG, 1 WG per CU)
         case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
         case 10: return launch_score_t<10, 1, 2>(P, st, fused);               // e.g. seg_len 20 split in halves / seg_len 10 concat
-        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3, 4, 5, 6, 8, 10, 12)");
+        case 7: return launch_score_t<7, 1, 2>(P, st, fused);                 // odd frame counts: one output frame per mix unit
+        case 9: return launch_score_t<9, 1, 2>(P, st, fused);
+        case 11: return launch_score_t<11, 1, 2>(P, st, fused);
+        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3 .. 12)");
     }
 #endif
 }
@@ -3678,6 +3681,11 @@ int launch_cond_fast(const mcd_weights* w, const DataView& data, const FrameIdx&
         case 5: return launch_cond_fast_t<5, 2>(w, data, fi, seg_len, emb, B, st);
         case 6: return launch_cond_fast_t<6, 2>(w, data, fi, seg_len, emb, B, st);
         case 10: return launch_cond_fast_t<10, 1>(w, data, fi, seg_len, emb, B, st);
+        case 4: return launch_cond_fast_t<4, 2>(w, data, fi, seg_len, emb, B, st);
+        case 7: return launch_cond_fast_t<7, 1>(w, data, fi, seg_len, emb, B, st);
+        case 8: return launch_cond_fast_t<8, 1>(w, data, fi, seg_len, emb, B, st);
+        case 9: return launch_cond_fast_t<9, 1>(w, data, fi, seg_len, emb, B, st);
+        case 11: return launch_cond_fast_t<11, 1>(w, data, fi, seg_len, emb, B, st);
         case 12: return launch_cond_fast_t<12, 1>(w, data, fi, seg_len, emb, B, st);
         default: return fail(MCD_EUNSUPPORTED, "cond_fast: frame count not instantiated");
     }
@@ -3695,7 +3703,7 @@ bool cond_unet_has_kernel(int Tc) {
 #ifdef MCD_FAST_T
     return Tc == 3 || Tc == 6 || Tc == 12;
 #else
-    return Tc == 3 || Tc == 4 || Tc == 5 || Tc == 6 || Tc == 8 || Tc == 10 || Tc == 12;
+    return Tc >= 3 && Tc <= 12;
 #endif
 }
 int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
@@ -3708,6 +3716,9 @@ int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx&
         case 5: return launch_cond_unet_t<5, 2>(w, data, fi, seg_len, emb, B, st);
         case 8: return launch_cond_unet_t<8, 1>(w, data, fi, seg_len, emb, B, st);
         case 10: return launch_cond_unet_t<10, 1>(w, data, fi, seg_len, emb, B, st);
+        case 7: return launch_cond_unet_t<7, 1>(w, data, fi, seg_len, emb, B, st);
+        case 9: return launch_cond_unet_t<9, 1>(w, data, fi, seg_len, emb, B, st);
+        case 11: return launch_cond_unet_t<11, 1>(w, data, fi, seg_len, emb, B, st);
 #endif
         default: return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated");
     }
@@ -3747,7 +3758,6 @@ int64_t tiled_scratch_bytes(int64_t chains, int TP) { return (int64_t)tiled_wgs(
 int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st) {
     const int wgs = tiled_wgs(P.n_chains, w->tiled_tp);
     switch (w->tiled_tp) {
-        case 12: return launch_score_tiled_t<12, tl_nb(12)>(w, P, M, scratch, wgs, st);
         case 16: return launch_score_tiled_t<16, tl_nb(16)>(w, P, M, scratch, wgs, st);
         case 24: return launch_score_tiled_t<24, tl_nb(24)>(w, P, M, scratch, wgs, st);
         case 32: return launch_score_tiled_t<32, tl_nb(32)>(w, P, M, scratch, wgs, st);
@@ -3805,7 +3815,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (cfg->emb_dim != EDIM) return fail(MCD_EUNSUPPORTED, "embedding_dim must be 16");
     const int T = cfg->t_unet;
     if (T < 1 || T > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "U-Net frame count must be in 1.." + std::to_string(MCD_MAX_FRAMES));
-    const bool fast_unet = T == 3 || T == 4 || T == 5 || T == 6 || T == 8 || T == 10 || T == 12;     // the instantiated score_kernel<T,...>
+    const bool fast_unet = T >= 3 && T <= 12;     // the instantiated score_kernel<T,...>
     GenNet G;
     memset(&G, 0, sizeof(G));
     GenCond GC;
@@ -3901,9 +3911,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     // GEMM fragments, biases, slopes and the embedding Linear are the specialised kernels' own
     TiledNet TN;
     memset(&TN, 0, sizeof(TN));
-    // slab-tiled kernel: 13 .. 32 frames padded to 16 / 24 / 32; 7, 9 and 11 frames (no specialised kernel) padded to 12, two
-    // chains per workgroup
-    const int tiled_tp = (T > 12 && T <= 32) ? (T <= 16 ? 16 : T <= 24 ? 24 : 32) : (T == 7 || T == 9 || T == 11) ? 12 : 0;
+    const int tiled_tp = (T > 12 && T <= 32) ? (T <= 16 ? 16 : T <= 24 ? 24 : 32) : 0;
     if (tiled_tp) {
         for (int l = 0; l < NLAYERS; ++l) {
             const LDesc D = layer_desc(l);
@@ -4032,7 +4040,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         Cw.lb = B.alloc(EDIM); memcpy(&B.buf[Cw.lb], lb, sizeof(float) * EDIM);
         // fast path (cond_fast_kernel): the shipped architecture at a frame count the MFMA stages are instantiated for
         cond_fast = Cw.n_layers == 4 && Cw.cout[0] == 32 && Cw.cout[1] == 16 && Cw.cout[2] == 32 && Cw.cout[3] == 32 &&
-                    (Cw.Tc == 3 || Cw.Tc == 5 || Cw.Tc == 6 || Cw.Tc == 10 || Cw.Tc == 12);
+                    Cw.Tc >= 3 && Cw.Tc <= 12;
         if (cond_fast) {
             int cinr = C0;
             for (int l = 0; l < 4; ++l) {

@@ -230,7 +230,7 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     # 5 and 10 U-Net frames (seg_len 10 / 20 split in halves, seg_len 10 with every frame in the U-Net): specialised since round 3
     ("inject", 10, 2, "AE"), ("no_condition", 5, None, "AE"), ("inject", 10, 2, "E_unet"), ("inbetween_imp", 10, 2, "AE"),
     ("inject", 20, 2, "AE"), ("concat", 10, [0, 1, 2], "AE"),
-    # 7, 9 and 11 U-Net frames: the slab-tiled kernel with the frame count padded to 12, two chains per workgroup
+    # 7, 9 and 11 U-Net frames: specialised too (one output frame per mix unit)
     ("concat", 7, [0, 1, 2], "AE"), ("inject", 18, 2, "AE"), ("inject", 22, 2, "E_unet"), ("inbetween_imp", 9, 3, "AE"),
     # frame counts WITHOUT any MFMA kernel -> the runtime-shape kernel (the reference is generic in n_frames)
     ("inject", 4, 2, "AE"), ("inject", 2, 2, "E_unet"),
@@ -264,8 +264,8 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     z = sc.philox_noise(B, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
     b, _ = sc.score(data, n_samples=S, noise_steps=ns, noise=z)
     assert torch.equal(a, b)
-    # frame counts with an MFMA kernel (4, 5, 8, 10 specialised; 7, 9, 11 and 13 .. 32 slab-tiled): the plain-FMA runtime-shape
-    # kernel forced on the same call agrees
+    # frame counts with an MFMA kernel (4, 5, 7 .. 11 specialised; 13 .. 32 slab-tiled): the plain-FMA runtime-shape kernel
+    # forced on the same call agrees
     if m.input_n_frames in (4, 5, 7, 8, 9, 10, 11) or m.input_n_frames > 12:
         sc.set_option("generic_unet", 1)
         c, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
