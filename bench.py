@@ -114,6 +114,7 @@ CONFIGS = {
     # (no reference-generated fixture holds these frame counts): ("rand:<strategy>:<seg_len>:<conditioning_indices>", ...)
     "seg10": ("rand:inject:10:2", 1024, 10, 5, "seg_len 10 = 5 cond + 5 denoised frames (inject), Avenue-shaped windows"),
     "seg20": ("rand:inject:20:2", 1024, 10, 5, "seg_len 20 = 10 cond + 10 denoised frames (inject), Avenue-shaped windows"),
+    "seg4": ("rand:inject:4:2", 1024, 10, 5, "seg_len 4 = 2 cond + 2 denoised frames (inject; U-Net on 2 frames)"),
     "seg14": ("rand:inject:14:2", 1024, 10, 5, "seg_len 14 = 7 cond + 7 denoised frames (inject; U-Net on 7 frames)"),
     "seg22": ("rand:inject:22:2", 1024, 10, 5, "seg_len 22 = 11 cond + 11 denoised frames (inject; U-Net on 11 frames)"),
     "concat12": ("rand:concat:12:2", 1024, 10, 5, "seg_len 12, concat conditioning (U-Net on 12 frames, 6 of them denoised)"),
@@ -436,7 +437,7 @@ def main():
         flop_per_window = P * f_unet(sc.t_unet) + (f_cond(sc.t_cond) if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
-        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2"}.get(
+        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2", 1: "1,4,4", 2: "2,3,4"}.get(
             sc.t_unet, f"slab-tiled, T_u={sc.t_unet}" if 12 < sc.t_unet <= 32 else f"runtime-shape, T_u={sc.t_unet}")
         split_used = sc.plan_split(B, S, ns) if B > 0 else 1         # what the library chose for this call (mcd_plan_split)
         launches = 1 if split_used == 1 else (3 if strat == "inject" else 2)

@@ -3533,7 +3533,7 @@ struct mcd_weights {
     bool has_cond;
     bool cond_fast;   // shipped condition-encoder architecture -> cond_fast_kernel
     bool cond_unet;   // 'E_unet' condition encoder -> cond_unet_kernel
-    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (3 .. 12); otherwise the slab-tiled (13 .. 32) or the runtime-shape kernel
+    bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (1 .. 12); otherwise the slab-tiled (13 .. 32) or the runtime-shape kernel
     TiledNet tiled;   // tables of score_tiled_kernel (12 < t_unet <= 32), frame count padded to tiled_tp
     int tiled_tp;     // 16, 24 or 32; 0 = none
     GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
@@ -3658,7 +3658,9 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
         case 7: return launch_score_t<7, 1, 2>(P, st, fused);                 // odd frame counts: one output frame per mix unit
         case 9: return launch_score_t<9, 1, 2>(P, st, fused);
         case 11: return launch_score_t<11, 1, 2>(P, st, fused);
-        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 3 .. 12)");
+        case 1: return launch_score_t<1, 4, 4>(P, st, fused);                 // (4 chains / WG, 2 WGs per CU)
+        case 2: return launch_score_t<2, 3, 4>(P, st, fused);                 // e.g. seg_len 4 split in halves (3 chains / WG, 2 WGs per CU)
+        default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 1 .. 12)");
     }
 #endif
 }
@@ -3686,6 +3688,8 @@ int launch_cond_fast(const mcd_weights* w, const DataView& data, const FrameIdx&
         case 8: return launch_cond_fast_t<8, 1>(w, data, fi, seg_len, emb, B, st);
         case 9: return launch_cond_fast_t<9, 1>(w, data, fi, seg_len, emb, B, st);
         case 11: return launch_cond_fast_t<11, 1>(w, data, fi, seg_len, emb, B, st);
+        case 1: return launch_cond_fast_t<1, 4>(w, data, fi, seg_len, emb, B, st);
+        case 2: return launch_cond_fast_t<2, 3>(w, data, fi, seg_len, emb, B, st);
         case 12: return launch_cond_fast_t<12, 1>(w, data, fi, seg_len, emb, B, st);
         default: return fail(MCD_EUNSUPPORTED, "cond_fast: frame count not instantiated");
     }
@@ -3703,7 +3707,7 @@ bool cond_unet_has_kernel(int Tc) {
 #ifdef MCD_FAST_T
     return Tc == 3 || Tc == 6 || Tc == 12;
 #else
-    return Tc >= 3 && Tc <= 12;
+    return Tc >= 1 && Tc <= 12;
 #endif
 }
 int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
@@ -3719,6 +3723,8 @@ int launch_cond_unet(const mcd_weights* w, const DataView& data, const FrameIdx&
         case 7: return launch_cond_unet_t<7, 1>(w, data, fi, seg_len, emb, B, st);
         case 9: return launch_cond_unet_t<9, 1>(w, data, fi, seg_len, emb, B, st);
         case 11: return launch_cond_unet_t<11, 1>(w, data, fi, seg_len, emb, B, st);
+        case 1: return launch_cond_unet_t<1, 4>(w, data, fi, seg_len, emb, B, st);
+        case 2: return launch_cond_unet_t<2, 3>(w, data, fi, seg_len, emb, B, st);
 #endif
         default: return fail(MCD_EUNSUPPORTED, "E_unet condition encoder: frame count not instantiated");
     }
@@ -3815,7 +3821,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (cfg->emb_dim != EDIM) return fail(MCD_EUNSUPPORTED, "embedding_dim must be 16");
     const int T = cfg->t_unet;
     if (T < 1 || T > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "U-Net frame count must be in 1.." + std::to_string(MCD_MAX_FRAMES));
-    const bool fast_unet = T >= 3 && T <= 12;     // the instantiated score_kernel<T,...>
+    const bool fast_unet = T >= 1 && T <= 12;     // the instantiated score_kernel<T,...>
     GenNet G;
     memset(&G, 0, sizeof(G));
     GenCond GC;
@@ -4040,7 +4046,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         Cw.lb = B.alloc(EDIM); memcpy(&B.buf[Cw.lb], lb, sizeof(float) * EDIM);
         // fast path (cond_fast_kernel): the shipped architecture at a frame count the MFMA stages are instantiated for
         cond_fast = Cw.n_layers == 4 && Cw.cout[0] == 32 && Cw.cout[1] == 16 && Cw.cout[2] == 32 && Cw.cout[3] == 32 &&
-                    Cw.Tc >= 3 && Cw.Tc <= 12;
+                    Cw.Tc >= 1 && Cw.Tc <= 12;
         if (cond_fast) {
             int cinr = C0;
             for (int l = 0; l < 4; ++l) {

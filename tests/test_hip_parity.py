@@ -232,16 +232,16 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     ("inject", 20, 2, "AE"), ("concat", 10, [0, 1, 2], "AE"),
     # 7, 9 and 11 U-Net frames: specialised too (one output frame per mix unit)
     ("concat", 7, [0, 1, 2], "AE"), ("inject", 18, 2, "AE"), ("inject", 22, 2, "E_unet"), ("inbetween_imp", 9, 3, "AE"),
-    # frame counts WITHOUT any MFMA kernel -> the runtime-shape kernel (the reference is generic in n_frames)
-    ("inject", 4, 2, "AE"), ("inject", 2, 2, "E_unet"),
+    # 1 and 2 U-Net frames (seg_len 4 / 2 split in halves, a 1-frame condition): specialised as well
+    ("inject", 4, 2, "AE"), ("inject", 2, 2, "E_unet"), ("concat", 2, [0], "AE"), ("no_condition", 1, None, "AE"),
     # 13 .. 32 U-Net frames: the slab-tiled MFMA kernel (frame count padded to 16 / 24 / 32), cross-checked with the plain-FMA kernel
     ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE"), ("concat", 13, [0, 1, 2], "AE"), ("inject", 26, 2, "E_unet"),
     ("concat", 20, [0, 1], "AE"), ("inbetween_imp", 30, 3, "AE"), ("no_condition", 17, None, "AE"), ("concat", 32, [28, 29, 30, 31], "AE")])
 def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
-    """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 4 / 5 / 8 / 10 frames on the specialised
-    kernels (seg_len 10 split 5 + 5, seg_len 20 split 10 + 10, concat over 10 frames, ...; cross-checked against the
-    runtime-shape kernel); 13 .. 32 frames (concat over 13 / 20 / 24 / 32 frames, 16 + 16, in-between imputation over 30, ...) on
-    the slab-tiled MFMA kernel, cross-checked likewise; 7 frames on the runtime-shape fallback; 'E_unet' encoder included.
+    """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 1, 2, 4, 5, 7 .. 11 frames on the
+    specialised kernels (seg_len 10 split 5 + 5, seg_len 20 split 10 + 10, concat over 10 frames, a 1-frame window, ...); 13 .. 32
+    frames (concat over 13 / 20 / 24 / 32 frames, 16 + 16, in-between imputation over 30, ...) on the slab-tiled MFMA kernel; both
+    cross-checked against the plain-FMA runtime-shape kernel; 'E_unet' encoder included.
     (concat with a 4-frame condition at the END of a 32-frame window chains 28 predictions: bound relative to the poses there.)"""
     from oracle import mocodad_oracle as O
     m, sd, gen = _random_model(strategy, seg_len, ci, arch)
@@ -266,7 +266,7 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     assert torch.equal(a, b)
     # frame counts with an MFMA kernel (4, 5, 7 .. 11 specialised; 13 .. 32 slab-tiled): the plain-FMA runtime-shape kernel
     # forced on the same call agrees
-    if m.input_n_frames in (4, 5, 7, 8, 9, 10, 11) or m.input_n_frames > 12:
+    if m.input_n_frames not in (3, 6, 12):
         sc.set_option("generic_unet", 1)
         c, _ = sc.score(data, n_samples=S, noise_steps=ns, seed=5, first_window_id=3)
         sc.set_option("generic_unet", 0)
