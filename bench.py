@@ -437,12 +437,19 @@ def main():
         flop_per_window = P * f_unet(sc.t_unet) + (f_cond(sc.t_cond) if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
-        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2", 1: "1,4,4", 2: "2,3,4"}.get(
-            sc.t_unet, f"slab-tiled, T_u={sc.t_unet}" if 12 < sc.t_unet <= 32 else f"runtime-shape, T_u={sc.t_unet}")
+        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2", 1: "1,4,4", 2: "2,3,4"}.get(sc.t_unet)
+        tiled = nb is None         # 13 .. 32 U-Net frames: the slab-tiled kernel, frame count padded to 16 (two chains per workgroup) / 24 / 32
+        kname = f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" if nb else \
+            "score_tiled_kernel<%s> (T_u=%d)" % ("16,2" if sc.t_unet <= 16 else "24,1" if sc.t_unet <= 24 else "32,1", sc.t_unet)
+        enc = "" if strat != "inject" else (" + cond_unet_generic_kernel" if cfg.get("conditioning_architecture") == "E_unet" else " + cond_encode_kernel") if sc.t_cond > 12 \
+            else (f" + cond_unet_kernel<{sc.t_cond}>" if cfg.get("conditioning_architecture") == "E_unet" else f" + cond_fast_kernel<{sc.t_cond}>")
         split_used = sc.plan_split(B, S, ns) if B > 0 else 1         # what the library chose for this call (mcd_plan_split)
-        launches = 1 if split_used == 1 else (3 if strat == "inject" else 2)
+        # the shipped ('AE') encoder with as many condition frames as the U-Net has frames runs inside the one-launch kernel
+        enc_inside = strat != "inject" or (cfg.get("conditioning_architecture") != "E_unet" and sc.t_cond == sc.t_unet)
+        one_launch = split_used == 1 and not tiled
+        launches = (1 if enc_inside else 2) if one_launch else (3 if strat == "inject" else 2)
         if args.variant:
-            nb += f" variant {args.variant}"
+            kname += f" variant {args.variant}"
         out = {
             "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
             "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps,
@@ -457,8 +464,9 @@ def main():
             "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
             "step_ms_first": [round(float(v), 4) for v in step_ms[:4]] if B > 0 else None,
             "step_ms_max": [round(float(np.max(step_ms)), 4), int(np.argmax(step_ms))] if B > 0 else None,    # [ms, step index]
-            "roofline": {"bound": "mfma", "kernel": f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" + (" (condition encoder and aggregation inside: one launch per step)" if split_used == 1
-                                    else (f" + cond_fast_kernel<{sc.t_cond}>" if strat == "inject" else "") + " + aggregate_kernel (one trajectory per workgroup: "
+            "roofline": {"bound": "mfma", "kernel": kname + (" (condition encoder and aggregation inside: one launch per step)" if one_launch and enc_inside
+                                    else enc + " (aggregation inside the trajectory kernel: 2 launches per step)" if one_launch
+                                    else enc + " + aggregate_kernel (one trajectory per workgroup: "
                                          f"{launches} launches per step)"),
                          "split": split_used, "launches_per_step": launches,
                          "achieved": round(achieved, 3),
