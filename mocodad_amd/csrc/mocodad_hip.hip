@@ -2695,8 +2695,10 @@ struct TiledNet {
 #define MCD_X_FC32 16
 #endif
 __host__ __device__ constexpr int tl_fc(int TP) { return TP == 16 ? MCD_X_FC16 : TP == 24 ? MCD_X_FC24 : MCD_X_FC32; }
-__host__ __device__ constexpr int tl_ra_floats(int TP) {          // LDS work region: mix (32 channels x all frames + pad rows) | GEMM (z + x chunks)
-    return cmax((TP * 17 + 16) * 36, 2 * ceil16(tl_fc(TP) * 12) * 68);
+__host__ __device__ constexpr int tl_ra_floats(int TP) {
+    // LDS work region.  Layers: X (32 channels of all frames, + pad rows) and z (the same; half the frames at 17 joints);
+    // resamplers / layer 6: in + out chunks
+    return cmax(cmax((TP * 17 + 16 + TP * 17 / 2 + 16) * 36, 2 * (TP * 12 + 16) * 36), 2 * ceil16(tl_fc(TP) * 12) * 68);
 }
 __host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
 __host__ __device__ constexpr long long tl_slab_floats(int TP) {
@@ -2757,6 +2759,7 @@ struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's Q
     static constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
     static constexpr int UNITS = CB * NB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
     float tq[QC][NR], aop[QC][MT][KS];
+    // u: unit index in the flat list of CB x (NB * NQ) units (clamped: waves without a unit fetch the last one's)
     __device__ __forceinline__ void load(const float* tqd, const float* af, int u, int lane) {
         gfloat* tqd_g = as_global(tqd);
         gfloat* af_g = as_global(af);
@@ -2773,20 +2776,23 @@ struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's Q
     }
 };
 // `first`: the coefficients of the wave's first unit, fetched by the caller before it waited for X to land in LDS
-template <int CINV, int V, int TP, int NB, class Init, class Store>
+// NGRP > 1: only the output frames of frame group `grp` (the flat frame list cut in NGRP equal parts) -- the caller's z region
+// holds one group at a time
+template <int CINV, int V, int TP, int NB, int NGRP = 1, class Init, class Store>
 __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP, NB>& first,
                                          const float* __restrict__ tqd, const float* __restrict__ af,
-                                         int wave, int lane, Init&& init, Store&& store) {
+                                         int wave, int lane, Init&& init, Store&& store, int grp = 0) {
     using MC = MixLongCoef<CINV, V, TP, NB>;
     constexpr int QC = MC::QC, KS = MC::KS, KP = 2 * (KS / 2), MT = MC::MT, CB = MC::CB, NQ = MC::NQ;
-    constexpr int UNITS = MC::UNITS, PER = MC::PER;
+    static_assert((NB * NQ) % NGRP == 0, "frame groups hold whole mix units");
+    constexpr int UNITS = MC::UNITS / NGRP, PER = (UNITS + NWAVES - 1) / NWAVES;
     constexpr bool J16 = V == 17;
     constexpr int MTM = J16 ? 1 : MT;
     const int j = lane & 15, g = lane >> 4;
     static_for<PER>([&](auto rr) {
         constexpr int rnd = decltype(rr)::value;
-        const int u = wave + rnd * NWAVES;
-        if (u >= UNITS) return;
+        if (wave + rnd * NWAVES >= UNITS) return;
+        const int u = wave + rnd * NWAVES + (NGRP > 1 ? grp * UNITS : 0);
         // (q0: first output frame of the unit in the flat list of NB * TP frames; its chain's frames start at row fo * V)
         const int cb = u % CB, qg = u / CB, fo = NB > 1 ? (qg / NQ) * TP : 0, q0 = fo + (qg % NQ) * QC;
         MC later;
@@ -2844,6 +2850,61 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
                 if (g == 0) store(q0 + qi, 16, cb * 16 + j, z16 + init(q0 + qi, 16, cb * 16 + j));
             }
         }
+    });
+}
+
+// partial channel GEMM of a layer of the slab-tiled kernel: acc[i] += A[O1 ..] . B1 (+ A[O2 ..] . B2) over this wave's n-tiles
+// (Tiling<MT, NT>), K = 16 KQ1 (+ 16 KQ2) channels of the LDS operands b1 / b2 ([col][ch]); two tiles' MFMA chains in flight
+// with their B fragments one read ahead, as in gemm_tiles.  The accumulators stay with the caller: a layer with 64 or 128
+// input channels sums its 32-channel halves into them and runs its epilogue once.
+template <int MT, int NT, int KQ1, int KQ2, int O1, int O2, int NA>
+__device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __restrict__ b1, int cs1, const float* __restrict__ b2,
+                                          int cs2, int wave, int lane, f32x4 (&acc)[Tiling<MT, NT>::MAXN]) {
+    constexpr int NG = Tiling<MT, NT>::NG, MAXN = Tiling<MT, NT>::MAXN, KQ = KQ1 + KQ2;
+    const int ng = MT > NWAVES ? 0 : wave / MT;
+    const int j = lane & 15, g = lane >> 4;
+    const float* const p1b = b1 + __mul24(ng * 16 + j, cs1) + 4 * g;
+    const float* const p2b = b2 + __mul24(ng * 16 + j, cs2) + 4 * g;
+    auto chain = [&](auto nn, auto ia, auto ib) {
+        constexpr int N = decltype(nn)::value, i0 = decltype(ia)::value, i1 = decltype(ib)::value;
+        const float* p1[2] = {p1b + i0 * NG * 16 * cs1, p1b + i1 * NG * 16 * cs1};
+        const float* p2[2] = {p2b + i0 * NG * 16 * cs2, p2b + i1 * NG * 16 * cs2};
+        auto rd = [&](int h, auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            return *reinterpret_cast<const float4*>(kq < KQ1 ? p1[h] + kq * 16 : p2[h] + (kq - KQ1) * 16);
+        };
+        float4 nxt[2];
+#pragma unroll
+        for (int h = 0; h < N; ++h) nxt[h] = rd(h, std::integral_constant<int, 0>{});
+        static_for<KQ>([&](auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            const float4 w = a[kq < KQ1 ? O1 + kq : O2 + kq - KQ1];
+            float4 u[2];
+#pragma unroll
+            for (int h = 0; h < N; ++h) u[h] = nxt[h];
+            if constexpr (kq + 1 < KQ) {
+#pragma unroll
+                for (int h = 0; h < N; ++h) nxt[h] = rd(h, std::integral_constant<int, kq + 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4& c0 = acc[i0];
+            f32x4& c1 = acc[i1];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[0].x, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[1].x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, u[0].y, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, u[1].y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, u[0].z, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, u[1].z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, u[0].w, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, u[1].w, c1, 0, 0, 0);
+        });
+    };
+    static_for<(MAXN + 1) / 2>([&](auto pp) {
+        constexpr int i0 = 2 * decltype(pp)::value, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
+        using I0 = std::integral_constant<int, i0>;
+        using I1 = std::integral_constant<int, i1>;
+        if (i1 != i0 && ng + i1 * NG < NT) chain(std::integral_constant<int, 2>{}, I0{}, I1{});
+        else if (ng + i0 * NG < NT) chain(std::integral_constant<int, 1>{}, I0{}, I0{});
     });
 }
 
@@ -2985,71 +3046,108 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             }
             __syncthreads();
 
-            // ---- one mix-first ST-GCN layer: xin (slab or XT) -> xout (slab)
+            // ---- one mix-first ST-GCN layer: xin (slab or XT) -> xout (slab).  Per 32-channel half of the input: X of ALL frames
+            // -> LDS, mix -> z in LDS (never in the slab), the half's share of the channel GEMM into register accumulators
+            // (z . W_t and x . W_r / + x); epilogue -> slab after the last half.  The layers at 17 joints (one half) take their
+            // frames in two groups, z holding one group at a time.
             auto layer = [&](auto lc, const float* xin, bool xin_lds, float* xout) {
                 constexpr int L = decltype(lc)::value;
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
-                constexpr int CSX = L == 0 ? 4 : CSI;            // layer 0 reads the chain state in place (see score_kernel)
-                constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSV = L == 0 ? 4 : cs_of(CINV);
-                constexpr int ROWS = TF * V, CROWS = TL_FC * V, CPAD = ceil16(CROWS);
+                constexpr bool RES = D.res != 0;
+                constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSZ = cs_of(CINV);
+                constexpr int CSV = L == 0 ? 4 : CSZ;            // layer 0 reads the chain state in place (see score_kernel)
+                constexpr int ROWS = TF * V, FS = V == 17 ? 2 : 1, ROWSG = ROWS / FS;
+                static_assert(FS == 1 || NH == 1, "frame groups and channel halves are not combined");
+                static_assert(COUT % 16 == 0 && ROWSG % (NB > 1 ? 1 : 1) == 0, "");
+                constexpr int MT = COUT / 16, NT = ceil16(ROWSG) / 16, KH = CINV / 16;
+                using TI = Tiling<MT, NT>;
+                using MC = MixLongCoef<CINV, V, TP, NB>;
+                constexpr int UG = MC::UNITS / FS;               // mix units per frame group
                 // (thread / wave ids opaque per LAYER: the per-lane addresses of a layer's copies and tiles are invariant across
-                // its chunk loops, and hoisted to the top of the pass for all eleven layers at once they spill)
+                // its loops, and hoisted to the top of the pass for all eleven layers at once they spill)
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                // mix: 32 channels of all frames at a time (the next 32 on their way while these are mixed)
+                float* const XA = RA;                                          // [ROWS + 16][CSZ]
+                float* const ZA = xin_lds ? RA : RA + (ROWS + 16) * CSZ;       // [ROWSG + 16][CSZ]
                 TlStage<ROWS, CINV> sx;
                 if (!xin_lds) sx.issue(tid, xin, CSI, 0);
-                MixLongCoef<CINV, V, TP, NB> mc;
+                MC mc;
                 mc.load(wb + N.tq[L], wb + N.am[L], wave, lane);
-                for (int h = 0; h < NH; ++h) {
-                    const float* Xl = xin;
-                    if (!xin_lds) {
-                        __syncthreads();
-                        sx.commit(tid, RA, CSV);
-                        __syncthreads();
-                        if (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
-                        Xl = RA;
-                    }
-                    float* zg = Zg + h * CINV;
-                    mix_long<CINV, V, TP, NB>(Xl, CSV, mc, wb + N.tq[L], wb + N.am[L], wave, lane, ZeroInitL{},
-                                          [&](int q, int w0, int c, auto v) {
-                                              float* zp = zg + (size_t)(q * V + w0) * CSI + c;
-                                              if constexpr (std::is_same_v<decltype(v), f32x4>) {
-#pragma unroll
-                                                  for (int r = 0; r < 4; ++r)
-                                                      if (w0 + r < V) zp[r * CSI] = v[r];
-                                              } else {
-                                                  *zp = v;
-                                              }
-                                          });
-                }
-                // GEMM + epilogue per chunk of 8 frames
-                LayerAfr<(CIN / 16) * (D.res ? 2 : 1)> A;
+                LayerAfr<(CIN / 16) * (RES ? 2 : 1)> A;
                 {
                     LayerW lw;
                     lw.wp = N.wp[L]; lw.bias = N.bias[L];
-                    A.template load<ceil16(COUT) / 16>(wb, lw, wave, lane);
+                    A.template load<MT>(wb, lw, wave, lane);
                 }
-                float* const zc = RA;
-                float* const xc = RA + CPAD * CSI;
-                TlStage<CPAD, CIN> sz, sxc;           // the next chunk's z / x rows ride in registers behind this chunk's GEMM
-                __syncthreads();                       // (every wave's z stores of the mix above are complete)
-                sz.issue(tid, Zg, CSI, 0);
-                if (!xin_lds) sxc.issue(tid, xin, CSI, 0);
-                for (int fc = 0; fc < NFC; ++fc) {
-                    __syncthreads();
-                    sz.commit(tid, zc, CSI);
-                    if (!xin_lds) sxc.commit(tid, xc, CSI);
-                    __syncthreads();
-                    if (fc + 1 < NFC) {
-                        sz.issue(tid, Zg + (size_t)(fc + 1) * CROWS * CSI, CSI, 0);
-                        if (!xin_lds) sxc.issue(tid, xin + (size_t)(fc + 1) * CROWS * CSI, CSI, 0);
+                const float slope = N.slope[L], pinf = prelu_bound(slope);
+                const int mt = wave % MT, ng = MT > NWAVES ? 0 : wave / MT, c0 = mt * 16 + 4 * (lane >> 4);
+                f32x4 acc[TI::MAXN];
+                static_for<NH>([&](auto hh) {
+                    constexpr int h = decltype(hh)::value;
+                    const float* Xl = xin;
+                    if (!xin_lds) {
+                        __syncthreads();                  // (the previous stage / half is done with XA)
+                        sx.commit(tid, XA, CSV);
+                        if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
+                        Xl = XA;
                     }
-                    const float* xs = xin_lds ? xin + fc * CROWS * CSX : xc;
-                    tl_gemm<CIN, COUT, CROWS, D.res != 0, CSX>(A, N.slope[L], zc, xs, xout + (size_t)fc * CROWS * CSO, EMB + (fc * TL_FC / TP) * EMBS + emb_off(L), wave, lane);
-                }
+                    if constexpr (h > 0) mc.load(wb + N.tq[L], wb + N.am[L], wave, lane);
+                    __syncthreads();
+#pragma unroll
+                    for (int fg = 0; fg < FS; ++fg) {
+                        if (fg > 0) mc.load(wb + N.tq[L], wb + N.am[L], wave + fg * UG, lane);
+                        mix_long<CINV, V, TP, NB, FS>(Xl, CSV, mc, wb + N.tq[L] , wb + N.am[L], wave, lane, ZeroInitL{},
+                                                      [&](int q, int w0, int c, auto v) {
+                                                          float* zp = ZA + ((q - fg * (TF / FS)) * V + w0) * CSZ + c;
+                                                          if constexpr (std::is_same_v<decltype(v), f32x4>) {
+#pragma unroll
+                                                              for (int r = 0; r < 4; ++r)
+                                                                  if (w0 + r < V) zp[r * CSZ] = v[r];
+                                                          } else {
+                                                              *zp = v;
+                                                          }
+                                                      }, fg);
+                        __syncthreads();
+                        const float* xg = Xl + fg * ROWSG * CSV;
+                        if (h == 0) {
+#pragma unroll
+                            for (int i = 0; i < TI::MAXN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
+                        else gemm_part<MT, NT, KH, 0, h * KH, 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
+                        if constexpr (!RES) {             // identity residual: the tile's own 4 channels of x, when they lie in this half
+                            if ((mt * 16) / CINV == h) {
+                                const float* xr = xg + __mul24(ng * 16 + (lane & 15), CSV) + c0 - h * CINV;
+                                static_for<TI::MAXN>([&](auto ii) {
+                                    constexpr int i = decltype(ii)::value;
+                                    if (ng + i * TI::NG < NT) {
+                                        const float4 r = *reinterpret_cast<const float4*>(xr + i * TI::NG * 16 * CSV);
+                                        acc[i] += f32x4{r.x, r.y, r.z, r.w};
+                                    }
+                                });
+                            }
+                        }
+                        if constexpr (h == NH - 1) {      // epilogue: bias, PReLU, embedding -> slab
+                            const float4 bcur = A.bcur;
+                            static_for<TI::MAXN>([&](auto ii) {
+                                constexpr int i = decltype(ii)::value;
+                                const int col = ng * 16 + (lane & 15) + i * TI::NG * 16;
+                                if (ng + i * TI::NG < NT && col < ROWSG) {
+                                    const int gcol = fg * ROWSG + col;
+                                    const float4 e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
+                                    const f32x2 t0 = f32x2{acc[i][0] + bcur.x, acc[i][1] + bcur.y}, t1 = f32x2{acc[i][2] + bcur.z, acc[i][3] + bcur.w};
+                                    const f32x2 m0 = t0 * slope, m1 = t1 * slope;
+                                    *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) =
+                                        make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
+                                                    __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
+                                }
+                            });
+                        }
+                        if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
+                    }
+                });
                 __syncthreads();
             };
             // ---- one joint resampler: xin (slab, C channels at VIN joints) -> xout (+ skip), per chunk of 8 frames
