@@ -2680,6 +2680,7 @@ __global__ __launch_bounds__(GEN_THREADS) void score_generic_kernel(const ScoreP
 // ------------------------------------------------------------------------------------------------
 struct TiledNet {
     int tq[NLAYERS], am[NLAYERS], wp[NLAYERS], bias[NLAYERS];
+    int tqm[NLAYERS];    // time-mix coefficients as MFMA A fragments (tl_time_mix): [joint][frame tile][k-step][lane]
     float slope[NLAYERS];
     int rsw[4];          // joint resamplers, non-capture fragment packs (RsCoef chunks: fragments then bias)
     int we, be;
@@ -2853,6 +2854,150 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
     });
 }
 
+// The two halves of a layer's mix in the slab-tiled kernel, both on the matrix cores (at 16 .. 32 frames the time mix is a third
+// of the layer's multiply-adds: as DPP FMAs it was 40 % of the kernel).
+// (1) time mix  Y[q][v][c] = sum_t Tq[q][v][t] X[t][v][c]: per (joint v, 16-channel block, tile of 16 output frames) one
+//     (16 frames x TP frames) . (TP frames x 16 channels) product; A = the pre-packed Tq fragments (tl_tqm_floats), B = X read from
+//     LDS with the frame index on the k axis; the result rows (frames) go to Y[(frame * V + v)][channel] in LDS.
+// (2) joint mix, in place  Z[q][w][c] = sum_v A_q[v][w] Y[q][v][c]: per (frame, 16-channel block) the fragments of mix_stage,
+//     B = Y read from LDS; a unit has read all of its frame's Y when it writes Z over it.
+// NGRP: frame groups of the layer (the flat list of NB * TP frames in NGRP equal parts; Y / Z hold group `grp`).
+template <int TP, int NB, int NGRP>
+struct TlGroups {
+    static constexpr int FG = NB * TP / NGRP;                   // frames of a group
+    static constexpr int NCH = NB >= NGRP ? NB / NGRP : 1;      // chains a group spans
+    static constexpr int FGC = FG / NCH;                        // frames of a group in one chain
+    static constexpr int MTG = (FGC + 15) / 16;                 // 16-frame tiles of a group per chain
+    static constexpr int NTC = MTG * (TP / FGC);                // ... of a chain (table rows)
+    static constexpr int KT = TP / 4;
+};
+__host__ __device__ constexpr int tl_ngrp(int V) { return V == 17 ? 2 : 1; }
+// A unit of (1) is (joint v, chain of the group, frame tile): its Tq fragments serve all 16-channel blocks, and the next unit's
+// are fetched (L2) while this one runs; a unit of (2) is a frame, likewise.
+// (the FIRST unit's fragments come from the caller, who fetched them -- tl_time_fetch / tl_joint_fetch -- a stage earlier)
+// unit -> (v, tile, chain of the group): v fastest, so that the waves of a round read neighbouring rows
+template <int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_time_fetch(float (&a)[TP / 4], const float* __restrict__ tqm, int u, int lane, int grp) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int UNITS = V * G::NCH * G::MTG;
+    if (u >= UNITS) u = UNITS - 1;
+    const int v = u % V, m = (u / V) % G::MTG;
+    gfloat* ap = as_global(tqm) + ((v * G::NTC + (NB >= NGRP ? 0 : grp * G::MTG) + m) * G::KT) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < G::KT; ++ks) a[ks] = ap[ks * 64];
+}
+template <int CINV, int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_time_mix(const float* __restrict__ X, int cs, float* __restrict__ Y, int csy,
+                                            const float* __restrict__ tqm, int wave, int lane, int grp, const float (&first)[TP / 4]) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int CB = CINV / 16, KT = G::KT, UNITS = V * G::NCH * G::MTG;
+    constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;
+    const int j = lane & 15, g = lane >> 4;
+    float a[2][KT];
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) a[0][ks] = first[ks];
+    static_for<PER>([&](auto rr) {
+        constexpr int rnd = decltype(rr)::value;
+        const int u = wave + rnd * NWAVES;
+        if (u >= UNITS) return;
+        if constexpr (rnd + 1 < PER) { if (u + NWAVES < UNITS) tl_time_fetch<V, TP, NB, NGRP>(a[(rnd + 1) & 1], tqm, u + NWAVES, lane, grp); }
+        const int v = u % V, m = (u / V) % G::MTG, ch = u / (V * G::MTG);
+        const int chain = NB >= NGRP ? grp * G::NCH + ch : 0;                    // chain of the flat frame list
+        const float* xp = X + __mul24((chain * TP + g) * V + v, cs) + j;
+        float b[CB][KT];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) b[cb][ks] = xp[ks * 4 * V * cs + cb * 16];
+        f32x4 acc[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rnd & 1][ks], b[cb][ks], acc[cb], 0, 0, 0);
+        const int fl = ch * G::FGC + m * 16 + 4 * g;                  // first of the lane's 4 output frames, group-local
+        float* yp = Y + __mul24(fl * V + v, csy) + j;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (G::FGC % 16 == 0 || m * 16 + 4 * g + r < G::FGC) yp[r * V * csy + cb * 16] = acc[cb][r];
+    });
+}
+template <int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_joint_fetch(float (&aop)[(V + 15) / 16][(V + 3) / 4], const float* __restrict__ af, int fl, int lane, int grp) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int KS = (V + 3) / 4, MT = (V + 15) / 16;
+    if (fl >= G::FG) fl = G::FG - 1;
+    const int q = (grp * G::FG + fl) % TP;               // the frame in its chain (the coefficient tables are per chain)
+    gfloat* af_g = as_global(af);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) aop[mt][ks] = af_g[((q * MT + mt) * KS + ks) * 64 + lane];
+}
+template <int CINV, int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_joint_mix(float* __restrict__ YZ, int cs, const float* __restrict__ af, int wave, int lane, int grp,
+                                             const float (&first)[(V + 15) / 16][(V + 3) / 4]) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int CB = CINV / 16, KS = (V + 3) / 4, KP = 2 * (KS / 2), MT = (V + 15) / 16;
+    constexpr bool J16 = V == 17;
+    constexpr int MTM = J16 ? 1 : MT;
+    constexpr int UNITS = G::FG, PER = (UNITS + NWAVES - 1) / NWAVES;
+    const int j = lane & 15, g = lane >> 4;
+    const int vp = 4 * (g & 1) + (g >> 1);              // mix_vmap: joint of this lane group in a paired k-step
+    float aop[2][MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) aop[0][mt][ks] = first[mt][ks];
+    static_for<PER>([&](auto rr) {
+        constexpr int rnd = decltype(rr)::value;
+        const int fl = wave + rnd * NWAVES;              // frame of the group
+        if (fl >= UNITS) return;
+        if constexpr (rnd + 1 < PER) { if (fl + NWAVES < UNITS) tl_joint_fetch<V, TP, NB, NGRP>(aop[(rnd + 1) & 1], af, fl + NWAVES, lane, grp); }
+        float* base = YZ + __mul24(fl * V, cs) + j;
+        float y[CB][KS];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) y[cb][ks] = base[(ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + vp : 4 * KP + g) * cs + cb * 16];
+        f32x4 acc[CB][MTM];
+        float part[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            part[cb] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt) acc[cb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                for (int mt = 0; mt < MTM; ++mt)
+                    acc[cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[rnd & 1][mt][ks], y[cb][ks], acc[cb][mt], 0, 0, 0);
+                if constexpr (J16) part[cb] = fmaf(aop[rnd & 1][1][ks], y[cb][ks], part[cb]);
+            }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mt * 16 + 4 * g + r < V) base[(mt * 16 + 4 * g + r) * cs + cb * 16] = acc[cb][mt][r];
+            if constexpr (J16) {      // joint 16: the four lane groups' partial sums (see mix_long)
+                const unsigned pu = __float_as_uint(part[cb]);
+                const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                if (g == 0) base[16 * cs + cb * 16] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+            }
+        }
+    });
+}
+
 // partial channel GEMM of a layer of the slab-tiled kernel: acc[i] += A[O1 ..] . B1 (+ A[O2 ..] . B2) over this wave's n-tiles
 // (Tiling<MT, NT>), K = 16 KQ1 (+ 16 KQ2) channels of the LDS operands b1 / b2 ([col][ch]); two tiles' MFMA chains in flight
 // with their B fragments one read ahead, as in gemm_tiles.  The accumulators stay with the caller: a layer with 64 or 128
@@ -2935,6 +3080,14 @@ __device__ __forceinline__ void tl_gemm(const AF& A, float slope, const float* _
 // NB chains of TP (padded) frames each per workgroup, laid out as one flat list of TF = NB * TP frames: the channel GEMMs, the
 // resamplers and the slab copies see TF frames; the time mix stays inside a chain (mix_long's units).  <16, 2> gives the
 // 13 .. 16-frame shapes the stage lengths (and the matrix-pipe fill per barrier) of the 32-frame shape.
+// profile builds (tools/tiled_stage_profile.py): thread 0 of workgroup 0 adds the cycles since its previous mark to slot
+// 2048 + id of the profile buffer
+#ifdef MCD_PROFILE
+#define TLMARK(id) do { if (tl_prof) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    atomicAdd(P.prof + 2048 + (id), t_ - tl_last); tl_last = t_; } } while (0)
+#else
+#define TLMARK(id) do { } while (0)
+#endif
 template <int TP, int NB>
 __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
@@ -2958,6 +3111,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
     int tid = tid0, lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* wb = P.wbuf;
+#ifdef MCD_PROFILE
+    const bool tl_prof = P.prof && blockIdx.x == 0 && tid0 == 0;
+    unsigned long long tl_last = __builtin_readcyclecounter();
+#endif
     float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TF);
     const int Tx = P.n_corrupt, K = P.ns > 2 ? P.ns - 1 : 1, per = C0 * Tx * 17;
     for (int u = tid; u < (int)tl_slab_floats(TF); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
@@ -3062,8 +3219,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 static_assert(COUT % 16 == 0 && ROWSG % (NB > 1 ? 1 : 1) == 0, "");
                 constexpr int MT = COUT / 16, NT = ceil16(ROWSG) / 16, KH = CINV / 16;
                 using TI = Tiling<MT, NT>;
-                using MC = MixLongCoef<CINV, V, TP, NB>;
-                constexpr int UG = MC::UNITS / FS;               // mix units per frame group
+                static_assert(FS == tl_ngrp(V), "the packed time-mix tiles follow the frame groups");
                 // (thread / wave ids opaque per LAYER: the per-lane addresses of a layer's copies and tiles are invariant across
                 // its loops, and hoisted to the top of the pass for all eleven layers at once they spill)
                 int tid = tid0;
@@ -3073,16 +3229,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 float* const ZA = xin_lds ? RA : RA + (ROWS + 16) * CSZ;       // [ROWSG + 16][CSZ]
                 TlStage<ROWS, CINV> sx;
                 if (!xin_lds) sx.issue(tid, xin, CSI, 0);
-                MC mc;
-                mc.load(wb + N.tq[L], wb + N.am[L], wave, lane);
-                LayerAfr<(CIN / 16) * (RES ? 2 : 1)> A;
-                {
+                float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
+                tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 0);
+                // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
+                constexpr bool AQ = NH > 2;
+                constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
+                const int mt = wave % MT, ng = MT > NWAVES ? 0 : wave / MT, c0 = mt * 16 + 4 * (lane >> 4);
+                LayerAfr<AQ ? 1 : KQA> A;
+                float4 aq[AQ ? 2 * KH : 1];
+                const float* wfr = wb + N.wp[L] + ((size_t)mt * KQA * 64 + lane) * 4;
+                if constexpr (!AQ) {
                     LayerW lw;
                     lw.wp = N.wp[L]; lw.bias = N.bias[L];
                     A.template load<MT>(wb, lw, wave, lane);
+                } else {
+                    A.bcur = load_global4(wb + N.bias[L] + c0);
                 }
                 const float slope = N.slope[L], pinf = prelu_bound(slope);
-                const int mt = wave % MT, ng = MT > NWAVES ? 0 : wave / MT, c0 = mt * 16 + 4 * (lane >> 4);
                 f32x4 acc[TI::MAXN];
                 static_for<NH>([&](auto hh) {
                     constexpr int h = decltype(hh)::value;
@@ -3093,29 +3256,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
                         Xl = XA;
                     }
-                    if constexpr (h > 0) mc.load(wb + N.tq[L], wb + N.am[L], wave, lane);
+                    if constexpr (AQ) {
+                        static_assert(!AQ || RES, "");
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) {
+                            aq[k] = load_global4(wfr + (h * KH + k) * 256);
+                            aq[KH + k] = load_global4(wfr + (CIN / 16 + h * KH + k) * 256);
+                        }
+                    }
                     __syncthreads();
+                    TLMARK(4 * L);
 #pragma unroll
                     for (int fg = 0; fg < FS; ++fg) {
-                        if (fg > 0) mc.load(wb + N.tq[L], wb + N.am[L], wave + fg * UG, lane);
-                        mix_long<CINV, V, TP, NB, FS>(Xl, CSV, mc, wb + N.tq[L] , wb + N.am[L], wave, lane, ZeroInitL{},
-                                                      [&](int q, int w0, int c, auto v) {
-                                                          float* zp = ZA + ((q - fg * (TF / FS)) * V + w0) * CSZ + c;
-                                                          if constexpr (std::is_same_v<decltype(v), f32x4>) {
-#pragma unroll
-                                                              for (int r = 0; r < 4; ++r)
-                                                                  if (w0 + r < V) zp[r * CSZ] = v[r];
-                                                          } else {
-                                                              *zp = v;
-                                                          }
-                                                      }, fg);
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, fg);
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, fg, tqa);
+                        if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
                         __syncthreads();
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, fg, aja);
+                        TLMARK(4 * L + 1);
+                        __syncthreads();
+                        TLMARK(4 * L + 2);
                         const float* xg = Xl + fg * ROWSG * CSV;
                         if (h == 0) {
 #pragma unroll
                             for (int i = 0; i < TI::MAXN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                        if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
+                        if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH>(aq, ZA, CSZ, xg, CSV, wave, lane, acc);
+                        else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
                         else gemm_part<MT, NT, KH, 0, h * KH, 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
                         if constexpr (!RES) {             // identity residual: the tile's own 4 channels of x, when they lie in this half
                             if ((mt * 16) / CINV == h) {
@@ -3146,6 +3313,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                             });
                         }
                         if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
+                        TLMARK(4 * L + 3);
                     }
                 });
                 __syncthreads();
@@ -3176,72 +3344,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 __syncthreads();
             };
 #define TL_C(x) std::integral_constant<int, x>{}
+            TLMARK(60);                                                     // pass prologue (noise, embeddings)
             layer(TL_C(0), XT, true, A0);
             layer(TL_C(1), A0, false, A1);
             layer(TL_C(2), A1, false, D1);                                  // -> d1
+            TLMARK(61);
             resample(TL_C(32), TL_C(17), TL_C(12), 0, D1, A0, nullptr);     // down1
+            TLMARK(48);
             layer(TL_C(3), A0, false, A1);
             layer(TL_C(4), A1, false, D2);                                  // -> d2
+            TLMARK(61);
             resample(TL_C(64), TL_C(12), TL_C(10), 1, D2, A0, nullptr);     // down2
+            TLMARK(49);
             layer(TL_C(5), A0, false, A1);                                  // 64 -> 128
-            {   // ---- layer 6 (128 -> 64) W-first: P = [W_t; W_r] x per chunk -> A0 (rows x 132: P_t | P_r), then the mix on P_t
-                constexpr int CROWS = TL_FC * 10;
-                int tid = tid0;
-                asm volatile("" : "+v"(tid));
-                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                LayerAfr<8> A;
-                { LayerW lw; lw.wp = N.wp[6]; lw.bias = N.bias[6]; A.template load<8>(wb, lw, wave, lane); }
-                auto epi6 = [&](float* pg) {
-                    return [pg](auto, int col, int c0, f32x4 acc, int, int) {
-                        if (col < CROWS) *reinterpret_cast<float4*>(pg + (size_t)col * 132 + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                    };
-                };
-                constexpr int CPAD6 = ceil16(CROWS);
-                TlStage<CPAD6, 128> s5;
-                s5.issue(tid, A1, 132, 0);
-                for (int fc = 0; fc < NFC; ++fc) {
-                    __syncthreads();
-                    s5.commit(tid, RA, 132);
-                    __syncthreads();
-                    if (fc + 1 < NFC) s5.issue(tid, A1 + (size_t)(fc + 1) * CROWS * 132, 132, 0);
-                    gemm_tiles<8, CPAD6 / 16, 8, 0, false, true>(A.a, RA, 132, RA, 132, wave, lane, epi6(A0 + (size_t)fc * CROWS * 132), 0);
-                }
-                const float slope6 = N.slope[6], pinf6 = prelu_bound(slope6);
-                TlStage<R10, 32> sp;
-                __syncthreads();                       // (phase A's P stores are complete)
-                sp.issue(tid, A0, 132, 0);
-                MixLongCoef<32, 10, TP, NB> mc6;
-                mc6.load(wb + N.tq[6], wb + N.am[6], wave, lane);
-                for (int h = 0; h < 2; ++h) {
-                    __syncthreads();
-                    sp.commit(tid, RA, 36);
-                    __syncthreads();
-                    if (h == 0) sp.issue(tid, A0, 132, 32);
-                    const float* pr = A0 + 64 + h * 32;
-                    float* og = A1 + h * 32;              // out6 (64 ch, stride 68) over the dead layer-5 output
-                    const float* bias = wb + N.bias[6] + h * 32;
-                    const float* e6 = EMB + emb_off(6) + h * 32;
-                    mix_long<32, 10, TP, NB>(RA, 36, mc6, wb + N.tq[6], wb + N.am[6], wave, lane,
-                                         [&](int q, int w0, int c, std::true_type) {
-                                             const float* pp = pr + (size_t)(q * 10 + w0) * 132 + c;
-                                             return f32x4{pp[0], pp[132], pp[264], pp[396]};          // (rows >= 10 of the fragment: next frame's, never stored)
-                                         },
-                                         [&](int q, int w0, int c, f32x4 v) {
-                                             const float bb = bias[c], ee = e6[(NB > 1 ? (q / TP) * EMBS : 0) + c];
-                                             float* op = og + (size_t)(q * 10 + w0) * 68 + c;
-#pragma unroll
-                                             for (int r = 0; r < 4; ++r)
-                                                 if (w0 + r < 10) op[r * 68] = __builtin_amdgcn_fmed3f(v[r] + bb, (v[r] + bb) * slope6, pinf6) + ee;
-                                         });
-                }
-                __syncthreads();
-            }
-            // (the layer-6 output was written with row stride 68 into A1; the P rows of A0 are dead)
-            resample(TL_C(64), TL_C(10), TL_C(12), 2, A1, A0, D2);          // up3 + d2
-            layer(TL_C(7), A0, false, A1);
-            layer(TL_C(8), A1, false, A0);
-            resample(TL_C(32), TL_C(12), TL_C(17), 3, A0, A1, D1);          // up2 + d1
-            layer(TL_C(9), A1, false, A0);
+            TLMARK(61);
+            layer(TL_C(6), A1, false, A0);                                  // 128 -> 64, mix-first here (four 32-channel quarters)
+            TLMARK(61);
+            resample(TL_C(64), TL_C(10), TL_C(12), 2, A0, A1, D2);          // up3 + d2
+            TLMARK(50);
+            layer(TL_C(7), A1, false, A0);
+            layer(TL_C(8), A0, false, A1);
+            TLMARK(61);
+            resample(TL_C(32), TL_C(12), TL_C(17), 3, A1, A0, D1);          // up2 + d1
+            TLMARK(51);
+            layer(TL_C(9), A0, false, A1);
+            TLMARK(61);
             {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
@@ -3249,7 +3376,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 const float* w4 = wb + N.wp[10];
                 for (int u = tid; u < R17 * 4; u += NTHREADS) {
                     const int col = u >> 2, r = u & 3;
-                    const float* xp = A0 + (size_t)col * 36;
+                    const float* xp = A1 + (size_t)col * 36;
                     float a = 0.f;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -3304,6 +3431,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
                     if (dst[it] >= 0) XT[dst[it]] = xn[it];
+                TLMARK(54);                            // layer 10 + DDPM update
             }
         }
         __syncthreads();
@@ -3579,6 +3707,19 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
         }
     }
     return true;
+}
+
+// time-mix coefficients of one layer as the A fragments of tl_time_mix: [joint v][frame tile of a chain][k-step][lane], lane
+// (i, g) = gcn.T[v][t = 4 ks + g][q], q = row i of the tile (tiles follow the layer's frame groups, TlGroups)
+int pack_time_mfma(const float* Tm, int T, int V, int TP, int NB, Builder& B) {
+    const int ngrp = tl_ngrp(V), nch = NB >= ngrp ? NB / ngrp : 1, fgc = NB * TP / ngrp / nch;
+    const int mtg = (fgc + 15) / 16, ntc = mtg * (TP / fgc), kt = TP / 4;
+    const int off = B.alloc((size_t)V * ntc * kt * 64);
+    for (int v = 0; v < V; ++v) for (int tile = 0; tile < ntc; ++tile) for (int ks = 0; ks < kt; ++ks) for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, g = lane >> 4, t = 4 * ks + g, r = (tile % mtg) * 16 + i, q = (tile / mtg) * fgc + r;
+        B.buf[off + ((size_t)(v * ntc + tile) * kt + ks) * 64 + lane] = (r < fgc && q < T && t < T) ? Tm[((size_t)v * T + t) * T + q] : 0.f;
+    }
+    return off;
 }
 
 // MFMA A-operand fragment order of a logical [M][K] matrix (M, K multiples of 16) with the K permutation that lets
@@ -4020,7 +4161,16 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         for (int l = 0; l < NLAYERS; ++l) {
             const LDesc D = layer_desc(l);
             if (!pack_mix_mfma(tm, std::string("model.") + names[l], T, D.V, B, TN.tq[l], TN.am[l], tiled_tp)) return fail(MCD_EMISSING, tm.missing);
+            TN.tqm[l] = pack_time_mfma(tm.get(std::string("model.") + names[l] + ".gcn.T", (int64_t)D.V * T * T), T, D.V, tiled_tp, tl_nb(tiled_tp), B);
             TN.wp[l] = U.L[l].wp; TN.bias[l] = U.L[l].bias; TN.slope[l] = U.L[l].slope;
+            if (l == 6) {    // this kernel runs layer 6 mix-first like the others: [W_t' | W_r'] fragments (the specialised kernels' are W-first)
+                Folded ft, fr;
+                const std::string p6 = std::string("model.") + names[l];
+                if (!fold_conv_bn(tm, p6 + ".tcn.0", p6 + ".tcn.1", D.cout, D.cin, ft) || !fold_conv_bn(tm, p6 + ".residual.0", p6 + ".residual.1", D.cout, D.cin, fr))
+                    return fail(MCD_EMISSING, tm.missing);
+                TN.wp[l] = pack_gemm_frags(B, D.cout, 2 * D.cin, [&](int r, int k) -> double {
+                    return k < D.cin ? ft.w[(size_t)r * D.cin + k] : fr.w[(size_t)r * D.cin + k - D.cin]; });
+            }
         }
         for (int r = 0; r < 4; ++r) {
             Folded f;

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-stage cycle breakdown of workgroup 0 of score_tiled_kernel (needs a -DMCD_PROFILE build: MCD_PROF_LIB or
+mocodad_amd/libmocodad_hip_prof.so).   usage (GPU box): python tools/tiled_stage_profile.py [config]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from mocodad_amd import _lib
+_lib.LIB_PATH = os.environ.get("MCD_PROF_LIB") or os.path.join(ROOT, "mocodad_amd", "libmocodad_hip_prof.so")
+import bench
+from mocodad_amd.engine import HipScorer
+
+CONFIG = sys.argv[1] if len(sys.argv) > 1 else "concat32"
+variant_w, B, NS, S, _ = bench.CONFIGS[CONFIG]
+sd, cfg = bench.load_weights(variant_w)
+ci, xi = bench.frame_split(cfg["seg_len"], cfg["conditioning_indices"], cfg["conditioning_strategy"])
+sc = HipScorer(sd, strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"], cond_idx=ci, corrupt_idx=xi,
+               cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+L = _lib.lib()
+prof = torch.zeros(4096, dtype=torch.int64, device="cuda:0")
+data = bench.synth_windows(B, cfg["seg_len"], 1).cuda()
+sc.score(data, n_samples=S, noise_steps=NS, seed=1)
+torch.cuda.synchronize()
+L.mcd_debug_set_prof(C.c_void_p(prof.data_ptr()))
+sc.score(data, n_samples=S, noise_steps=NS, seed=1)
+torch.cuda.synchronize()
+L.mcd_debug_set_prof(None)
+p = prof.cpu().numpy().astype(float)[2048:2048 + 64]
+tot = p.sum()
+chains = -(-B * S // 256)          # chains (or chain pairs) workgroup 0 ran: the grid is one workgroup per CU
+print(f"{CONFIG}: T_u={sc.t_unet}  workgroup 0: {tot:.0f} cycles over the launch, {tot / 2.4e6:.2f} ms at 2.4 GHz")
+lname = ["L0", "L1", "L2", "L3", "L4", "L5", "L6", "L7", "L8", "L9"]      # (a layer's row sums its 32-channel parts and frame groups)
+print("  layer     X wait       mix   barrier  gemm+epi   (% of the launch)")
+for l in range(10):
+    v = p[4 * l:4 * l + 4]
+    print(f"  {lname[l]:4s} {v[0]:10.0f} {v[1]:9.0f} {v[2]:9.0f} {v[3]:9.0f}   {100 * v.sum() / tot:5.1f}%")
+for i, n in [(54, "L10 + update"), (48, "down1"), (49, "down2"), (50, "up3 + d2"), (51, "up2 + d1"),
+             (60, "pass prologue"), (61, "layer tails")]:
+    print(f"  {n:14s} {p[i]:12.0f}   {100 * p[i] / tot:5.1f}%")
