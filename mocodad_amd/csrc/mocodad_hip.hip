@@ -3207,8 +3207,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             // -> LDS, mix -> z in LDS (never in the slab), the half's share of the channel GEMM into register accumulators
             // (z . W_t and x . W_r / + x); epilogue -> slab after the last half.  The layers at 17 joints (one half) take their
             // frames in two groups, z holding one group at a time.
-            auto layer = [&](auto lc, const float* xin, bool xin_lds, float* xout) {
-                constexpr int L = decltype(lc)::value;
+            // RSI >= 0: the layer's input is joint resampler RSI applied to `xin` (+ `skip`): each 32-channel part of X is built in
+            // LDS from the resampler's input rows, chunk of frames by chunk -- the resampled tensor never exists in the slab
+            auto layer = [&](auto lc, auto rsc, const float* xin, bool xin_lds, float* xout, const float* skip) {
+                constexpr int L = decltype(lc)::value, RSI = decltype(rsc)::value;
+                constexpr int VIN = RSI == 0 ? 17 : RSI == 2 ? 10 : 12;      // joints of the resampler's input (down1, down2, up3, up2)
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
@@ -3227,8 +3230,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
                 float* const XA = RA;                                          // [ROWS + 16][CSZ]
                 float* const ZA = xin_lds ? RA : RA + (ROWS + 16) * CSZ;       // [ROWSG + 16][CSZ]
-                TlStage<ROWS, CINV> sx;
-                if (!xin_lds) sx.issue(tid, xin, CSI, 0);
+                TlStage<ROWS, CINV> sx;                // plain input: a 32-channel part of all frames; resampled input: the skip rows
+                constexpr int IR = TL_FC * VIN, OR = TL_FC * V;
+                TlStage<RSI >= 0 ? IR : 1, 32> si;     // resampled input: a chunk of the resampler's input rows
+                RsCoef<32, VIN, V, TL_FC, 1, false> rc;
+                if constexpr (RSI >= 0) {
+                    si.issue(tid, xin, CSI, 0);
+                    rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                    if (skip) sx.issue(tid, skip, CSI, 0);
+                } else if (!xin_lds) {
+                    sx.issue(tid, xin, CSI, 0);
+                }
                 float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
                 tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 0);
                 // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
@@ -3250,7 +3262,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 static_for<NH>([&](auto hh) {
                     constexpr int h = decltype(hh)::value;
                     const float* Xl = xin;
-                    if (!xin_lds) {
+                    if constexpr (RSI >= 0) {
+                        static_assert(RSI < 0 || (CINV == 32 && L != 0), "");
+                        float nosk[1] = {0.f};
+#pragma unroll
+                        for (int fc = 0; fc < NFC; ++fc) {
+                            __syncthreads();              // (the previous stage / part / chunk is done with XA and the chunk region)
+                            si.commit(tid, ZA, CSZ);
+                            __syncthreads();
+                            if (fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
+                            else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
+                            resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                        }
+                        if (skip) {                       // + the U-Net skip (d2 / d1), this part's channels
+                            __syncthreads();
+#pragma unroll
+                            for (int i = 0; i < decltype(sx)::N; ++i) {
+                                const int u = tid + i * NTHREADS;
+                                if (u < ROWS * 8) {
+                                    float4* xp = reinterpret_cast<float4*>(XA + (u >> 3) * CSV + (u & 7) * 4);
+                                    const float4 a = *xp, b = sx.v[i];
+                                    *xp = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                                }
+                            }
+                            if constexpr (h + 1 < NH) sx.issue(tid, skip, CSI, (h + 1) * CINV);
+                        }
+                        Xl = XA;
+                    } else if (!xin_lds) {
                         __syncthreads();                  // (the previous stage / half is done with XA)
                         sx.commit(tid, XA, CSV);
                         if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
@@ -3318,56 +3356,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 });
                 __syncthreads();
             };
-            // ---- one joint resampler: xin (slab, C channels at VIN joints) -> xout (+ skip), per chunk of 8 frames
-            auto resample = [&](auto cc, auto vic, auto voc, int r, const float* xin, float* xout, const float* skip) {
-                constexpr int C = decltype(cc)::value, VIN = decltype(vic)::value, VOUT = decltype(voc)::value, CS = cs_of(C);
-                constexpr int IR = TL_FC * VIN, OR = TL_FC * VOUT;
-                int tid = tid0;
-                asm volatile("" : "+v"(tid));
-                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                RsCoef<C, VIN, VOUT, TL_FC, 1, false> rc;
-                rc.load(wb + N.rsw[r], wb + N.rsw[r] + ((VOUT + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
-                float* const ic = RA;
-                float* const oc = RA + ceil16(IR) * CS;
-                float nosk[1] = {0.f};
-                TlStage<IR, C> si;
-                si.issue(tid, xin, CS, 0);
-                for (int fc = 0; fc < NFC; ++fc) {
-                    __syncthreads();
-                    si.commit(tid, ic, CS);
-                    __syncthreads();
-                    if (fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CS, CS, 0);
-                    resample_stage<C, VIN, VOUT, TL_FC, 1, false, false, true>(ic, CS, oc, CS, rc, nosk, wave, lane);
-                    __syncthreads();
-                    tl_l2g(tid, xout + (size_t)fc * OR * CS, CS, oc, CS, C, OR, skip ? skip + (size_t)fc * OR * CS : nullptr);
-                }
-                __syncthreads();
-            };
 #define TL_C(x) std::integral_constant<int, x>{}
             TLMARK(60);                                                     // pass prologue (noise, embeddings)
-            layer(TL_C(0), XT, true, A0);
-            layer(TL_C(1), A0, false, A1);
-            layer(TL_C(2), A1, false, D1);                                  // -> d1
-            TLMARK(61);
-            resample(TL_C(32), TL_C(17), TL_C(12), 0, D1, A0, nullptr);     // down1
-            TLMARK(48);
-            layer(TL_C(3), A0, false, A1);
-            layer(TL_C(4), A1, false, D2);                                  // -> d2
-            TLMARK(61);
-            resample(TL_C(64), TL_C(12), TL_C(10), 1, D2, A0, nullptr);     // down2
-            TLMARK(49);
-            layer(TL_C(5), A0, false, A1);                                  // 64 -> 128
-            TLMARK(61);
-            layer(TL_C(6), A1, false, A0);                                  // 128 -> 64, mix-first here (four 32-channel quarters)
-            TLMARK(61);
-            resample(TL_C(64), TL_C(10), TL_C(12), 2, A0, A1, D2);          // up3 + d2
-            TLMARK(50);
-            layer(TL_C(7), A1, false, A0);
-            layer(TL_C(8), A0, false, A1);
-            TLMARK(61);
-            resample(TL_C(32), TL_C(12), TL_C(17), 3, A1, A0, D1);          // up2 + d1
-            TLMARK(51);
-            layer(TL_C(9), A0, false, A1);
+#define TL_NORS std::integral_constant<int, -1>{}
+            layer(TL_C(0), TL_NORS, XT, true, A0, nullptr);
+            layer(TL_C(1), TL_NORS, A0, false, A1, nullptr);
+            layer(TL_C(2), TL_NORS, A1, false, D1, nullptr);                // -> d1
+            layer(TL_C(3), TL_C(0), D1, false, A0, nullptr);                // down1 on the way in
+            layer(TL_C(4), TL_NORS, A0, false, D2, nullptr);                // -> d2
+            layer(TL_C(5), TL_C(1), D2, false, A0, nullptr);                // down2 on the way in; 64 -> 128
+            layer(TL_C(6), TL_NORS, A0, false, A1, nullptr);                // 128 -> 64, mix-first here (four 32-channel quarters)
+            layer(TL_C(7), TL_C(2), A1, false, A0, D2);                     // up3 + d2 on the way in
+            layer(TL_C(8), TL_NORS, A0, false, A1, nullptr);
+            layer(TL_C(9), TL_C(3), A1, false, A0, D1);                     // up2 + d1 on the way in
             TLMARK(61);
             {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
                 int tid = tid0;
@@ -3376,7 +3377,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 const float* w4 = wb + N.wp[10];
                 for (int u = tid; u < R17 * 4; u += NTHREADS) {
                     const int col = u >> 2, r = u & 3;
-                    const float* xp = A1 + (size_t)col * 36;
+                    const float* xp = A0 + (size_t)col * 36;
                     float a = 0.f;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
