@@ -3374,23 +3374,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                const float* w4 = wb + N.wp[10];
-                for (int u = tid; u < R17 * 4; u += NTHREADS) {
-                    const int col = u >> 2, r = u & 3;
+                MixLongCoef<16, 17, TP, NB> mc10;      // (the mix's first coefficients: in flight behind the product)
+                mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
+                const float* w4 = wb + N.wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
+                for (int col = tid; col < R17; col += NTHREADS) {
                     const float* xp = A0 + (size_t)col * 36;
-                    float a = 0.f;
+                    float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const float4 x = load_global4(xp + 4 * q);
-                        a = fmaf(w4[r * 32 + 4 * q + 0], x.x, a); a = fmaf(w4[r * 32 + 4 * q + 1], x.y, a);
-                        a = fmaf(w4[r * 32 + 4 * q + 2], x.z, a); a = fmaf(w4[r * 32 + 4 * q + 3], x.w, a);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a[r] = fmaf(w4[r * 32 + 4 * q + 0], x.x, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 1], x.y, a[r]);
+                            a[r] = fmaf(w4[r * 32 + 4 * q + 2], x.z, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 3], x.w, a[r]);
+                        }
                     }
-                    P4[u] = a;
+                    *reinterpret_cast<float4*>(P4 + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
                 }
                 __syncthreads();
                 // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
-                MixLongCoef<16, 17, TP, NB> mc10;
-                mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
                 mix_long<16, 17, TP, NB>(P4, 4, mc10, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
                                      [&](int q, int w0, int c, auto v) {
                                          if (c < C0) {
