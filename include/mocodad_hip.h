@@ -126,15 +126,17 @@ int mcd_philox_noise(uint64_t seed, int64_t first_window_id, int32_t n_windows, 
  * as its own launch, (B,S) losses when an aggregation cannot be fused, scratch slabs of the runtime-shape kernels.
  * ALWAYS allocate it: workspace == NULL is accepted only by calls that end up as ONE launch (mcd_plan_split() == 1 with the
  * shipped condition encoder on a specialised frame count and a loss-based aggregation); every other form -- one trajectory
- * per workgroup for small or oddly sized batches, mcd_score without aggregation, another encoder architecture, a frame count
- * on the runtime-shape kernel -- fails with MCD_EINVAL ("workspace required") without it. */
+ * per workgroup for small or oddly sized batches, mcd_score without aggregation, another encoder architecture, more than 12
+ * U-Net frames (the slab-tiled kernel's activations live in the workspace) -- fails with MCD_EINVAL ("workspace required")
+ * without it. */
 int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* How the library would cut this scoring call into workgroups (a pure function of the shapes, the device and MCD_OPT_SPLIT):
  * 1 = a workgroup runs every sample of its windows -- condition encoder, trajectories and aggregation in ONE kernel launch,
  * the default for batches that fill the device (1024 windows x 5 samples on 256 CUs); n_samples = one trajectory per
- * workgroup with the encoder and the aggregation as their own launches (better fill for small batches); 0 = the call runs
- * on the runtime-shape kernel (no specialised instantiation for this frame count).  Negative: MCD_E*. */
+ * workgroup with the encoder and the aggregation as their own launches (better fill for small batches); 0 = the call does
+ * not run on score_kernel<T_u, ...> at all: 13 .. 32 U-Net frames (the slab-tiled kernel, one or two trajectories per
+ * workgroup, aggregation as its own launch) or MCD_OPT_GENERIC_UNET.  Negative: MCD_E*. */
 int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* Per-handle options (no environment variables; the only process-wide state is mcd_debug_set_prof's pointer).  Set them before the calls they affect, from the
@@ -145,8 +147,8 @@ int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
  *   MCD_OPT_VARIANT       alternative workgroup shapes of the trajectory kernel (tuning experiments only).
  *   MCD_OPT_COND_GENERIC  1: run the condition encoder through the runtime-channel-list kernel even when the shipped
  *                         architecture's MFMA kernel applies (used by the tests to cover both).
- *   MCD_OPT_GENERIC_UNET  1: run the trajectory through the runtime-shape fallback kernel even when a specialised
- *                         instantiation exists (used by the tests to cover both).
+ *   MCD_OPT_GENERIC_UNET  1: run the trajectory through the plain-FMA runtime-shape kernel instead of the MFMA kernels (every
+ *                         frame count 1 .. 32 has one; the tests use this to cross-check the two implementations).
  *   MCD_OPT_SPLIT         0 (default): the library chooses how many workgroups share a window's samples (1 = a workgroup
  *                         runs all samples of its windows: condition encoder and aggregation fused into the ONE launch;
  *                         n_samples = one trajectory per workgroup, better fill for odd batch sizes); n > 0 forces it

@@ -1,11 +1,14 @@
 // mocodad_hip.hip — MI355X (gfx950 / CDNA4) kernels + C ABI for the MoCoDAD anomaly-scoring path.
 //
 // What runs here (reference: /root/reference, Python/PyTorch):
-//   MoCoDAD.forward hot loop            models/mocodad.py:155-180      -> score_kernel (persistent, one
-//   STSAE_Unet.forward                  models/stsae/stsae_unet.py:406-438   launch for all S*(ns-1) passes)
+//   MoCoDAD.forward hot loop            models/mocodad.py:155-180      -> score_kernel<T_u, ...> for 1 .. 12 U-Net frames (persistent,
+//   STSAE_Unet.forward                  models/stsae/stsae_unet.py:406-438   one launch for all S*(ns-1) passes), score_tiled_kernel
+//                                                                       for 13 .. 32 (activations in an L2 slab, stages through LDS);
+//                                                                       score_generic_kernel (plain FMAs, any count) cross-checks both
 //   ST_GCNN_layer / ConvTemporalGraphical / CNN_layer  models/gcae/stsgcn.py:94-199
 //   DDPM ancestral update + SmoothL1    models/mocodad.py:172-178,484
-//   STSE.encode (condition encoder)     models/stsae/stsae.py:59-92    -> cond_fast_kernel / cond_encode_kernel
+//   STSE.encode (condition encoder)     models/stsae/stsae.py:59-92    -> cond_fast_kernel (1 .. 12 frames) / cond_encode_kernel;
+//   STSE_Unet ('E_unet' encoder)        models/stsae/stsae_unet.py:62-146     cond_unet_kernel (1 .. 12) / cond_unet_generic_kernel
 //   _aggregation_strategy               models/mocodad.py:454-520      -> aggregate_kernel
 //
 // Design: one 512-thread workgroup owns NB reverse-diffusion chains (a chain = one
@@ -811,10 +814,7 @@ __device__ __forceinline__ void load_afrags(const float4* __restrict__ wp, int w
 // FRONT of the tile's MFMA chain and handed to epi as a 7th argument -- read inside the epilogue they put an LDS round trip
 // between the tile's last MFMA and its store
 struct NoPre { static constexpr bool none = true; };
-#ifndef MCD_X_DUAL
-#define MCD_X_DUAL 0
-#endif
-template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, bool DUAL = (FORCE || MCD_X_DUAL), class Epi, class Pre = NoPre>
+template <int MT, int NT, int KQ1, int KQ2, bool IDRES, bool FORCE = false, bool DUAL = FORCE, class Epi, class Pre = NoPre>
 __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const float* __restrict__ b1, int cs1,
                                            const float* __restrict__ b2, int cs2, int wave, int lane, Epi&& epi, int mi = 0,
                                            const float4 cinit = make_float4(0.f, 0.f, 0.f, 0.f), Pre&& pre = Pre{}) {
@@ -934,7 +934,7 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
 }
 
 // ------------------------------------------------------------------------------------------------
-// OPT-IN (MCD_BF16X3=1, not the measured default): the same channel GEMM on the bf16 matrix path with both operands
+// OPT-IN (mcd_set_option(MCD_OPT_BF16X3, 1), not the measured default): the same channel GEMM on the bf16 matrix path with both operands
 // split into bf16 pairs, x = hi + lo, and hi*hi + hi*lo + lo*hi accumulated in fp32 -- three v_mfma_f32_16x16x32_bf16
 // per K = 32 instead of eight v_mfma_f32_16x16x4_f32 (which run at the vector-FP32 rate and hold the SIMD's FP32 lanes).
 // Scores stay within ~1e-6 of the fp32 path (tests/studies/bf16x3_error.py).  Weights are split at pack time
@@ -2669,14 +2669,21 @@ __global__ __launch_bounds__(GEN_THREADS) void score_generic_kernel(const ScoreP
 
 // ------------------------------------------------------------------------------------------------
 // MFMA path for 12 < T_u <= 32 U-Net frames (concat over 24 frames, 16 + 16, ...): the activations of such a chain do not
-// fit LDS (257 KB at layer 5 of a 24-frame chain), so the chain lives in an L2-resident slab of global memory and every
-// stage is "slab -> LDS -> MFMA stage function -> slab", one 512-thread workgroup per chain at a time:
-//   mix    the time mix couples all frames: 32 channels of ALL frames are staged in LDS (<= 78 KB) and mixed by mix_long
-//          (the matrix-core joint mix of mix_stage with the time mix sliced over the frames); z goes to the slab
-//   GEMM   per chunk of 8 frames: z and x of the chunk -> LDS, gemm_tiles (two tiles in flight) -> epilogue -> slab
-//   joint resamplers per chunk of 8 frames through resample_stage; the U-Net skips d1 / d2 are slab buffers
+// fit LDS (257 KB at layer 5 of a 24-frame chain), so the chain lives in a slab of global memory (L2 / Infinity Cache) and a
+// layer is "32 input channels of ALL frames -> LDS -> mix -> channel GEMM -> slab", one 512-thread workgroup per CU:
+//   X      one 32-channel part of the layer's input, every frame, staged slab -> registers -> LDS (the next part's loads in
+//          flight behind this part's stages).  The four joint resamplers are not stages of their own: the layer behind one
+//          builds its X from the resampler's input rows (chunk of frames by chunk, resample_stage LDS -> LDS, + the U-Net skip)
+//   mix    both halves on the matrix cores: tl_time_mix (the (frames x frames) time mix of a joint as one MFMA product, Tq
+//          pre-packed as A fragments) writes Y to LDS, tl_joint_mix turns it into z in place.  z never leaves LDS
+//   GEMM   gemm_part: z . W_t + x . W_r (or + x) of the part into register accumulators (<= 80 per lane); layers with 64 or
+//          128 input channels sum their 2 or 4 parts there; one epilogue (bias, PReLU, embedding) -> slab
+//   layers at 17 joints (32 input channels, X = 78 KB at 32 frames) take their frames in two groups so that X + z fit
+//   layer 6 runs mix-first here (the specialised kernels run it W-first); layer 10 W-first on plain FMAs + mix_long
 // The frame count is padded to TP = 16, 24 or 32 with zero mixing coefficients (a padded frame's activations are finite
-// garbage that no real frame ever reads).  Same noise keys, update, loss and strategies as score_kernel.
+// garbage that no real frame ever reads); two 16-frame chains share a workgroup (<16, 2>: the stage lengths of 32 frames).
+// Same noise keys, update, loss and strategies as score_kernel.  Slab traffic: 14.3 k floats per frame and pass (the first
+// version, every stage through the slab: 37 k -- it ran at the HBM / fabric roofline, 4.6 TB/s, profiles/README.md).
 // ------------------------------------------------------------------------------------------------
 struct TiledNet {
     int tq[NLAYERS], am[NLAYERS], wp[NLAYERS], bias[NLAYERS];
@@ -2685,17 +2692,8 @@ struct TiledNet {
     int rsw[4];          // joint resamplers, non-capture fragment packs (RsCoef chunks: fragments then bias)
     int we, be;
 };
-#ifndef MCD_X_TLFC
-#define MCD_X_TLFC 1
-#endif
-// frames per GEMM / resampler chunk: half the padded frame count at 24 / 32 frames, all 16 at 16 (fewer, longer stages:
-// every chunk costs two barriers that wait for the previous stage's slab stores to land)
-#ifndef MCD_X_FC16
-#define MCD_X_FC16 16
-#define MCD_X_FC24 12
-#define MCD_X_FC32 16
-#endif
-__host__ __device__ constexpr int tl_fc(int TP) { return TP == 16 ? MCD_X_FC16 : TP == 24 ? MCD_X_FC24 : MCD_X_FC32; }
+// frames per chunk of a fused joint resampler (its input rows of those frames pass through the z region): 16, 12 at 24 frames
+__host__ __device__ constexpr int tl_fc(int TP) { return TP == 24 ? 12 : 16; }
 __host__ __device__ constexpr int tl_ra_floats(int TP) {
     // LDS work region.  Layers: X (32 channels of all frames, + pad rows) and z (the same; half the frames at 17 joints);
     // resamplers / layer 6: in + out chunks
@@ -2703,8 +2701,8 @@ __host__ __device__ constexpr int tl_ra_floats(int TP) {
 }
 __host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
 __host__ __device__ constexpr long long tl_slab_floats(int TP) {
-    // A0, A1 (ping-pong, up to 128 ch x 10 joints), Zg, D1, D2 -- each with 16 rows of padding behind it
-    return (long long)2 * (TP * 10 + 16) * 132 + (long long)(TP * 12 + 16) * 68 + (long long)(TP * 17 + 16) * 36 + (long long)(TP * 12 + 16) * 68;
+    // A0, A1 (ping-pong, up to 128 ch x 10 joints), the skips D1, D2 -- each with 16 rows of padding behind it
+    return (long long)2 * (TP * 10 + 16) * 132 + (long long)(TP * 17 + 16) * 36 + (long long)(TP * 12 + 16) * 68;
 }
 
 // cooperative copies between the slab and LDS, `ch` channels (multiple of 4) from channel ch0 of `rows` rows
@@ -2715,16 +2713,6 @@ __device__ __forceinline__ void tl_g2l(float* dst, int ds, const float* src, int
         *reinterpret_cast<float4*>(dst + r * ds + c) = load_global4(src + (size_t)r * ss + ch0 + c);
     }
 }
-__device__ __forceinline__ void tl_l2g(int tid, float* dst, int ds, const float* src, int ss, int ch, int rows, const float* add) {
-    const int q = ch >> 2;
-    for (int u = tid; u < rows * q; u += NTHREADS) {
-        const int r = u / q, c = (u - r * q) * 4;
-        float4 v = *reinterpret_cast<const float4*>(src + r * ss + c);
-        if (add) { const float4 a = load_global4(add + (size_t)r * ds + c); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-        *reinterpret_cast<float4*>(dst + (size_t)r * ds + c) = v;
-    }
-}
-
 // slab -> LDS through registers, in two halves: issue() puts the global loads in flight (typically one stage ahead, so that
 // their L2 latency runs behind the stage's MFMAs), commit() writes them to LDS once the region is free
 template <int ROWS, int CH>
@@ -2797,11 +2785,8 @@ __device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, co
         // (q0: first output frame of the unit in the flat list of NB * TP frames; its chain's frames start at row fo * V)
         const int cb = u % CB, qg = u / CB, fo = NB > 1 ? (qg / NQ) * TP : 0, q0 = fo + (qg % NQ) * QC;
         MC later;
-#ifndef MCD_X_TLFIRST
-#define MCD_X_TLFIRST 1
-#endif
-        if constexpr (rnd > 0 || !MCD_X_TLFIRST) later.load(tqd, af, u, lane);        // (a second live set of 50 .. 80 registers for a prefetch does not fit)
-        const MC& cur = (rnd > 0 || !MCD_X_TLFIRST) ? later : first;
+        if constexpr (rnd > 0) later.load(tqd, af, u, lane);        // (a second live set of 50 .. 80 registers for a prefetch does not fit)
+        const MC& cur = rnd > 0 ? later : first;
         const auto& tq = cur.tq;
         const auto& aop = cur.aop;
         f32x4 acc[QC][MTM];
@@ -3053,33 +3038,6 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
     });
 }
 
-// channel GEMM + epilogue of one 8-frame chunk: z / x chunks in LDS ([col][ch], strides cs_of(CIN) / CSX), result rows to
-// the slab (row stride cs_of(COUT)); COLS = real columns of the chunk (the last tile's pad columns are not stored)
-template <int CIN, int COUT, int COLS, bool RES, int CSX, class AF>
-__device__ __forceinline__ void tl_gemm(const AF& A, float slope, const float* __restrict__ z, const float* __restrict__ x,
-                                        float* __restrict__ outg, const float* __restrict__ embl, int wave, int lane) {
-    constexpr int MT = ceil16(COUT) / 16, NT = ceil16(COLS) / 16, CSI = cs_of(CIN), CSO = cs_of(COUT);
-    constexpr int KQ1 = CIN / 16, KQ2 = RES ? CIN / 16 : 0;
-    const float pinf = prelu_bound(slope);
-    const int mt = wave % MT;
-    const float4 e = embl ? *reinterpret_cast<const float4*>(embl + mt * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 bcur = A.bcur;
-    auto epi = [&](auto, int col, int c0, f32x4 acc, int, int) {
-        if (col < COLS && (COUT % 16 == 0 || c0 < COUT)) {
-            f32x2 t0 = f32x2{acc[0], acc[1]}, t1 = f32x2{acc[2], acc[3]};
-            if constexpr (!RES) { t0 += f32x2{bcur.x, bcur.y}; t1 += f32x2{bcur.z, bcur.w}; }
-            const f32x2 m0 = t0 * slope, m1 = t1 * slope;
-            const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf)} + f32x2{e.x, e.y};
-            const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf)} + f32x2{e.z, e.w};
-            *reinterpret_cast<float4*>(outg + (size_t)col * CSO + c0) = make_float4(r0[0], r0[1], r1[0], r1[1]);
-        }
-    };
-    gemm_tiles<MT, NT, KQ1, KQ2, !RES, true>(A.a, z, CSI, x, CSX, wave, lane, epi, 0, RES ? bcur : make_float4(0.f, 0.f, 0.f, 0.f));
-}
-
-// NB chains of TP (padded) frames each per workgroup, laid out as one flat list of TF = NB * TP frames: the channel GEMMs, the
-// resamplers and the slab copies see TF frames; the time mix stays inside a chain (mix_long's units).  <16, 2> gives the
-// 13 .. 16-frame shapes the stage lengths (and the matrix-pipe fill per barrier) of the 32-frame shape.
 // profile builds (tools/tiled_stage_profile.py): thread 0 of workgroup 0 adds the cycles since its previous mark to slot
 // 2048 + id of the profile buffer
 #ifdef MCD_PROFILE
@@ -3161,8 +3119,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             asm volatile("" : "+s"(sl));
             float* const A0 = sl;
             float* const A1 = A0 + (R10 + 16) * 132;
-            float* const Zg = A1 + (R10 + 16) * 132;
-            float* const D1 = Zg + (R12 + 16) * 68;
+            float* const D1 = A1 + (R10 + 16) * 132;
             float* const D2 = D1 + (R17 + 16) * 36;
             __syncthreads();
             if (tid < NB * EDIM) {

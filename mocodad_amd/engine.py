@@ -128,7 +128,7 @@ class HipScorer:
     def plan_split(self, n_windows: int, n_samples: int, noise_steps: int) -> int:
         """How a scoring call of this size is cut into workgroups (mcd_plan_split): 1 = ONE launch (a workgroup runs all samples
         of its windows, condition encoder and aggregation inside), n_samples = one trajectory per workgroup + the encoder and
-        the aggregation as their own launches, 0 = runtime-shape kernel."""
+        the aggregation as their own launches, 0 = not on score_kernel (13 .. 32 U-Net frames: the slab-tiled kernel; or 'generic_unet')."""
         cfg = self._score_cfg(int(n_windows), int(n_samples), int(noise_steps), "smooth_l1")
         with torch.cuda.device(self.device):
             r = int(self.L.mcd_plan_split(self._h, C.byref(cfg)))
