@@ -2871,44 +2871,60 @@ __device__ __forceinline__ void tl_time_fetch(float (&a)[TP / 4], const float* _
 #pragma unroll
     for (int ks = 0; ks < G::KT; ++ks) a[ks] = ap[ks * 64];
 }
+// The wave's first unit runs alone on coefficients the caller fetched a stage ahead; the others' coefficients are fetched in
+// front of it and those units then run together (their LDS reads, then their MFMA chains interleaved: with two waves per SIMD
+// a single unit's read -> 8 dependent MFMAs -> write sequence leaves the matrix pipe idle most of the time).
 template <int CINV, int V, int TP, int NB, int NGRP>
 __device__ __forceinline__ void tl_time_mix(const float* __restrict__ X, int cs, float* __restrict__ Y, int csy,
                                             const float* __restrict__ tqm, int wave, int lane, int grp, const float (&first)[TP / 4]) {
     using G = TlGroups<TP, NB, NGRP>;
     constexpr int CB = CINV / 16, KT = G::KT, UNITS = V * G::NCH * G::MTG;
-    constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;
+    constexpr int PER = (UNITS + NWAVES - 1) / NWAVES, NR = PER > 1 ? PER - 1 : 1;
     const int j = lane & 15, g = lane >> 4;
-    float a[2][KT];
+    float ar[NR][KT];
+    if constexpr (PER > 1) {
 #pragma unroll
-    for (int ks = 0; ks < KT; ++ks) a[0][ks] = first[ks];
-    static_for<PER>([&](auto rr) {
-        constexpr int rnd = decltype(rr)::value;
-        const int u = wave + rnd * NWAVES;
-        if (u >= UNITS) return;
-        if constexpr (rnd + 1 < PER) { if (u + NWAVES < UNITS) tl_time_fetch<V, TP, NB, NGRP>(a[(rnd + 1) & 1], tqm, u + NWAVES, lane, grp); }
-        const int v = u % V, m = (u / V) % G::MTG, ch = u / (V * G::MTG);
-        const int chain = NB >= NGRP ? grp * G::NCH + ch : 0;                    // chain of the flat frame list
-        const float* xp = X + __mul24((chain * TP + g) * V + v, cs) + j;
-        float b[CB][KT];
+        for (int i = 0; i < PER - 1; ++i) tl_time_fetch<V, TP, NB, NGRP>(ar[i], tqm, wave + (i + 1) * NWAVES, lane, grp);
+    }
+    auto run = [&](auto r0c, auto nic, const auto& a) {
+        constexpr int r0 = decltype(r0c)::value, NI = decltype(nic)::value;
+        float b[NI][CB][KT];
+        f32x4 acc[NI][CB];
+        int vv[NI], mm[NI], cc[NI];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+        for (int i = 0; i < NI; ++i) {
+            const int u0 = wave + (r0 + i) * NWAVES, u = u0 < UNITS ? u0 : UNITS - 1;      // (a wave past the end repeats the last unit, unstored)
+            vv[i] = u % V; mm[i] = (u / V) % G::MTG; cc[i] = u / (V * G::MTG);
+            const int chain = NB >= NGRP ? grp * G::NCH + cc[i] : 0;                    // chain of the flat frame list
+            const float* xp = X + __mul24((chain * TP + g) * V + vv[i], cs) + j;
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) b[cb][ks] = xp[ks * 4 * V * cs + cb * 16];
-        f32x4 acc[CB];
+            for (int cb = 0; cb < CB; ++cb) {
+                acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < KT; ++ks) b[i][cb][ks] = xp[ks * 4 * V * cs + cb * 16];
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rnd & 1][ks], b[cb][ks], acc[cb], 0, 0, 0);
-        const int fl = ch * G::FGC + m * 16 + 4 * g;                  // first of the lane's 4 output frames, group-local
-        float* yp = Y + __mul24(fl * V + v, csy) + j;
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+                for (int cb = 0; cb < CB; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][ks], b[i][cb][ks], acc[i][cb], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (G::FGC % 16 == 0 || m * 16 + 4 * g + r < G::FGC) yp[r * V * csy + cb * 16] = acc[cb][r];
-    });
+        for (int i = 0; i < NI; ++i) {
+            if (wave + (r0 + i) * NWAVES >= UNITS) continue;
+            const int fl = cc[i] * G::FGC + mm[i] * 16 + 4 * g;          // first of the lane's 4 output frames, group-local
+            float* yp = Y + __mul24(fl * V + vv[i], csy) + j;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (G::FGC % 16 == 0 || mm[i] * 16 + 4 * g + r < G::FGC) yp[r * V * csy + cb * 16] = acc[i][cb][r];
+        }
+    };
+    const float (&f1)[1][TP / 4] = reinterpret_cast<const float (&)[1][TP / 4]>(first);
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f1);
+    if constexpr (PER > 1) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 1>{}, ar);
 }
 template <int V, int TP, int NB, int NGRP>
 __device__ __forceinline__ void tl_joint_fetch(float (&aop)[(V + 15) / 16][(V + 3) / 4], const float* __restrict__ af, int fl, int lane, int grp) {
@@ -2929,58 +2945,68 @@ __device__ __forceinline__ void tl_joint_mix(float* __restrict__ YZ, int cs, con
     constexpr int CB = CINV / 16, KS = (V + 3) / 4, KP = 2 * (KS / 2), MT = (V + 15) / 16;
     constexpr bool J16 = V == 17;
     constexpr int MTM = J16 ? 1 : MT;
-    constexpr int UNITS = G::FG, PER = (UNITS + NWAVES - 1) / NWAVES;
+    constexpr int UNITS = G::FG, PER = (UNITS + NWAVES - 1) / NWAVES, NR = PER > 1 ? PER - 1 : 1;
     const int j = lane & 15, g = lane >> 4;
     const int vp = 4 * (g & 1) + (g >> 1);              // mix_vmap: joint of this lane group in a paired k-step
-    float aop[2][MT][KS];
+    float ar[NR][MT][KS];
+    if constexpr (PER > 1) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int i = 0; i < PER - 1; ++i) tl_joint_fetch<V, TP, NB, NGRP>(ar[i], af, wave + (i + 1) * NWAVES, lane, grp);
+    }
+    auto run = [&](auto r0c, auto nic, const auto& aop) {
+        constexpr int r0 = decltype(r0c)::value, NI = decltype(nic)::value;
+        float y[NI][CB][KS];
+        f32x4 acc[NI][CB][MTM];
+        float part[NI][CB];
+        float* base[NI];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) aop[0][mt][ks] = first[mt][ks];
-    static_for<PER>([&](auto rr) {
-        constexpr int rnd = decltype(rr)::value;
-        const int fl = wave + rnd * NWAVES;              // frame of the group
-        if (fl >= UNITS) return;
-        if constexpr (rnd + 1 < PER) { if (fl + NWAVES < UNITS) tl_joint_fetch<V, TP, NB, NGRP>(aop[(rnd + 1) & 1], af, fl + NWAVES, lane, grp); }
-        float* base = YZ + __mul24(fl * V, cs) + j;
-        float y[CB][KS];
+        for (int i = 0; i < NI; ++i) {
+            const int f0 = wave + (r0 + i) * NWAVES, fl = f0 < UNITS ? f0 : UNITS - 1;       // frame of the group
+            base[i] = YZ + __mul24(fl * V, cs) + j;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
+            for (int cb = 0; cb < CB; ++cb) {
+                part[i][cb] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) y[cb][ks] = base[(ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + vp : 4 * KP + g) * cs + cb * 16];
-        f32x4 acc[CB][MTM];
-        float part[CB];
+                for (int mt = 0; mt < MTM; ++mt) acc[i][cb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            part[cb] = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MTM; ++mt) acc[cb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < KS; ++ks)
+                    y[i][cb][ks] = base[i][(ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + vp : 4 * KP + g) * cs + cb * 16];
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                    for (int mt = 0; mt < MTM; ++mt)
+                        acc[i][cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[i][mt][ks], y[i][cb][ks], acc[i][cb][mt], 0, 0, 0);
+                    if constexpr (J16) part[i][cb] = fmaf(aop[i][1][ks], y[i][cb][ks], part[i][cb]);
+                }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (wave + (r0 + i) * NWAVES >= UNITS) continue;
+#pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
 #pragma unroll
                 for (int mt = 0; mt < MTM; ++mt)
-                    acc[cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[rnd & 1][mt][ks], y[cb][ks], acc[cb][mt], 0, 0, 0);
-                if constexpr (J16) part[cb] = fmaf(aop[rnd & 1][1][ks], y[cb][ks], part[cb]);
-            }
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-#pragma unroll
-            for (int mt = 0; mt < MTM; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (mt * 16 + 4 * g + r < V) base[(mt * 16 + 4 * g + r) * cs + cb * 16] = acc[cb][mt][r];
-            if constexpr (J16) {      // joint 16: the four lane groups' partial sums (see mix_long)
-                const unsigned pu = __float_as_uint(part[cb]);
-                const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
-                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
-                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
-                if (g == 0) base[16 * cs + cb * 16] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                    for (int r = 0; r < 4; ++r)
+                        if (mt * 16 + 4 * g + r < V) base[i][(mt * 16 + 4 * g + r) * cs + cb * 16] = acc[i][cb][mt][r];
+                if constexpr (J16) {      // joint 16: the four lane groups' partial sums (see mix_long)
+                    const unsigned pu = __float_as_uint(part[i][cb]);
+                    const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+                    const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                    const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                    if (g == 0) base[i][16 * cs + cb * 16] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                }
             }
         }
-    });
+    };
+    const float (&f1)[1][MT][KS] = reinterpret_cast<const float (&)[1][MT][KS]>(first);
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f1);
+    if constexpr (PER > 1) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 1>{}, ar);
 }
 
 // partial channel GEMM of a layer of the slab-tiled kernel: acc[i] += A[O1 ..] . B1 (+ A[O2 ..] . B2) over this wave's n-tiles
