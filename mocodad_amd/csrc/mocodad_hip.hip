@@ -2695,9 +2695,9 @@ struct TiledNet {
 // frames per chunk of a fused joint resampler (its input rows of those frames pass through the z region): 16, 12 at 24 frames
 __host__ __device__ constexpr int tl_fc(int TP) { return TP == 24 ? 12 : 16; }
 __host__ __device__ constexpr int tl_ra_floats(int TP) {
-    // LDS work region.  Layers: X (32 channels of all frames, + pad rows) and z (the same; half the frames at 17 joints);
-    // resamplers / layer 6: in + out chunks
-    return cmax(cmax((TP * 17 + 16 + TP * 17 / 2 + 16) * 36, 2 * (TP * 12 + 16) * 36), 2 * ceil16(tl_fc(TP) * 12) * 68);
+    // LDS work region of a layer: X (32 channels of all frames, + pad rows) and z (the same; half the frames at 17 joints).
+    // (A fused resampler's input chunk passes through the z region.)
+    return cmax((TP * 17 + 16 + TP * 17 / 2 + 16) * 36, 2 * (TP * 12 + 16) * 36);
 }
 __host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
 __host__ __device__ constexpr long long tl_slab_floats(int TP) {
@@ -3247,6 +3247,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                     const float* Xl = xin;
                     if constexpr (RSI >= 0) {
                         static_assert(RSI < 0 || (CINV == 32 && L != 0), "");
+                        static_assert(RSI < 0 || IR <= ROWSG + 16, "the resampler's input chunk fits the z region");
                         float nosk[1] = {0.f};
 #pragma unroll
                         for (int fc = 0; fc < NFC; ++fc) {
