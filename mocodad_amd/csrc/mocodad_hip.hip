@@ -3064,11 +3064,11 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
     });
 }
 
-// profile builds (tools/tiled_stage_profile.py): thread 0 of workgroup 0 adds the cycles since its previous mark to slot
-// 2048 + id of the profile buffer
+// profile builds (tools/tiled_stage_profile.py): lane 0 of waves 0 and 7 of workgroup 0 add the cycles since their previous
+// mark to slot 2048 (+ 64 for wave 7) + id of the profile buffer
 #ifdef MCD_PROFILE
 #define TLMARK(id) do { if (tl_prof) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-    atomicAdd(P.prof + 2048 + (id), t_ - tl_last); tl_last = t_; } } while (0)
+    atomicAdd(P.prof + 2048 + (tid0 ? 64 : 0) + (id), t_ - tl_last); tl_last = t_; } } while (0)
 #else
 #define TLMARK(id) do { } while (0)
 #endif
@@ -3096,7 +3096,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* wb = P.wbuf;
 #ifdef MCD_PROFILE
-    const bool tl_prof = P.prof && blockIdx.x == 0 && tid0 == 0;
+    const bool tl_prof = P.prof && blockIdx.x == 0 && (tid0 == 0 || tid0 == NTHREADS - 64);
     unsigned long long tl_last = __builtin_readcyclecounter();
 #endif
     float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TF);

@@ -28,15 +28,16 @@ L.mcd_debug_set_prof(C.c_void_p(prof.data_ptr()))
 sc.score(data, n_samples=S, noise_steps=NS, seed=1)
 torch.cuda.synchronize()
 L.mcd_debug_set_prof(None)
-p = prof.cpu().numpy().astype(float)[2048:2048 + 64]
-tot = p.sum()
-chains = -(-B * S // 256)          # chains (or chain pairs) workgroup 0 ran: the grid is one workgroup per CU
-print(f"{CONFIG}: T_u={sc.t_unet}  workgroup 0: {tot:.0f} cycles over the launch, {tot / 2.4e6:.2f} ms at 2.4 GHz")
-lname = ["L0", "L1", "L2", "L3", "L4", "L5", "L6", "L7", "L8", "L9"]      # (a layer's row sums its 32-channel parts and frame groups)
-print("  layer     X wait       mix   barrier  gemm+epi   (% of the launch)")
-for l in range(10):
-    v = p[4 * l:4 * l + 4]
-    print(f"  {lname[l]:4s} {v[0]:10.0f} {v[1]:9.0f} {v[2]:9.0f} {v[3]:9.0f}   {100 * v.sum() / tot:5.1f}%")
-for i, n in [(54, "L10 + update"), (48, "down1"), (49, "down2"), (50, "up3 + d2"), (51, "up2 + d1"),
-             (60, "pass prologue"), (61, "layer tails")]:
-    print(f"  {n:14s} {p[i]:12.0f}   {100 * p[i] / tot:5.1f}%")
+pall = prof.cpu().numpy().astype(float)
+for wv, off in ((0, 2048), (7, 2048 + 64)):
+    p = pall[off:off + 64]
+    tot = p.sum()
+    print(f"{CONFIG}: T_u={sc.t_unet}  workgroup 0, wave {wv}: {tot:.0f} cycles over the launch, {tot / 2.4e6:.2f} ms at 2.4 GHz")
+    lname = ["L0", "L1", "L2", "L3", "L4", "L5", "L6", "L7", "L8", "L9"]      # (a layer's row sums its 32-channel parts and frame groups)
+    print("  layer  X staged       mix   barrier  gemm+epi   (% of the launch)     [X staged: from the layer's / part's start to its X in LDS,")
+    print("                                                                         incl. the wait for the other waves' previous stage]")
+    for l in range(10):
+        v = p[4 * l:4 * l + 4]
+        print(f"  {lname[l]:4s} {v[0]:10.0f} {v[1]:9.0f} {v[2]:9.0f} {v[3]:9.0f}   {100 * v.sum() / tot:5.1f}%")
+    for i, n in [(54, "L10 + update"), (60, "pass prologue"), (61, "layer tails")]:
+        print(f"  {n:14s} {p[i]:12.0f}   {100 * p[i] / tot:5.1f}%")
