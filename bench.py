@@ -57,7 +57,7 @@ PEAK_HBM_GBS = 8000.0
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
 PMC_PROFILES = {"avenue": ("profiles/r03z_avenue_pmc.txt", 1024, 10, 5), "ubnormal_concat": ("profiles/r03z_ubnormal_concat_pmc.txt", 1024, 10, 5),
-                "seq24": ("profiles/r03z_seq24_pmc.txt", 1024, 50, 8)}
+                "seq24": ("profiles/r03z_seq24_pmc.txt", 1024, 50, 8), "concat32": ("profiles/r03z_concat32_pmc.txt", 1024, 10, 5)}
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
 
 
@@ -79,7 +79,8 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
                 cur[f[0]] = float(f[1])
     except Exception:
         return None
-    sk = next((v for k, v in kernels.items() if k.startswith("score_kernel")), None)
+    sk = next((v for k, v in kernels.items() if k.startswith("score_kernel") or k.startswith("score_tiled_kernel")), None)
+    tiled = any(k.startswith("score_tiled_kernel") for k in kernels)
     if not sk:
         return None
     scale = (B * S * (ns - 1)) / float(pB * pS * (pns - 1))       # counters scale with the chain-passes of a launch
@@ -91,7 +92,8 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
         out["mfma_issued_per_launch"] = round(mfma)
         # the time mix (2 T^2 FLOP per (input channel, joint) of each of the 11 layers: sum of C_in V = 5396) runs on the
         # VALU (DPP FMAs), everything else on the matrix cores; what the issued MFMAs exceed that by is tile padding
-        vec_flop = S * (ns - 1) * 2 * t_unet * t_unet * 5396
+        # (the slab-tiled kernel runs its time mix on the matrix cores too, layer 10's excepted: 32 x 17 = 544 of the 5396)
+        vec_flop = S * (ns - 1) * 2 * t_unet * t_unet * (544 if tiled else 5396)
         out["useful_mfma_frac"] = round(min(1.0, B * (flop_per_window - vec_flop) / 2048.0 / mfma), 4)
         out["mfma_pipe_busy_frac"] = round(mfma * 32 / (1024 * CLOCK_GHZ * 1e9 * kern_ms * 1e-3), 4)
         if "SQ_INSTS_VALU" in sk:
