@@ -3195,6 +3195,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             auto layer = [&](auto lc, auto rsc, const float* xin, bool xin_lds, float* xout, const float* skip) {
                 constexpr int L = decltype(lc)::value, RSI = decltype(rsc)::value;
                 constexpr int VIN = RSI == 0 ? 17 : RSI == 2 ? 10 : 12;      // joints of the resampler's input (down1, down2, up3, up2)
+                // LDS hand-over between two plain layers at the same joint count (3 -> 4, 5 -> 6, 7 -> 8): the first layer's epilogue
+                // writes output channels 0 .. 31 straight into the X region -- the second layer's first 32-channel part, which then
+                // never touches the slab (its load was the one nothing could hide: stores -> barrier -> loads, 3 - 4 us a layer)
+                constexpr bool HO = L == 3 || L == 5 || L == 7, HI = L == 4 || L == 6 || L == 8;
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
@@ -3222,7 +3226,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                     rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     if (skip) sx.issue(tid, skip, CSI, 0);
                 } else if (!xin_lds) {
-                    sx.issue(tid, xin, CSI, 0);
+                    static_assert(!HI || (RSI < 0 && NH >= 2), "");
+                    sx.issue(tid, xin, CSI, HI ? CINV : 0);
                 }
                 float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
                 tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 0);
@@ -3273,9 +3278,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         }
                         Xl = XA;
                     } else if (!xin_lds) {
-                        __syncthreads();                  // (the previous stage / half is done with XA)
-                        sx.commit(tid, XA, CSV);
-                        if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
+                        if constexpr (!(HI && h == 0)) {  // (HI: part 0 is in XA already, part 1 on its way)
+                            __syncthreads();              // (the previous stage / half is done with XA)
+                            sx.commit(tid, XA, CSV);
+                            if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
+                        }
                         Xl = XA;
                     }
                     if constexpr (AQ) {
@@ -3319,6 +3326,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                             }
                         }
                         if constexpr (h == NH - 1) {      // epilogue: bias, PReLU, embedding -> slab
+                            static_assert(!HO || (FS == 1 && CSV == 36), "");
+                            if constexpr (HO) __syncthreads();        // (every wave is done with XA: the m-tiles 0, 1 go there)
                             const float4 bcur = A.bcur;
                             static_for<TI::MAXN>([&](auto ii) {
                                 constexpr int i = decltype(ii)::value;
@@ -3328,9 +3337,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                                     const float4 e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
                                     const f32x2 t0 = f32x2{acc[i][0] + bcur.x, acc[i][1] + bcur.y}, t1 = f32x2{acc[i][2] + bcur.z, acc[i][3] + bcur.w};
                                     const f32x2 m0 = t0 * slope, m1 = t1 * slope;
-                                    *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) =
-                                        make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
-                                                    __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
+                                    const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
+                                                                 __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
+                                    if (HO && mt < 2) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
+                                    else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;
                                 }
                             });
                         }
