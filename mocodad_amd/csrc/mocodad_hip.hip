@@ -3199,11 +3199,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 // writes output channels 0 .. 31 straight into the X region -- the second layer's first 32-channel part, which then
                 // never touches the slab (its load was the one nothing could hide: stores -> barrier -> loads, 3 - 4 us a layer)
                 constexpr bool HO = L == 3 || L == 5 || L == 7, HI = L == 4 || L == 6 || L == 8;
+                // ... and between the layers at 17 joints (0 -> 1 -> 2, 9 -> 10; one 32-channel part, two frame groups): the whole output
+                // goes to the X region, group 0's once group 1's time mix has read the old rows (its accumulators wait in registers)
+                constexpr bool HO17 = L == 0 || L == 1 || L == 9, HI17 = L == 1 || L == 2;
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
                 constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSZ = cs_of(CINV);
-                constexpr int CSV = L == 0 ? 4 : CSZ;            // layer 0 reads the chain state in place (see score_kernel)
+                constexpr int CSV = L == 0 ? 4 : L == 1 ? 36 : CSZ;    // layer 0 reads the chain state in place (see score_kernel); layer 1's
+                                                                       // X is layer 0's output, written with the 32-channel row stride
                 constexpr int ROWS = TF * V, FS = V == 17 ? 2 : 1, ROWSG = ROWS / FS;
                 static_assert(FS == 1 || NH == 1, "frame groups and channel halves are not combined");
                 static_assert(COUT % 16 == 0 && ROWSG % (NB > 1 ? 1 : 1) == 0, "");
@@ -3215,8 +3219,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-                float* const XA = RA;                                          // [ROWS + 16][CSZ]
-                float* const ZA = xin_lds ? RA : RA + (ROWS + 16) * CSZ;       // [ROWSG + 16][CSZ]
+                float* const XA = RA;                                          // [ROWS + 16][CSV]
+                float* const ZA = RA + (ROWS + 16) * (L <= 1 ? 36 : CSZ);      // [ROWSG + 16][CSZ]  (layer 0: behind the next layer's X)
                 TlStage<ROWS, CINV> sx;                // plain input: a 32-channel part of all frames; resampled input: the skip rows
                 constexpr int IR = TL_FC * VIN, OR = TL_FC * V;
                 TlStage<RSI >= 0 ? IR : 1, 32> si;     // resampled input: a chunk of the resampler's input rows
@@ -3225,7 +3229,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                     si.issue(tid, xin, CSI, 0);
                     rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     if (skip) sx.issue(tid, skip, CSI, 0);
-                } else if (!xin_lds) {
+                } else if (!xin_lds && !HI17) {
                     static_assert(!HI || (RSI < 0 && NH >= 2), "");
                     sx.issue(tid, xin, CSI, HI ? CINV : 0);
                 }
@@ -3277,6 +3281,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                             if constexpr (h + 1 < NH) sx.issue(tid, skip, CSI, (h + 1) * CINV);
                         }
                         Xl = XA;
+                    } else if (HI17) {
+                        Xl = XA;                          // (the previous layer's epilogue left it there)
                     } else if (!xin_lds) {
                         if constexpr (!(HI && h == 0)) {  // (HI: part 0 is in XA already, part 1 on its way)
                             __syncthreads();              // (the previous stage / half is done with XA)
@@ -3295,24 +3301,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                     }
                     __syncthreads();
                     TLMARK(4 * L);
-#pragma unroll
-                    for (int fg = 0; fg < FS; ++fg) {
-                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, fg);
-                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, fg, tqa);
-                        if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
-                        __syncthreads();
-                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, fg, aja);
-                        TLMARK(4 * L + 1);
-                        __syncthreads();
-                        TLMARK(4 * L + 2);
+                    auto gemm_fg = [&](int fg, f32x4 (&ac)[TI::MAXN]) {
                         const float* xg = Xl + fg * ROWSG * CSV;
                         if (h == 0) {
 #pragma unroll
-                            for (int i = 0; i < TI::MAXN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            for (int i = 0; i < TI::MAXN; ++i) ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                        if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH>(aq, ZA, CSZ, xg, CSV, wave, lane, acc);
-                        else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
-                        else gemm_part<MT, NT, KH, 0, h * KH, 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, acc);
+                        if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH>(aq, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        else gemm_part<MT, NT, KH, 0, h * KH, 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
                         if constexpr (!RES) {             // identity residual: the tile's own 4 channels of x, when they lie in this half
                             if ((mt * 16) / CINV == h) {
                                 const float* xr = xg + __mul24(ng * 16 + (lane & 15), CSV) + c0 - h * CINV;
@@ -3320,32 +3317,76 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                                     constexpr int i = decltype(ii)::value;
                                     if (ng + i * TI::NG < NT) {
                                         const float4 r = *reinterpret_cast<const float4*>(xr + i * TI::NG * 16 * CSV);
-                                        acc[i] += f32x4{r.x, r.y, r.z, r.w};
+                                        ac[i] += f32x4{r.x, r.y, r.z, r.w};
                                     }
                                 });
                             }
                         }
-                        if constexpr (h == NH - 1) {      // epilogue: bias, PReLU, embedding -> slab
-                            static_assert(!HO || (FS == 1 && CSV == 36), "");
-                            if constexpr (HO) __syncthreads();        // (every wave is done with XA: the m-tiles 0, 1 go there)
-                            const float4 bcur = A.bcur;
-                            static_for<TI::MAXN>([&](auto ii) {
-                                constexpr int i = decltype(ii)::value;
-                                const int col = ng * 16 + (lane & 15) + i * TI::NG * 16;
-                                if (ng + i * TI::NG < NT && col < ROWSG) {
-                                    const int gcol = fg * ROWSG + col;
-                                    const float4 e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
-                                    const f32x2 t0 = f32x2{acc[i][0] + bcur.x, acc[i][1] + bcur.y}, t1 = f32x2{acc[i][2] + bcur.z, acc[i][3] + bcur.w};
-                                    const f32x2 m0 = t0 * slope, m1 = t1 * slope;
-                                    const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
-                                                                 __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
-                                    if (HO && mt < 2) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
-                                    else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;
-                                }
-                            });
-                        }
-                        if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
+                    };
+                    // epilogue: bias, PReLU, embedding -> slab, or -> the X region (the next layer's input, row stride 36)
+                    auto epi_fg = [&](int fg, const f32x4 (&ac)[TI::MAXN]) {
+                        const float4 bcur = A.bcur;
+                        static_for<TI::MAXN>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            const int col = ng * 16 + (lane & 15) + i * TI::NG * 16;
+                            if (ng + i * TI::NG < NT && col < ROWSG) {
+                                const int gcol = fg * ROWSG + col;
+                                const float4 e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
+                                const f32x2 t0 = f32x2{ac[i][0] + bcur.x, ac[i][1] + bcur.y}, t1 = f32x2{ac[i][2] + bcur.z, ac[i][3] + bcur.w};
+                                const f32x2 m0 = t0 * slope, m1 = t1 * slope;
+                                const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
+                                                             __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
+                                if (HO17 || (HO && mt < 2)) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
+                                else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;
+                            }
+                        });
+                    };
+                    if constexpr (HO17) {
+                        static_assert(!HO17 || (FS == 2 && NH == 1 && COUT <= 32), "");
+                        f32x4 acc0[TI::MAXN];
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 0);
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 0, tqa);
+                        tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 1);
+                        __syncthreads();
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 0, aja);
+                        TLMARK(4 * L + 1);
+                        __syncthreads();
+                        TLMARK(4 * L + 2);
+                        gemm_fg(0, acc0);
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 1);
                         TLMARK(4 * L + 3);
+                        __syncthreads();                  // (z is free)
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 1, tqa);
+                        __syncthreads();                  // (nobody reads the X rows of group 0 any more)
+                        epi_fg(0, acc0);
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 1, aja);
+                        TLMARK(4 * L + 1);
+                        __syncthreads();
+                        TLMARK(4 * L + 2);
+                        gemm_fg(1, acc);
+                        __syncthreads();                  // (... nor those of group 1)
+                        epi_fg(1, acc);
+                        TLMARK(4 * L + 3);
+                    } else {
+#pragma unroll
+                        for (int fg = 0; fg < FS; ++fg) {
+                            tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, fg);
+                            tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, fg, tqa);
+                            if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
+                            __syncthreads();
+                            tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, fg, aja);
+                            TLMARK(4 * L + 1);
+                            __syncthreads();
+                            TLMARK(4 * L + 2);
+                            gemm_fg(fg, acc);
+                            if constexpr (h == NH - 1) {
+                                static_assert(!HO || (FS == 1 && CSV == 36), "");
+                                if constexpr (HO) __syncthreads();    // (every wave is done with XA: the m-tiles 0, 1 go there)
+                                epi_fg(fg, acc);
+                            }
+                            if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
+                            TLMARK(4 * L + 3);
+                        }
                     }
                 });
                 __syncthreads();
@@ -3372,11 +3413,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
                 const float* w4 = wb + N.wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
                 for (int col = tid; col < R17; col += NTHREADS) {
-                    const float* xp = A0 + (size_t)col * 36;
+                    const float* xp = RA + col * 36;          // layer 9's output, handed over in LDS
                     float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const float4 x = load_global4(xp + 4 * q);
+                        const float4 x = *reinterpret_cast<const float4*>(xp + 4 * q);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             a[r] = fmaf(w4[r * 32 + 4 * q + 0], x.x, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 1], x.y, a[r]);
