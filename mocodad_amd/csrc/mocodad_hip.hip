@@ -3202,6 +3202,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 // ... and between the layers at 17 joints (0 -> 1 -> 2, 9 -> 10; one 32-channel part, two frame groups): the whole output
                 // goes to the X region, group 0's once group 1's time mix has read the old rows (its accumulators wait in registers)
                 constexpr bool HO17 = L == 0 || L == 1 || L == 9, HI17 = L == 1 || L == 2;
+                // ... and into a fused resampler (4 -> down2 -> 5, 6 -> up3 -> 7): output channels 0 .. 31 go where the next layer's
+                // resampler takes its input chunks from (that layer's z region), all frames at once
+                constexpr bool HOR = L == 4 || L == 6, HIR = L == 5 || L == 7;
+                constexpr int TNEXT = (TF * (L == 4 ? 10 : 12) + 16) * 36;     // offset of the next layer's z region
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
@@ -3226,7 +3230,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 TlStage<RSI >= 0 ? IR : 1, 32> si;     // resampled input: a chunk of the resampler's input rows
                 RsCoef<32, VIN, V, TL_FC, 1, false> rc;
                 if constexpr (RSI >= 0) {
-                    si.issue(tid, xin, CSI, 0);
+                    static_assert(!HIR || NH >= 2, "");
+                    si.issue(tid, xin, CSI, HIR ? CINV : 0);       // (HIR: part 0 is in the z region already, all chunks of it)
                     rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     if (skip) sx.issue(tid, skip, CSI, 0);
                 } else if (!xin_lds && !HI17) {
@@ -3258,14 +3263,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         static_assert(RSI < 0 || (CINV == 32 && L != 0), "");
                         static_assert(RSI < 0 || IR <= ROWSG + 16, "the resampler's input chunk fits the z region");
                         float nosk[1] = {0.f};
+                        if constexpr (HIR && h == 0) {
 #pragma unroll
-                        for (int fc = 0; fc < NFC; ++fc) {
-                            __syncthreads();              // (the previous stage / part / chunk is done with XA and the chunk region)
-                            si.commit(tid, ZA, CSZ);
-                            __syncthreads();
-                            if (fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
-                            else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
-                            resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                            for (int fc = 0; fc < NFC; ++fc)
+                                resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA + fc * IR * CSZ, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                        } else {
+#pragma unroll
+                            for (int fc = 0; fc < NFC; ++fc) {
+                                __syncthreads();          // (the previous stage / part / chunk is done with XA and the chunk region)
+                                si.commit(tid, ZA, CSZ);
+                                __syncthreads();
+                                if (fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
+                                else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
+                                resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                            }
                         }
                         if (skip) {                       // + the U-Net skip (d2 / d1), this part's channels
                             __syncthreads();
@@ -3337,7 +3348,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                                 const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
                                                              __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
                                 if (HO17 || (HO && mt < 2)) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
-                                else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;
+                                else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;      // (layer 4's is the skip d2 as well)
+                                if (HOR && mt < 2) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
                             }
                         });
                     };
@@ -3380,8 +3392,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                             TLMARK(4 * L + 2);
                             gemm_fg(fg, acc);
                             if constexpr (h == NH - 1) {
-                                static_assert(!HO || (FS == 1 && CSV == 36), "");
-                                if constexpr (HO) __syncthreads();    // (every wave is done with XA: the m-tiles 0, 1 go there)
+                                static_assert(!(HO || HOR) || (FS == 1 && CSV == 36), "");
+                                if constexpr (HO || HOR) __syncthreads();    // (every wave is done with XA / z: the m-tiles 0, 1 go there)
                                 epi_fg(fg, acc);
                             }
                             if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
