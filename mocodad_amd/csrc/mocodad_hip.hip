@@ -3205,7 +3205,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 // ... and into a fused resampler (4 -> down2 -> 5, 6 -> up3 -> 7): output channels 0 .. 31 go where the next layer's
                 // resampler takes its input chunks from (that layer's z region), all frames at once
                 constexpr bool HOR = L == 4 || L == 6, HIR = L == 5 || L == 7;
-                constexpr int TNEXT = (TF * (L == 4 ? 10 : 12) + 16) * 36;     // offset of the next layer's z region
+                constexpr int TNEXT = (TF * (L == 4 ? 10 : L == 8 ? 17 : 12) + 16) * 36;     // offset of the next layer's z region
+                // ... or only the resampler's FIRST chunk where all of it does not fit (2 -> down1 -> 3, 8 -> up2 -> 9); layer 2 keeps
+                // group 0's accumulators until both groups are through (the chunk's place is still its own X rows before)
+                constexpr bool HOC = L == 2 || L == 8, HIC = L == 3 || L == 9;
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
@@ -3231,7 +3234,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 RsCoef<32, VIN, V, TL_FC, 1, false> rc;
                 if constexpr (RSI >= 0) {
                     static_assert(!HIR || NH >= 2, "");
-                    si.issue(tid, xin, CSI, HIR ? CINV : 0);       // (HIR: part 0 is in the z region already, all chunks of it)
+                    static_assert(!HIC || (NH == 1 && NFC == 2), "");
+                    if constexpr (HIC) si.issue(tid, xin + (size_t)IR * CSI, CSI, 0);      // (chunk 0 is in the z region already)
+                    else si.issue(tid, xin, CSI, HIR ? CINV : 0);   // (HIR: part 0 is in the z region already, all chunks of it)
                     rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     if (skip) sx.issue(tid, skip, CSI, 0);
                 } else if (!xin_lds && !HI17) {
@@ -3270,11 +3275,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         } else {
 #pragma unroll
                             for (int fc = 0; fc < NFC; ++fc) {
-                                __syncthreads();          // (the previous stage / part / chunk is done with XA and the chunk region)
-                                si.commit(tid, ZA, CSZ);
-                                __syncthreads();
-                                if (fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
-                                else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
+                                if (!(HIC && fc == 0)) {
+                                    __syncthreads();      // (the previous stage / part / chunk is done with XA and the chunk region)
+                                    si.commit(tid, ZA, CSZ);
+                                    __syncthreads();
+                                    if (!HIC && fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
+                                    else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
+                                }
                                 resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
                             }
                         }
@@ -3350,11 +3357,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                                 if (HO17 || (HO && mt < 2)) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
                                 else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;      // (layer 4's is the skip d2 as well)
                                 if (HOR && mt < 2) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
+                                if (HOC && gcol < TL_FC * V) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
                             }
                         });
                     };
-                    if constexpr (HO17) {
-                        static_assert(!HO17 || (FS == 2 && NH == 1 && COUT <= 32), "");
+                    if constexpr (HO17 || L == 2) {
+                        static_assert(!(HO17 || L == 2) || (FS == 2 && NH == 1 && COUT <= 32), "");
                         f32x4 acc0[TI::MAXN];
                         tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 0);
                         tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 0, tqa);
@@ -3370,13 +3378,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         __syncthreads();                  // (z is free)
                         tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 1, tqa);
                         __syncthreads();                  // (nobody reads the X rows of group 0 any more)
-                        epi_fg(0, acc0);
+                        if constexpr (HO17) epi_fg(0, acc0);
                         tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 1, aja);
                         TLMARK(4 * L + 1);
                         __syncthreads();
                         TLMARK(4 * L + 2);
                         gemm_fg(1, acc);
                         __syncthreads();                  // (... nor those of group 1)
+                        if constexpr (!HO17) epi_fg(0, acc0);
                         epi_fg(1, acc);
                         TLMARK(4 * L + 3);
                     } else {
@@ -3393,7 +3402,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                             gemm_fg(fg, acc);
                             if constexpr (h == NH - 1) {
                                 static_assert(!(HO || HOR) || (FS == 1 && CSV == 36), "");
-                                if constexpr (HO || HOR) __syncthreads();    // (every wave is done with XA / z: the m-tiles 0, 1 go there)
+                                if constexpr (HO || HOR || L == 8) __syncthreads();    // (every wave is done with XA / z: the m-tiles 0, 1 go there)
                                 epi_fg(fg, acc);
                             }
                             if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
