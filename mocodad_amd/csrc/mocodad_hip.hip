@@ -2680,9 +2680,13 @@ __global__ __launch_bounds__(GEN_THREADS) void score_generic_kernel(const ScoreP
 //          128 input channels sum their 2 or 4 parts there; one epilogue (bias, PReLU, embedding) -> slab
 //   layers at 17 joints (32 input channels, X = 78 KB at 32 frames) take their frames in two groups so that X + z fit
 //   layer 6 runs mix-first here (the specialised kernels run it W-first); layer 10 W-first on plain FMAs + mix_long
+//   hand-overs: no layer waits for the slab.  A layer's epilogue writes what the next layer reads first straight into LDS --
+//          its first 32-channel part (3->4, 5->6, 7->8; the whole output across the 17-joint layers 0->1->2, 9->10, group 0's
+//          accumulators held back until group 1's time mix has read the old rows), or the next layer's resampler input (all of
+//          channels 0..31: 4->5, 6->7; its first chunk: 2->3, 8->9).  The slab keeps the later parts and the skips d1 / d2
 // The frame count is padded to TP = 16, 24 or 32 with zero mixing coefficients (a padded frame's activations are finite
 // garbage that no real frame ever reads); two 16-frame chains share a workgroup (<16, 2>: the stage lengths of 32 frames).
-// Same noise keys, update, loss and strategies as score_kernel.  Slab traffic: 14.3 k floats per frame and pass (the first
+// Same noise keys, update, loss and strategies as score_kernel.  Slab traffic: 9 k floats per frame and pass (the first
 // version, every stage through the slab: 37 k -- it ran at the HBM / fabric roofline, 4.6 TB/s, profiles/README.md).
 // ------------------------------------------------------------------------------------------------
 struct TiledNet {
