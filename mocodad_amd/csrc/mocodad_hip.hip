@@ -3213,8 +3213,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 // ... or only the resampler's FIRST chunk where all of it does not fit (2 -> down1 -> 3, 8 -> up2 -> 9); layer 2 keeps
                 // group 0's accumulators until both groups are through (the chunk's place is still its own X rows before)
                 constexpr bool HOC = L == 2 || L == 8, HIC = L == 3 || L == 9;
-                static_assert(!HOR || TNEXT + TF * V * 36 <= RA_F, "the handed-over resampler input fits behind the next layer's X");
-                static_assert(!HOC || TNEXT + TL_FC * V * 36 <= RA_F, "the handed-over first chunk fits behind the next layer's X");
                 constexpr LDesc D = layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
@@ -3223,6 +3221,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                                                                        // X is layer 0's output, written with the 32-channel row stride
                 constexpr int ROWS = TF * V, FS = V == 17 ? 2 : 1, ROWSG = ROWS / FS;
                 static_assert(FS == 1 || NH == 1, "frame groups and channel halves are not combined");
+                static_assert(!HOR || TNEXT + TF * V * 36 <= RA_F, "the handed-over resampler input fits behind the next layer's X");
+                static_assert(!HOC || TNEXT + TL_FC * V * 36 <= RA_F, "the handed-over first chunk fits behind the next layer's X");
                 static_assert(COUT % 16 == 0 && ROWSG % (NB > 1 ? 1 : 1) == 0, "");
                 constexpr int MT = COUT / 16, NT = ceil16(ROWSG) / 16, KH = CINV / 16;
                 using TI = Tiling<MT, NT>;
