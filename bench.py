@@ -98,6 +98,17 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
         out["mfma_pipe_busy_frac"] = round(mfma * 32 / (1024 * CLOCK_GHZ * 1e9 * kern_ms * 1e-3), 4)
         if "SQ_INSTS_VALU" in sk:
             out["other_valu_per_mfma"] = round((sk["SQ_INSTS_VALU"] * scale - mfma) / mfma, 3)
+        if "SQ_WAIT_ANY" in sk and sk.get("SQ_WAVE_CYCLES"):
+            out["wave_wait_frac"] = round(sk["SQ_WAIT_ANY"] / sk["SQ_WAVE_CYCLES"], 4)     # a wave parked on any counter or barrier
+    # barrier share of a pass from the committed in-kernel stage profile (an instrumented -DMCD_PROFILE build of the same kernel:
+    # mean cycles a wave waits at the pass's workgroup barriers / cycles of the pass)
+    try:
+        import re
+        m = re.search(r"mean wait per wave\s+(\d+)\s+\(pass total\s+(\d+)\)", open(os.path.join(ROOT, path.replace("_pmc.txt", "_stage_profile.txt"))).read())
+        if m:
+            out["barrier_wait_frac"] = round(int(m.group(1)) / int(m.group(2)), 4)
+    except Exception:
+        pass
     if (ns, S) == (pns, pS) and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in kernels.values()):
         # same chain length: the bytes of a launch scale with its windows (inputs, scores, per-workgroup weight fetches, spills)
         out["hbm_bytes_per_step"] = sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in kernels.values()) * 1024.0 * B / float(pB)
