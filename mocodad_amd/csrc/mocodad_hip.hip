@@ -2890,45 +2890,61 @@ __device__ __forceinline__ void tl_time_mix(const float* __restrict__ X, int cs,
 #pragma unroll
         for (int i = 0; i < PER - 1; ++i) tl_time_fetch<V, TP, NB, NGRP>(ar[i], tqm, wave + (i + 1) * NWAVES, lane, grp);
     }
-    auto run = [&](auto r0c, auto nic, const auto& a) {
-        constexpr int r0 = decltype(r0c)::value, NI = decltype(nic)::value;
-        float b[NI][CB][KT];
-        f32x4 acc[NI][CB];
-        int vv[NI], mm[NI], cc[NI];
+    // (all LDS reads of the wave's units first, the later units' behind the first one's: they run under its MFMAs.  The same
+    // order in tl_joint_mix costs registers the 16- and 32-frame kernels do not have: -1.2 % / +0.4 %, not taken)
+    struct Unit { int v, m, c; };
+    auto unit_of = [&](int r) {
+        const int u0 = wave + r * NWAVES, u = u0 < UNITS ? u0 : UNITS - 1;          // (a wave past the end repeats the last unit, unstored)
+        return Unit{u % V, (u / V) % G::MTG, u / (V * G::MTG)};
+    };
+    auto read_b = [&](const Unit& un, float (&b)[CB][KT]) {
+        const int chain = NB >= NGRP ? grp * G::NCH + un.c : 0;                      // chain of the flat frame list
+        const float* xp = X + __mul24((chain * TP + g) * V + un.v, cs) + j;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int u0 = wave + (r0 + i) * NWAVES, u = u0 < UNITS ? u0 : UNITS - 1;      // (a wave past the end repeats the last unit, unstored)
-            vv[i] = u % V; mm[i] = (u / V) % G::MTG; cc[i] = u / (V * G::MTG);
-            const int chain = NB >= NGRP ? grp * G::NCH + cc[i] : 0;                    // chain of the flat frame list
-            const float* xp = X + __mul24((chain * TP + g) * V + vv[i], cs) + j;
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < KT; ++ks) b[cb][ks] = xp[ks * 4 * V * cs + cb * 16];
+    };
+    auto write_y = [&](int r, const Unit& un, const f32x4 (&acc)[CB]) {
+        if (wave + r * NWAVES >= UNITS) return;
+        const int fl = un.c * G::FGC + un.m * 16 + 4 * g;             // first of the lane's 4 output frames, group-local
+        float* yp = Y + __mul24(fl * V + un.v, csy) + j;
 #pragma unroll
-                for (int ks = 0; ks < KT; ++ks) b[i][cb][ks] = xp[ks * 4 * V * cs + cb * 16];
-            }
-        }
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                if (G::FGC % 16 == 0 || un.m * 16 + 4 * g + r4 < G::FGC) yp[r4 * V * csy + cb * 16] = acc[cb][r4];
+    };
+    Unit u0 = unit_of(0), ur[NR];
+    float b0[CB][KT], br[NR][CB][KT];
+    read_b(u0, b0);
+    if constexpr (PER > 1) {
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i) { ur[i] = unit_of(i + 1); read_b(ur[i], br[i]); }
+    }
+    f32x4 acc0[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc0[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(first[ks], b0[cb][ks], acc0[cb], 0, 0, 0);
+    write_y(0, u0, acc0);
+    if constexpr (PER > 1) {
+        f32x4 accr[NR][CB];
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) accr[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < PER - 1; ++i)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][ks], b[i][cb][ks], acc[i][cb], 0, 0, 0);
+                for (int cb = 0; cb < CB; ++cb) accr[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i][ks], br[i][cb][ks], accr[i][cb], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (wave + (r0 + i) * NWAVES >= UNITS) continue;
-            const int fl = cc[i] * G::FGC + mm[i] * 16 + 4 * g;          // first of the lane's 4 output frames, group-local
-            float* yp = Y + __mul24(fl * V + vv[i], csy) + j;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (G::FGC % 16 == 0 || mm[i] * 16 + 4 * g + r < G::FGC) yp[r * V * csy + cb * 16] = acc[i][cb][r];
-        }
-    };
-    const float (&f1)[1][TP / 4] = reinterpret_cast<const float (&)[1][TP / 4]>(first);
-    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f1);
-    if constexpr (PER > 1) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 1>{}, ar);
+        for (int i = 0; i < PER - 1; ++i) write_y(i + 1, ur[i], accr[i]);
+    }
 }
 template <int V, int TP, int NB, int NGRP>
 __device__ __forceinline__ void tl_joint_fetch(float (&aop)[(V + 15) / 16][(V + 3) / 4], const float* __restrict__ af, int fl, int lane, int grp) {
