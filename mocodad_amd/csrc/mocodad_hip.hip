@@ -3041,17 +3041,26 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
     const int j = lane & 15, g = lane >> 4;
     const float* const p1b = b1 + __mul24(ng * 16 + j, cs1) + 4 * g;
     const float* const p2b = b2 + __mul24(ng * 16 + j, cs2) + 4 * g;
-    auto chain = [&](auto nn, auto ia, auto ib) {
-        constexpr int N = decltype(nn)::value, i0 = decltype(ia)::value, i1 = decltype(ib)::value;
+    constexpr int NP = (MAXN + 1) / 2;
+    // first B fragment (k-group 0) of tile slot i -- read a pair ahead: the last k-group of a pair fetches the next pair's
+    auto rd0 = [&](int i) { return *reinterpret_cast<const float4*>((KQ1 > 0 ? p1b + i * NG * 16 * cs1 : p2b + i * NG * 16 * cs2)); };
+    float4 nxt[2];
+    auto prime = [&](auto pp) {
+        constexpr int p = decltype(pp)::value;
+        if constexpr (p < NP) {
+            constexpr int i0 = 2 * p, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
+            if (ng + i0 * NG < NT) nxt[0] = rd0(i0);
+            if (i1 != i0 && ng + i1 * NG < NT) nxt[1] = rd0(i1);
+        }
+    };
+    auto chain = [&](auto nn, auto pp, auto ia, auto ib) {
+        constexpr int N = decltype(nn)::value, p = decltype(pp)::value, i0 = decltype(ia)::value, i1 = decltype(ib)::value;
         const float* p1[2] = {p1b + i0 * NG * 16 * cs1, p1b + i1 * NG * 16 * cs1};
         const float* p2[2] = {p2b + i0 * NG * 16 * cs2, p2b + i1 * NG * 16 * cs2};
         auto rd = [&](int h, auto kk) {
             constexpr int kq = decltype(kk)::value;
             return *reinterpret_cast<const float4*>(kq < KQ1 ? p1[h] + kq * 16 : p2[h] + (kq - KQ1) * 16);
         };
-        float4 nxt[2];
-#pragma unroll
-        for (int h = 0; h < N; ++h) nxt[h] = rd(h, std::integral_constant<int, 0>{});
         static_for<KQ>([&](auto kk) {
             constexpr int kq = decltype(kk)::value;
             const float4 w = a[kq < KQ1 ? O1 + kq : O2 + kq - KQ1];
@@ -3061,6 +3070,8 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
             if constexpr (kq + 1 < KQ) {
 #pragma unroll
                 for (int h = 0; h < N; ++h) nxt[h] = rd(h, std::integral_constant<int, kq + 1>{});
+            } else {
+                prime(std::integral_constant<int, p + 1>{});
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4& c0 = acc[i0];
@@ -3075,12 +3086,13 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
             if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, u[1].w, c1, 0, 0, 0);
         });
     };
-    static_for<(MAXN + 1) / 2>([&](auto pp) {
+    prime(std::integral_constant<int, 0>{});
+    static_for<NP>([&](auto pp) {
         constexpr int i0 = 2 * decltype(pp)::value, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
         using I0 = std::integral_constant<int, i0>;
         using I1 = std::integral_constant<int, i1>;
-        if (i1 != i0 && ng + i1 * NG < NT) chain(std::integral_constant<int, 2>{}, I0{}, I1{});
-        else if (ng + i0 * NG < NT) chain(std::integral_constant<int, 1>{}, I0{}, I0{});
+        if (i1 != i0 && ng + i1 * NG < NT) chain(std::integral_constant<int, 2>{}, pp, I0{}, I1{});
+        else if (ng + i0 * NG < NT) chain(std::integral_constant<int, 1>{}, pp, I0{}, I0{});
     });
 }
 
