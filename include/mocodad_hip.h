@@ -97,7 +97,9 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
 void mcd_free_weights(mcd_weights_t* w);
 
 /* Replaces: MoCoDAD._encode_condition -> STSAE/STSE.encode (mocodad.py:546-560, stsae.py:59-92).
- * cond_data (B,C,t_cond,V) -> emb_out (B,emb_dim).  The AE decoder (dead work at eval) is not run. */
+ * cond_data (B,C,t_cond,V) -> emb_out (B,emb_dim).  The AE decoder (dead work at eval) is not run.
+ * (A test / diagnostic entry without a workspace argument: encoders that need scratch memory -- 'E_unet' above 12 condition
+ * frames, any encoder at 26 .. 31 -- return MCD_EUNSUPPORTED here and run inside mcd_score / mcd_score_fused.) */
 int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_windows, float* emb_out,
                     void* stream);
 

@@ -2194,6 +2194,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void cond_unet_kernel(const float* wbu
 struct CondW {
     const float* base;
     int n_layers, Tc, latent, cmax;
+    int gmode;       // 1: three LDS buffers of cmax x Tc x 17 do not fit (26 .. 31 condition frames): the third one lives in global scratch
     int cin[MCD_MAX_COND_LAYERS], cout[MCD_MAX_COND_LAYERS];
     int tq[MCD_MAX_COND_LAYERS], am[MCD_MAX_COND_LAYERS], wt[MCD_MAX_COND_LAYERS], wr[MCD_MAX_COND_LAYERS];
     int bias[MCD_MAX_COND_LAYERS];
@@ -2206,17 +2207,21 @@ struct CondW {
 // scalar loads.  (The first version ran the two mixes as one 17 x (T + 1) loop per output element: 8x the multiplies, 0.45
 // TFLOP/s; at 16 condition frames it was a quarter of the whole scoring step.)
 constexpr int CE_THREADS = 512;
+// gbuf (W.gmode): one buffer of cmax x Tc x 17 floats per workgroup in global scratch -- the buffers rotate, so a different one of
+// the three is the global one in every layer.
 __global__ __launch_bounds__(CE_THREADS) void cond_encode_kernel(const CondW W, const float* __restrict__ cond,
-                                                                 float* __restrict__ emb_out, int B) {
+                                                                 float* __restrict__ emb_out, int B, float* __restrict__ gbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Tc = W.Tc, TV = Tc * 17, nblk = (TV + 63) / 64;
-    float* X = smem;
-    float* Z = X + W.cmax * TV;
-    float* O = Z + W.cmax * TV;
-    float* RED = O + W.cmax * TV;  // CE_THREADS partial sums
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = CE_THREADS / 64;
+    float* RED = smem + (gbuf ? 2 : 3) * W.cmax * TV;  // CE_THREADS partial sums
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    float* X = smem;
+    float* Z = X + W.cmax * TV;
+    float* O = gbuf ? gbuf + (size_t)blockIdx.x * W.cmax * TV : Z + W.cmax * TV;
+    __syncthreads();
     for (int u = tid; u < C0 * TV; u += CE_THREADS) X[u] = cond[(size_t)b * C0 * TV + u];  // (c, t, v) row-major
     __syncthreads();
     for (int l = 0; l < W.n_layers; ++l) {
@@ -2324,6 +2329,7 @@ __global__ __launch_bounds__(CE_THREADS) void cond_encode_kernel(const CondW W, 
             emb_out[(size_t)b * W.latent + jo] = s;
         }
         __syncthreads();
+    }
     }
 }
 
@@ -4102,6 +4108,23 @@ int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMa
         default: return fail(MCD_EUNSUPPORTED, "tiled kernel: frame count");
     }
 }
+// plain condition encoder (any channel list; 13 .. 31 condition frames of the shipped one).  scratch: cond_plain_scratch_bytes()
+// of global memory when three LDS buffers do not fit (W.gmode), else unused
+constexpr int CE_MAX_WGS = 512;
+int64_t cond_plain_scratch_bytes(const mcd_weights* w, int64_t B) {
+    if (!w->has_cond || w->cond_unet || !w->cond.gmode) return 0;
+    return (B < CE_MAX_WGS ? B : CE_MAX_WGS) * (int64_t)w->cond.cmax * w->cond.Tc * 17 * 4;
+}
+int launch_cond_plain(const mcd_weights* w, const float* cond_data, int B, float* emb, float* scratch, hipStream_t st) {
+    const bool g = w->cond.gmode != 0;
+    if (g && !scratch) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for this many condition frames");
+    const size_t lds = ((size_t)(g ? 2 : 3) * w->cond.cmax * w->cond.Tc * 17 + CE_THREADS) * 4;
+    LDS_LIMIT(&cond_encode_kernel, (size_t)160 * 1024);
+    const int wgs = g && B > CE_MAX_WGS ? CE_MAX_WGS : B;
+    hipLaunchKernelGGL(cond_encode_kernel, dim3(wgs), dim3(CE_THREADS), lds, st, w->cond, cond_data, emb, B, g ? scratch : nullptr);
+    HIP_TRY(hipGetLastError());
+    return MCD_OK;
+}
 // the condition encoders that read the condition frames straight from the window view: the MFMA kernels for the frame
 // counts they are instantiated for, the runtime-shape 'E_unet' kernel otherwise (scratch: gen_scratch_bytes(B, Tc))
 int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, float* scratch,
@@ -4413,7 +4436,8 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             }
         }
         const size_t lds = ((size_t)3 * Cw.cmax * Cw.Tc * 17 + CE_THREADS) * 4;
-        if (lds > 160 * 1024) return fail(MCD_EUNSUPPORTED, "condition encoder activations exceed LDS");
+        Cw.gmode = lds > 160 * 1024;
+        if (((size_t)2 * Cw.cmax * Cw.Tc * 17 + CE_THREADS) * 4 > 160 * 1024) return fail(MCD_EUNSUPPORTED, "condition encoder activations exceed LDS");
     }
     {
         int* tab = reinterpret_cast<int*>(B.buf.data());
@@ -4479,11 +4503,8 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
             return fail(MCD_EUNSUPPORTED, "mcd_cond_encode: the 'E_unet' encoder at this frame count needs scratch memory; use mcd_score");
         return launch_cond_mfma(w, dv, fi, w->cond.Tc, emb_out, n_windows, nullptr, (hipStream_t)stream);
     }
-    const size_t lds = ((size_t)3 * w->cond.cmax * w->cond.Tc * 17 + CE_THREADS) * 4;
-    LDS_LIMIT(&cond_encode_kernel, (size_t)160 * 1024);
-    hipLaunchKernelGGL(cond_encode_kernel, dim3(n_windows), dim3(CE_THREADS), lds, (hipStream_t)stream, w->cond, cond_data, emb_out, n_windows);
-    HIP_TRY(hipGetLastError());
-    return MCD_OK;
+    if (w->cond.gmode) return fail(MCD_EUNSUPPORTED, "mcd_cond_encode: this many condition frames need scratch memory; use mcd_score");
+    return launch_cond_plain(w, cond_data, n_windows, emb_out, nullptr, (hipStream_t)stream);
 }
 
 int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table, int32_t t,
@@ -4598,6 +4619,7 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
         if (g3 > gen) gen = g3;
     }
     if (w->cond_unet) { const int64_t g2 = gen_scratch_bytes(cfg->n_windows, w->cond.Tc); if (g2 > gen) gen = g2; }
+    { const int64_t g4 = cond_plain_scratch_bytes(w, cfg->n_windows); if (g4 > gen) gen = g4; }
     return ws_cond_bytes(w, cfg->n_windows) + ws_loss_bytes(cfg->n_windows, cfg->n_samples) + gen;
 }
 
@@ -4745,7 +4767,7 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
         hipLaunchKernelGGL(gather_frames_kernel, dim3((total + 255) / 256), dim3(256), 0, st, P.dv, cbuf, B, C0, cfg->seg_len,
                            17, Tc, fi);
         HIP_TRY(hipGetLastError());
-        int rc = mcd_cond_encode(w, cbuf, B, emb, stream);
+        int rc = launch_cond_plain(w, cbuf, B, emb, gen_scratch, st);
         if (rc != MCD_OK) return rc;
         P.cond_emb = emb;
     }

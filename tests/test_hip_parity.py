@@ -236,7 +236,9 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     ("inject", 4, 2, "AE"), ("inject", 2, 2, "E_unet"), ("concat", 2, [0], "AE"), ("no_condition", 1, None, "AE"),
     # 13 .. 32 U-Net frames: the slab-tiled MFMA kernel (frame count padded to 16 / 24 / 32), cross-checked with the plain-FMA kernel
     ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE"), ("concat", 13, [0, 1, 2], "AE"), ("inject", 26, 2, "E_unet"),
-    ("concat", 20, [0, 1], "AE"), ("inbetween_imp", 30, 3, "AE"), ("no_condition", 17, None, "AE"), ("concat", 32, [28, 29, 30, 31], "AE")])
+    ("concat", 20, [0, 1], "AE"), ("inbetween_imp", 30, 3, "AE"), ("no_condition", 17, None, "AE"), ("concat", 32, [28, 29, 30, 31], "AE"),
+    # 26 .. 31 condition frames: the plain condition encoder with one of its three activation buffers in global scratch
+    ("inject", 32, list(range(28)), "AE"), ("inject", 30, list(range(4, 30)), "AE"), ("inject", 32, list(range(31)), "E_unet")])
 def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 1, 2, 4, 5, 7 .. 11 frames on the
     specialised kernels (seg_len 10 split 5 + 5, seg_len 20 split 10 + 10, concat over 10 frames, a 1-frame window, ...); 13 .. 32

@@ -56,15 +56,11 @@ def _draw_long(seed):
         arch = r.choice(["AE", "AE", "E", "E_unet"])
         if arch == "E":
             channels, h_dim = [r.choice([8, 24]) for _ in range(r.choice([1, 2]))], r.choice([8, 16])
-        elif arch == "AE" and seg_len > 24:
-            seg_len = 24          # (the plain AE encoder keeps 3 x 32 channels of all condition frames in LDS: <= 25 frames)
     if strategy in ("inject", "concat"):
         if r.random() < 0.4:
             ci = r.choice([2, 3, 4])
         else:
             k = r.randint(1, seg_len - 1)
-            if strategy == "inject" and arch == "AE":
-                k = min(k, 24)
             ci = list(range(k)) if r.random() < 0.6 else list(range(seg_len - k, seg_len))
     elif strategy == "no_condition":
         ci = None
