@@ -2417,11 +2417,11 @@ __global__ void aggregate_kernel(const AggrParams P) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Runtime-shape fallback of the trajectory kernel: ANY U-Net frame count 1..MCD_MAX_FRAMES (the reference is generic in
+// Runtime-shape form of the trajectory kernel: ANY U-Net frame count 1..MCD_MAX_FRAMES (the reference is generic in
 // n_frames, mocodad.py:780-796, stsgcn.py:134-141), every strategy.  Plain fp32 FMAs, one 256-thread workgroup per chain
-// at a time (persistent grid), activations [channel][frame][joint] in a per-workgroup global scratch slab (they do not fit
-// LDS beyond ~12 frames).  Correct, not fast: the specialised score_kernel<T,...> instantiations are the product path for
-// 3, 4, 6, 8 and 12 frames; this one removes MCD_EUNSUPPORTED for everything else and cross-checks them in the tests.
+// at a time (persistent grid), activations [channel][frame][joint] in a per-workgroup global scratch slab.  Correct, not fast,
+// and since round 3 off every default path (score_kernel<T,...> covers 1 .. 12 frames, score_tiled_kernel 13 .. 32): it is the
+// independent implementation MCD_OPT_GENERIC_UNET switches to, which the tests compare the MFMA kernels with.
 // Same noise keys, same update, same loss as score_kernel.
 // ------------------------------------------------------------------------------------------------
 struct GLayer { int cin, cout, V, tq, am, wt, wr, bias, embo; float slope; };    // wr < 0: identity residual; embo < 0: no embedding
