@@ -292,8 +292,6 @@ def main():
                     help="weak: every GPU scores --batch windows per step; strong: --batch windows per step are split over the GPUs")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams consecutive batches alternate over (2: the ramp of "
                     "batch i+1 fills the tail of batch i, +2 %%; per-launch durations then overlap, so the default keeps 1)")
-    ap.add_argument("--bf16x3", action="store_true", help="OPT-IN, not the headline: channel GEMMs on the bf16 matrix path with both "
-                    "operands split into bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate; scores within ~1e-6 of the fp32 path)")
     ap.add_argument("--split", type=int, default=0, help="tuning / A-B: workgroups per window group (0 = library's choice; 1 = one "
                     "launch with encoder and aggregation inside; n_samples = one trajectory per workgroup, 3 launches)")
     ap.add_argument("--variant", type=int, default=0, help="tuning / A-B: alternative workgroup shape of the trajectory kernel (MCD_OPT_VARIANT)")
@@ -321,9 +319,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
-    if world > ndev and args.dist_backend == "nccl":
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))      # ranks on THIS node (bench.py itself is single-node)
+    if local_world > ndev and args.dist_backend == "nccl":
         # RCCL refuses two ranks on one GPU (and would otherwise hang in its bootstrap)
-        print(f"bench.py: {world} ranks but {ndev} GPU(s) visible; one rank per GPU is required with the nccl backend", file=sys.stderr)
+        print(f"bench.py: {local_world} ranks on this node but {ndev} GPU(s) visible; one rank per GPU is required with the nccl backend", file=sys.stderr)
         sys.exit(2)
     dev_index = local_rank % ndev          # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
     torch.cuda.set_device(dev_index)
@@ -350,7 +349,7 @@ def main():
     ci, xi = frame_split(seg_len, cfg["conditioning_indices"], strat)
     sc = HipScorer(sd, strategy=strat, seg_len=seg_len, cond_idx=ci, corrupt_idx=xi,
                    cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], cond_unet=cfg.get("conditioning_architecture") == "E_unet",
-                   device=dev, options=dict({"bf16x3": 1} if args.bf16x3 else {}, split=args.split, phase=args.phase, variant=args.variant,
+                   device=dev, options=dict(split=args.split, phase=args.phase, variant=args.variant,
                                 **({"cond_generic": 1} if args.cond_generic else {})))
     if args.scaling == "weak":
         # every rank owns its own shard of B windows per step (global window ids keep the Philox streams distinct and
@@ -450,10 +449,10 @@ def main():
         P = S * (ns - 1)
         flop_per_window = P * f_unet(sc.t_unet) + (f_cond(sc.t_cond) if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
-        pmc = None if args.bf16x3 else pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
+        pmc = pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
         nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,2,2", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2", 1: "1,4,4", 2: "2,3,4"}.get(sc.t_unet)
         tiled = nb is None         # 13 .. 32 U-Net frames: the slab-tiled kernel, frame count padded to 16 (two chains per workgroup) / 24 / 32
-        kname = f"score_kernel<{nb}{',bf16x3' if args.bf16x3 else ''}>" if nb else \
+        kname = f"score_kernel<{nb}>" if nb else \
             "score_tiled_kernel<%s> (T_u=%d)" % ("16,2" if sc.t_unet <= 16 else "24,1" if sc.t_unet <= 24 else "32,1", sc.t_unet)
         enc = "" if strat != "inject" else (" + cond_unet_generic_kernel" if cfg.get("conditioning_architecture") == "E_unet" else " + cond_encode_kernel") if sc.t_cond > 12 \
             else (f" + cond_unet_kernel<{sc.t_cond}>" if cfg.get("conditioning_architecture") == "E_unet" else f" + cond_fast_kernel<{sc.t_cond}>")
@@ -468,7 +467,7 @@ def main():
             "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
             "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "bf16x3 split operands, f32 accumulate (opt-in)" if args.bf16x3 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{desc}, noise_steps={ns}, {S} generated samples, {strat} conditioning, 'best' aggregation",
                        "name": args.config, "windows_per_step_per_gpu": B if args.scaling == "weak" else None,
                        "windows_per_step_total": B_total, "denoiser_passes_per_window": P,
@@ -506,10 +505,8 @@ def main():
             out["ref_value_1gpu"] = args.ref_value
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, ns, S, args.cpu_budget)
-        if world == 1 and not use_dist and not args.no_extras and not args.bf16x3:
+        if world == 1 and not use_dist and not args.no_extras:
             # informational only (never `value`): the same steps fed from pinned HOST windows, the H2D copy inside the timed loop
-            # (the opt-in split-bf16 GEMM path is no longer part of the default line: its own fp64 study puts the 3-term split
-            # outside 1e-4 on trained-scale weights -- `--bf16x3` still measures it, separately labelled)
             n_x = min(args.steps, 10)
             pinned = data_host.pin_memory()
             run(sc, 2, 300, src=pinned)

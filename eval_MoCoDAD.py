@@ -30,8 +30,6 @@ def main():
     ap.add_argument("-c", "--config", type=str, required=True)
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic clips instead of dataset files")
     ap.add_argument("--frames-per-clip", type=int, default=200)
-    ap.add_argument("--bf16x3", action="store_true", help="OPT-IN split-bf16 channel GEMMs (default shape only; scores within "
-                    "~2e-6 of the fp32 path, DESIGN.md 3.1); the default computes in fp32")
     ap.add_argument("--device-windows", action="store_true",
                     help="upload per-person trajectories once and let the kernels window + transform them on load "
                          "(instead of materialising seg_len x num_transform copies on the host)")
@@ -48,10 +46,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
-    if world > ndev and cli.dist_backend == "nccl":
+    # ranks on THIS node (torchrun exports LOCAL_WORLD_SIZE; a multi-node job has world > ndev with one GPU per rank)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > ndev and cli.dist_backend == "nccl":
         # RCCL refuses two ranks on one GPU (and would otherwise hang in its bootstrap)
-        raise SystemExit(f"eval_MoCoDAD.py: {world} ranks but {ndev} GPU(s) visible; the nccl backend needs one rank per GPU "
-                         "(--dist-backend gloo is for tests that share a GPU)")
+        raise SystemExit(f"eval_MoCoDAD.py: {local_world} ranks on this node but {ndev} GPU(s) visible; the nccl backend needs one "
+                         "rank per GPU (--dist-backend gloo is for tests that share a GPU)")
     local = local % ndev   # (several ranks per GPU only in the 1-GPU tests, with --dist-backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
@@ -100,8 +100,6 @@ def main():
         model.shard = shard
     model.save_tensors = False
     import sklearn.metrics  # noqa: F401  (imported here, not inside the timed region: ~0.3 s on first use)
-    if cli.bf16x3:
-        model.hip_options = {"bf16x3": 1}
     t0 = time.perf_counter()
     model.on_test_epoch_start()
     with torch.no_grad():

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MCD_ABI_VERSION 3
+#define MCD_ABI_VERSION 4
 
 enum {
     MCD_OK = 0,
@@ -143,9 +143,6 @@ int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* Per-handle options (no environment variables; the only process-wide state is mcd_debug_set_prof's pointer).  Set them before the calls they affect, from the
  * thread that owns the handle; none is needed for normal use.
- *   MCD_OPT_BF16X3        1: channel GEMMs (3, 6 or 12 U-Net frames) on the bf16 matrix path with both operands split into
- *                         bf16 pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate).  OPT-IN, off by default: the shipped, measured
- *                         path computes in fp32.
  *   MCD_OPT_VARIANT       alternative workgroup shapes of the trajectory kernel (tuning experiments only).
  *   MCD_OPT_COND_GENERIC  1: run the condition encoder through the runtime-channel-list kernel even when the shipped
  *                         architecture's MFMA kernel applies (used by the tests to cover both).
@@ -155,9 +152,9 @@ int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
  *                         runs all samples of its windows: condition encoder and aggregation fused into the ONE launch;
  *                         n_samples = one trajectory per workgroup, better fill for odd batch sizes); n > 0 forces it
  *                         (tests). */
-enum { MCD_OPT_BF16X3 = 0, MCD_OPT_VARIANT = 1, MCD_OPT_COND_GENERIC = 2, MCD_OPT_GENERIC_UNET = 3, MCD_OPT_SPLIT = 4,
-       MCD_OPT_PHASE = 5, /* tuning experiment: start the second half of the grid `value` x 1024 clock cycles late */
-       MCD_OPT_COUNT = 6 };
+enum { MCD_OPT_VARIANT = 0, MCD_OPT_COND_GENERIC = 1, MCD_OPT_GENERIC_UNET = 2, MCD_OPT_SPLIT = 3,
+       MCD_OPT_PHASE = 4, /* tuning experiment: start the second half of the grid `value` x 1024 clock cycles late */
+       MCD_OPT_COUNT = 5 };
 int mcd_set_option(mcd_weights_t* w, int32_t option, int32_t value);
 
 /* Replaces: the hot loop of MoCoDAD.forward (mocodad.py:155-180) + the per-sample loss of :484.

@@ -13,8 +13,8 @@ STRATEGY = {"inject": 0, "concat": 1, "no_condition": 2, "inbetween_imp": 3, "ra
 LOSS = {"smooth_l1": 0, "l1": 1, "mse": 2}
 COND_UNET = -1  # MCD_COND_UNET
 AGGR = {"all": 0, "best": 1, "worst": 2, "mean": 3, "median": 4, "mean_pose": 5, "median_pose": 6, "quantile": 7}
-OPT = {"bf16x3": 0, "variant": 1, "cond_generic": 2, "generic_unet": 3, "split": 4, "phase": 5}     # MCD_OPT_*
-ABI_VERSION = 3
+OPT = {"variant": 0, "cond_generic": 1, "generic_unet": 2, "split": 3, "phase": 4}     # MCD_OPT_*
+ABI_VERSION = 4
 
 
 class Tensor(C.Structure):

@@ -1,0 +1,104 @@
+"""Builds libmocodad_hip.so for gfx950 from mocodad_amd/csrc: mcd_api.hip (C ABI, packers, dispatch, the runtime-shape kernels)
+plus mcd_inst.hip once per unit of kernel instantiations (csrc/mcd_instances.hpp), compiled in parallel and linked with hipcc.
+
+    python -m mocodad_amd.build                       # the shipped library (mocodad_amd/libmocodad_hip.so)
+    python -m mocodad_amd.build --profile             # + -DMCD_PROFILE -> libmocodad_hip_prof.so (tools/stage_profile.py)
+    python -m mocodad_amd.build --fast-t 3 -o /tmp/x.so -D MCD_STASH=0    # developer build: one trajectory kernel only
+
+Objects are cached under csrc/_obj/<tag>/ (git-ignored) and rebuilt when a source, the public header or the flag set is newer /
+different; the library is relinked when any object changed."""
+import argparse
+import concurrent.futures as cf
+import hashlib
+import os
+import re
+import subprocess
+import sys
+import time
+from typing import Iterable, List, Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HEADER = os.path.join(ROOT, "include", "mocodad_hip.h")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+DEFAULT_OUT = os.path.join(HERE, "libmocodad_hip.so")
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+
+
+def n_units() -> int:
+    txt = open(os.path.join(CSRC, "mcd_instances.hpp")).read()
+    return int(re.search(r"#define\s+MCD_INST_UNITS\s+(\d+)", txt).group(1))
+
+
+def sources() -> List[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [HEADER]
+
+
+def _run(cmd: List[str]) -> float:
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + p.stdout[-8000:])
+    if p.stdout.strip():
+        print(p.stdout, file=sys.stderr)
+    return time.perf_counter() - t0
+
+
+def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_flags: Iterable[str] = (), force: bool = False,
+                  jobs: Optional[int] = None, obj_dir: Optional[str] = None, verbose: bool = True) -> bool:
+    """Compile + link; returns True when anything was rebuilt.  `defines`: "NAME" or "NAME=VALUE" strings."""
+    defines = list(defines)
+    flags = BASE_FLAGS + ["-D" + d for d in defines] + list(extra_flags)
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    obj_dir = obj_dir or os.path.join(CSRC, "_obj", tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    newest_src = max(os.path.getmtime(p) for p in sources())
+    fast = any(d.split("=")[0] == "MCD_FAST_T" for d in defines)
+    units = [1] if fast else list(range(1, n_units() + 1))
+    jobs_l = [("mcd_api.o", os.path.join(CSRC, "mcd_api.hip"), [])]
+    jobs_l += [(f"mcd_inst_{u}.o", os.path.join(CSRC, "mcd_inst.hip"), [f"-DMCD_INST_UNIT={u}"]) for u in units]
+    todo = [(o, s, f) for o, s, f in jobs_l
+            if force or not os.path.exists(os.path.join(obj_dir, o)) or os.path.getmtime(os.path.join(obj_dir, o)) < newest_src]
+    t0 = time.perf_counter()
+    if todo:
+        workers = jobs or min(len(todo), os.cpu_count() or 4)
+        if verbose:
+            print(f"+ {HIPCC} {' '.join(flags)} -c  x {len(todo)} translation units, {workers} at a time", flush=True)
+        with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+            futs = {ex.submit(_run, [HIPCC] + flags + f + ["-c", s, "-o", os.path.join(obj_dir, o)]): o for o, s, f in todo}
+            for fu in cf.as_completed(futs):
+                dt = fu.result()
+                if verbose:
+                    print(f"  {futs[fu]:16s} {dt:6.1f} s", flush=True)
+    objs = [os.path.join(obj_dir, o) for o, _, _ in jobs_l]
+    relink = bool(todo) or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(o) for o in objs)
+    if relink:
+        tmp = out + ".tmp%d" % os.getpid()
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+        os.replace(tmp, out)        # (atomic: a concurrent reader never maps a half-written library)
+        if verbose:
+            print(f"+ linked {os.path.relpath(out, ROOT)}  ({time.perf_counter() - t0:.1f} s)", flush=True)
+    return relink
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("-o", "--out", default=None)
+    ap.add_argument("-D", dest="defines", action="append", default=[], help="extra macro (NAME or NAME=VALUE)")
+    ap.add_argument("--profile", action="store_true", help="-DMCD_PROFILE build (default output: libmocodad_hip_prof.so)")
+    ap.add_argument("--fast-t", type=int, default=None, help="developer build holding only score_kernel<T, ...> (+ its encoders)")
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", "--jobs", type=int, default=None)
+    a = ap.parse_args()
+    defs = list(a.defines)
+    if a.profile:
+        defs.append("MCD_PROFILE")
+    if a.fast_t is not None:
+        defs.append(f"MCD_FAST_T={a.fast_t}")
+    out = a.out or (os.path.join(HERE, "libmocodad_hip_prof.so") if a.profile else DEFAULT_OUT)
+    build_library(out, defs, force=a.force, jobs=a.jobs)
+
+
+if __name__ == "__main__":
+    main()

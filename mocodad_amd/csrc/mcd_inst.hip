@@ -1,0 +1,98 @@
+// mcd_inst.hip — one unit of kernel instantiations (see mcd_instances.hpp); compiled with -DMCD_INST_UNIT=1 .. MCD_INST_UNITS.
+#include "mcd_launch.hpp"
+
+#ifndef MCD_INST_UNIT
+#error "compile with -DMCD_INST_UNIT=<n> (mocodad_amd/build.py does)"
+#endif
+
+#define MCD_UNIT_IS(n) (MCD_INST_UNIT == n)
+#if MCD_UNIT_IS(1)
+#define MCD_U1(...) __VA_ARGS__
+#else
+#define MCD_U1(...)
+#endif
+#if MCD_UNIT_IS(2)
+#define MCD_U2(...) __VA_ARGS__
+#else
+#define MCD_U2(...)
+#endif
+#if MCD_UNIT_IS(3)
+#define MCD_U3(...) __VA_ARGS__
+#else
+#define MCD_U3(...)
+#endif
+#if MCD_UNIT_IS(4)
+#define MCD_U4(...) __VA_ARGS__
+#else
+#define MCD_U4(...)
+#endif
+#if MCD_UNIT_IS(5)
+#define MCD_U5(...) __VA_ARGS__
+#else
+#define MCD_U5(...)
+#endif
+#if MCD_UNIT_IS(6)
+#define MCD_U6(...) __VA_ARGS__
+#else
+#define MCD_U6(...)
+#endif
+#if MCD_UNIT_IS(7)
+#define MCD_U7(...) __VA_ARGS__
+#else
+#define MCD_U7(...)
+#endif
+#if MCD_UNIT_IS(8)
+#define MCD_U8(...) __VA_ARGS__
+#else
+#define MCD_U8(...)
+#endif
+#if MCD_UNIT_IS(9)
+#define MCD_U9(...) __VA_ARGS__
+#else
+#define MCD_U9(...)
+#endif
+#if MCD_UNIT_IS(10)
+#define MCD_U10(...) __VA_ARGS__
+#else
+#define MCD_U10(...)
+#endif
+#if MCD_UNIT_IS(11)
+#define MCD_U11(...) __VA_ARGS__
+#else
+#define MCD_U11(...)
+#endif
+#if MCD_UNIT_IS(12)
+#define MCD_U12(...) __VA_ARGS__
+#else
+#define MCD_U12(...)
+#endif
+#if MCD_INST_UNITS != 12
+#error "add the MCD_U<n> selectors of the new units"
+#endif
+
+namespace mcd {
+
+#ifdef MCD_FAST_T       // developer builds (see mcd_api.hip): unit 1 holds the one trajectory kernel and its encoders, the rest is empty
+#if MCD_UNIT_IS(1)
+template int launch_score_t<MCD_FAST_T, MCD_FAST_NB, MCD_FAST_MINW, false>(ScoreParams&, hipStream_t, bool*);
+template int launch_cond_fast_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
+template int launch_cond_unet_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
+#ifdef MCD_FAST_TILED
+template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED)>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+#endif
+#endif
+#else
+#define MCD_DEF_SCORE(unit, T, NB, MINW, LT) MCD_U##unit(template int launch_score_t<T, NB, MINW, LT>(ScoreParams&, hipStream_t, bool*);)
+#define MCD_DEF_COND_FAST(unit, T, NB) \
+    MCD_U##unit(template int launch_cond_fast_t<T, NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);)
+#define MCD_DEF_COND_UNET(unit, T, NB) \
+    MCD_U##unit(template int launch_cond_unet_t<T, NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);)
+#define MCD_DEF_TILED(unit, TP, NB) \
+    MCD_U##unit(template int launch_score_tiled_t<TP, NB>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);)
+MCD_SCORE_INSTANCES(MCD_DEF_SCORE)
+MCD_COND_FAST_INSTANCES(MCD_DEF_COND_FAST)
+MCD_COND_UNET_INSTANCES(MCD_DEF_COND_UNET)
+MCD_TILED_INSTANCES(MCD_DEF_TILED)
+#endif
+
+}  // namespace mcd

@@ -1,0 +1,38 @@
+// mcd_instances.hpp — every kernel instantiation of libmocodad_hip.so and the translation unit that holds it.
+//
+// The library is built from mcd_api.hip (C ABI, packers, dispatch, the runtime-shape kernels) plus mcd_inst.hip compiled once
+// per unit with -DMCD_INST_UNIT=<n>: a unit explicitly instantiates the launcher templates of its rows (and with them the
+// kernels); every other translation unit sees them as `extern template` and compiles none of that device code.  The units
+// build in parallel (mocodad_amd/build.py); their number and the assignment below only balance compile times.
+//   X(unit, T_u, NB, MINW, LT)   score_kernel<T_u, NB, MINW, LT>      (LT: the layer-test form behind mcd_layer_forward)
+//   X(unit, T_c, NB)             cond_fast_kernel / cond_unet_kernel<T_c, NB>
+//   X(unit, TP, NB)              score_tiled_kernel<TP, NB>
+#pragma once
+
+#define MCD_INST_UNITS 12
+
+#ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only
+#define MCD_SCORE_VARIANT_INSTANCES(X) X(1, 3, 4, 2, false) X(1, 3, 1, 4, false) X(1, 3, 2, 2, false) X(2, 6, 2, 2, false)
+#else
+#define MCD_SCORE_VARIANT_INSTANCES(X)
+#endif
+
+#define MCD_SCORE_INSTANCES(X) \
+    X(1, 3, 2, 4, false)  /* HR-Avenue / HR-STC: 2 chains per workgroup, 2 workgroups per CU (<= 128 VGPRs) */ \
+    X(1, 1, 4, 4, false) X(1, 2, 3, 4, false) \
+    X(2, 6, 1, 4, false)  /* concat over 6 frames */ \
+    X(2, 4, 1, 4, false) \
+    X(3, 12, 1, 2, false) /* seg_len 24 split in halves: 1 workgroup per CU, no register cap */ \
+    X(3, 8, 1, 2, false) \
+    X(4, 5, 2, 2, false) X(4, 10, 1, 2, false) X(4, 7, 1, 2, false) \
+    X(5, 9, 1, 2, false) X(5, 11, 1, 2, false) \
+    X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \
+    MCD_SCORE_VARIANT_INSTANCES(X)
+
+#define MCD_COND_FAST_INSTANCES(X) \
+    X(7, 1, 4) X(7, 2, 3) X(7, 3, 2) X(7, 4, 2) X(7, 5, 2) X(7, 6, 2) X(7, 7, 1) X(7, 8, 1) X(7, 9, 1) X(7, 10, 1) X(7, 11, 1) X(7, 12, 1)
+
+#define MCD_COND_UNET_INSTANCES(X) \
+    X(8, 1, 4) X(8, 2, 3) X(8, 3, 2) X(8, 4, 2) X(8, 5, 2) X(8, 6, 1) X(8, 7, 1) X(10, 8, 1) X(10, 9, 1) X(10, 10, 1) X(10, 11, 1) X(10, 12, 1)
+
+#define MCD_TILED_INSTANCES(X) X(6, 16, 2) X(11, 24, 1) X(12, 32, 1)

@@ -1,0 +1,894 @@
+// mcd_tiled_kernel.hpp — score_tiled_kernel<TP, NB>: the MFMA trajectory kernel of 13 .. 32 U-Net frames.
+#pragma once
+#include "mcd_device.hpp"
+
+namespace mcd {
+
+// ------------------------------------------------------------------------------------------------
+// MFMA path for 12 < T_u <= 32 U-Net frames (concat over 24 frames, 16 + 16, ...): the activations of such a chain do not
+// fit LDS (257 KB at layer 5 of a 24-frame chain), so the chain lives in a slab of global memory (L2 / Infinity Cache) and a
+// layer is "32 input channels of ALL frames -> LDS -> mix -> channel GEMM -> slab", one 512-thread workgroup per CU:
+//   X      one 32-channel part of the layer's input, every frame, staged slab -> registers -> LDS (the next part's loads in
+//          flight behind this part's stages).  The four joint resamplers are not stages of their own: the layer behind one
+//          builds its X from the resampler's input rows (chunk of frames by chunk, resample_stage LDS -> LDS, + the U-Net skip)
+//   mix    both halves on the matrix cores: tl_time_mix (the (frames x frames) time mix of a joint as one MFMA product, Tq
+//          pre-packed as A fragments) writes Y to LDS, tl_joint_mix turns it into z in place.  z never leaves LDS
+//   GEMM   gemm_part: z . W_t + x . W_r (or + x) of the part into register accumulators (<= 80 per lane); layers with 64 or
+//          128 input channels sum their 2 or 4 parts there; one epilogue (bias, PReLU, embedding) -> slab
+//   layers at 17 joints (32 input channels, X = 78 KB at 32 frames) take their frames in two groups so that X + z fit
+//   layer 6 runs mix-first here (the specialised kernels run it W-first); layer 10 W-first on plain FMAs + mix_long
+//   hand-overs: no layer waits for the slab.  A layer's epilogue writes what the next layer reads first straight into LDS --
+//          its first 32-channel part (3->4, 5->6, 7->8; the whole output across the 17-joint layers 0->1->2, 9->10, group 0's
+//          accumulators held back until group 1's time mix has read the old rows), or the next layer's resampler input (all of
+//          channels 0..31: 4->5, 6->7; its first chunk: 2->3, 8->9).  The slab keeps the later parts and the skips d1 / d2
+// The frame count is padded to TP = 16, 24 or 32 with zero mixing coefficients (a padded frame's activations are finite
+// garbage that no real frame ever reads); two 16-frame chains share a workgroup (<16, 2>: the stage lengths of 32 frames).
+// Same noise keys, update, loss and strategies as score_kernel.  Slab traffic: 9 k floats per frame and pass (the first
+// version, every stage through the slab: 37 k -- it ran at the HBM / fabric roofline, 4.6 TB/s, profiles/README.md).
+// ------------------------------------------------------------------------------------------------
+struct TiledNet {
+    int tq[NLAYERS], am[NLAYERS], wp[NLAYERS], bias[NLAYERS];
+    int tqm[NLAYERS];    // time-mix coefficients as MFMA A fragments (tl_time_mix): [joint][frame tile][k-step][lane]
+    float slope[NLAYERS];
+    int rsw[4];          // joint resamplers, non-capture fragment packs (RsCoef chunks: fragments then bias)
+    int we, be;
+};
+// frames per chunk of a fused joint resampler (its input rows of those frames pass through the z region): 16, 12 at 24 frames
+__host__ __device__ constexpr int tl_fc(int TP) { return TP == 24 ? 12 : 16; }
+__host__ __device__ constexpr int tl_ra_floats(int TP) {
+    // LDS work region of a layer: X (32 channels of all frames, + pad rows) and z (the same; half the frames at 17 joints).
+    // (A fused resampler's input chunk passes through the z region.)
+    return cmax((TP * 17 + 16 + TP * 17 / 2 + 16) * 36, 2 * (TP * 12 + 16) * 36);
+}
+__host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
+__host__ __device__ constexpr long long tl_slab_floats(int TP) {
+    // A0, A1 (ping-pong, up to 128 ch x 10 joints), the skips D1, D2 -- each with 16 rows of padding behind it
+    return (long long)2 * (TP * 10 + 16) * 132 + (long long)(TP * 17 + 16) * 36 + (long long)(TP * 12 + 16) * 68;
+}
+
+// cooperative copies between the slab and LDS, `ch` channels (multiple of 4) from channel ch0 of `rows` rows
+__device__ __forceinline__ void tl_g2l(float* dst, int ds, const float* src, int ss, int ch0, int ch, int rows) {
+    const int q = ch >> 2;
+    for (int u = threadIdx.x; u < rows * q; u += NTHREADS) {
+        const int r = u / q, c = (u - r * q) * 4;
+        *reinterpret_cast<float4*>(dst + r * ds + c) = load_global4(src + (size_t)r * ss + ch0 + c);
+    }
+}
+// slab -> LDS through registers, in two halves: issue() puts the global loads in flight (typically one stage ahead, so that
+// their L2 latency runs behind the stage's MFMAs), commit() writes them to LDS once the region is free
+template <int ROWS, int CH>
+struct TlStage {
+    static constexpr int Q = CH / 4, N = (ROWS * Q + NTHREADS - 1) / NTHREADS;
+    float4 v[N];
+    __device__ __forceinline__ void issue(int tid, const float* src, int ss, int ch0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (u < ROWS * Q) { const int r = u / Q, c = (u - r * Q) * 4; v[i] = load_global4(src + (size_t)r * ss + ch0 + c); }
+        }
+    }
+    __device__ __forceinline__ void commit(int tid, float* dst, int ds) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (u < ROWS * Q) { const int r = u / Q, c = (u - r * Q) * 4; *reinterpret_cast<float4*>(dst + r * ds + c) = v[i]; }
+        }
+    }
+};
+
+// zero start of a mix's accumulators: the 4-joint fragment form and the single-joint form (joint 16 of the V = 17 layers)
+struct ZeroInitL {
+    __device__ __forceinline__ f32x4 operator()(int, int, int, std::true_type) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ float operator()(int, int, int) const { return 0.f; }
+};
+// mix of CINV (16 or 32) channels over ALL TP frames: X (LDS, [frame * V + joint][channel], stride cs) -> store functor.
+// unit = (16-channel block, QC output frames); joint mix on the matrix cores exactly as in mix_stage, the time mix as
+// tm_step groups over one k-step's TP input frames at a time.
+template <int CINV, int V, int TP, int NB = 1>
+struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's QC output frames (NB chains of TP frames each)
+    static constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
+    static constexpr int UNITS = CB * NB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
+    float tq[QC][NR], aop[QC][MT][KS];
+    // u: unit index in the flat list of CB x (NB * NQ) units (clamped: waves without a unit fetch the last one's)
+    __device__ __forceinline__ void load(const float* tqd, const float* af, int u, int lane) {
+        gfloat* tqd_g = as_global(tqd);
+        gfloat* af_g = as_global(af);
+        const int q0 = (((u < UNITS ? u : UNITS - 1) / CB) % NQ) * QC;
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) tq[qi][r] = tqd_g[((q0 + qi) * NR + r) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) aop[qi][mt][ks] = af_g[(((q0 + qi) * MT + mt) * KS + ks) * 64 + lane];
+        }
+    }
+};
+// `first`: the coefficients of the wave's first unit, fetched by the caller before it waited for X to land in LDS
+// NGRP > 1: only the output frames of frame group `grp` (the flat frame list cut in NGRP equal parts) -- the caller's z region
+// holds one group at a time
+template <int CINV, int V, int TP, int NB, int NGRP = 1, class Init, class Store>
+__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP, NB>& first,
+                                         const float* __restrict__ tqd, const float* __restrict__ af,
+                                         int wave, int lane, Init&& init, Store&& store, int grp = 0) {
+    using MC = MixLongCoef<CINV, V, TP, NB>;
+    constexpr int QC = MC::QC, KS = MC::KS, KP = 2 * (KS / 2), MT = MC::MT, CB = MC::CB, NQ = MC::NQ;
+    static_assert((NB * NQ) % NGRP == 0, "frame groups hold whole mix units");
+    constexpr int UNITS = MC::UNITS / NGRP, PER = (UNITS + NWAVES - 1) / NWAVES;
+    constexpr bool J16 = V == 17;
+    constexpr int MTM = J16 ? 1 : MT;
+    const int j = lane & 15, g = lane >> 4;
+    static_for<PER>([&](auto rr) {
+        constexpr int rnd = decltype(rr)::value;
+        if (wave + rnd * NWAVES >= UNITS) return;
+        const int u = wave + rnd * NWAVES + (NGRP > 1 ? grp * UNITS : 0);
+        // (q0: first output frame of the unit in the flat list of NB * TP frames; its chain's frames start at row fo * V)
+        const int cb = u % CB, qg = u / CB, fo = NB > 1 ? (qg / NQ) * TP : 0, q0 = fo + (qg % NQ) * QC;
+        MC later;
+        if constexpr (rnd > 0) later.load(tqd, af, u, lane);        // (a second live set of 50 .. 80 registers for a prefetch does not fit)
+        const MC& cur = rnd > 0 ? later : first;
+        const auto& tq = cur.tq;
+        const auto& aop = cur.aop;
+        f32x4 acc[QC][MTM];
+        float part[QC];
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+            part[qi] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt) acc[qi][mt] = init(q0 + qi, mt * 16 + 4 * g, cb * 16 + j, std::true_type{});
+        }
+        const float* xin_p = X + __mul24(fo * V + 4 * (g & 1) + (g >> 1), cs) + cb * 16 + j;
+        const float* xin_l = X + __mul24(fo * V + g, cs) + cb * 16 + j;
+        static_for<KS>([&](auto si) {
+            constexpr int ks = decltype(si)::value;
+            constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
+            const float* xb = ks < KP ? xin_p : xin_l;
+            float x[TP];
+#pragma unroll
+            for (int t = 0; t < TP; ++t) x[t] = xb[(t * V + vbase) * cs];
+            __builtin_amdgcn_sched_barrier(0);
+            float y[QC];
+            static_for<TP>([&](auto ti) {
+                constexpr int t = decltype(ti)::value;
+                float c[QC];
+#pragma unroll
+                for (int qi = 0; qi < QC; ++qi) c[qi] = tq[qi][(ks * TP + t) / 16];
+                tm_step<QC, (ks * TP + t) % 16, t == 0, t == TP - 1>(y, c, x[t]);
+            });
+            static_for<QC>([&](auto qq) {
+                constexpr int qi = decltype(qq)::value;
+#pragma unroll
+                for (int mt = 0; mt < MTM; ++mt)
+                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[qi][mt][ks], y[qi], acc[qi][mt], 0, 0, 0);
+                if constexpr (J16) part[qi] = fmaf(aop[qi][1][ks], y[qi], part[qi]);
+            });
+        });
+#pragma unroll
+        for (int qi = 0; qi < QC; ++qi) {
+#pragma unroll
+            for (int mt = 0; mt < MTM; ++mt) store(q0 + qi, mt * 16 + 4 * g, cb * 16 + j, acc[qi][mt]);
+            if constexpr (J16) {
+                const unsigned pu = __float_as_uint(part[qi]);
+                const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+                const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                const float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                if (g == 0) store(q0 + qi, 16, cb * 16 + j, z16 + init(q0 + qi, 16, cb * 16 + j));
+            }
+        }
+    });
+}
+
+// The two halves of a layer's mix in the slab-tiled kernel, both on the matrix cores (at 16 .. 32 frames the time mix is a third
+// of the layer's multiply-adds: as DPP FMAs it was 40 % of the kernel).
+// (1) time mix  Y[q][v][c] = sum_t Tq[q][v][t] X[t][v][c]: per (joint v, 16-channel block, tile of 16 output frames) one
+//     (16 frames x TP frames) . (TP frames x 16 channels) product; A = the pre-packed Tq fragments (tl_tqm_floats), B = X read from
+//     LDS with the frame index on the k axis; the result rows (frames) go to Y[(frame * V + v)][channel] in LDS.
+// (2) joint mix, in place  Z[q][w][c] = sum_v A_q[v][w] Y[q][v][c]: per (frame, 16-channel block) the fragments of mix_stage,
+//     B = Y read from LDS; a unit has read all of its frame's Y when it writes Z over it.
+// NGRP: frame groups of the layer (the flat list of NB * TP frames in NGRP equal parts; Y / Z hold group `grp`).
+template <int TP, int NB, int NGRP>
+struct TlGroups {
+    static constexpr int FG = NB * TP / NGRP;                   // frames of a group
+    static constexpr int NCH = NB >= NGRP ? NB / NGRP : 1;      // chains a group spans
+    static constexpr int FGC = FG / NCH;                        // frames of a group in one chain
+    static constexpr int MTG = (FGC + 15) / 16;                 // 16-frame tiles of a group per chain
+    static constexpr int NTC = MTG * (TP / FGC);                // ... of a chain (table rows)
+    static constexpr int KT = TP / 4;
+};
+__host__ __device__ constexpr int tl_ngrp(int V) { return V == 17 ? 2 : 1; }
+// A unit of (1) is (joint v, chain of the group, frame tile): its Tq fragments serve all 16-channel blocks, and the next unit's
+// are fetched (L2) while this one runs; a unit of (2) is a frame, likewise.
+// (the FIRST unit's fragments come from the caller, who fetched them -- tl_time_fetch / tl_joint_fetch -- a stage earlier)
+// unit -> (v, tile, chain of the group): v fastest, so that the waves of a round read neighbouring rows
+template <int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_time_fetch(float (&a)[TP / 4], const float* __restrict__ tqm, int u, int lane, int grp) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int UNITS = V * G::NCH * G::MTG;
+    if (u >= UNITS) u = UNITS - 1;
+    const int v = u % V, m = (u / V) % G::MTG;
+    gfloat* ap = as_global(tqm) + ((v * G::NTC + (NB >= NGRP ? 0 : grp * G::MTG) + m) * G::KT) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < G::KT; ++ks) a[ks] = ap[ks * 64];
+}
+// The wave's first unit runs alone on coefficients the caller fetched a stage ahead; the others' coefficients are fetched in
+// front of it and those units then run together (their LDS reads, then their MFMA chains interleaved: with two waves per SIMD
+// a single unit's read -> 8 dependent MFMAs -> write sequence leaves the matrix pipe idle most of the time).
+template <int CINV, int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_time_mix(const float* __restrict__ X, int cs, float* __restrict__ Y, int csy,
+                                            const float* __restrict__ tqm, int wave, int lane, int grp, const float (&first)[TP / 4]) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int CB = CINV / 16, KT = G::KT, UNITS = V * G::NCH * G::MTG;
+    constexpr int PER = (UNITS + NWAVES - 1) / NWAVES, NR = PER > 1 ? PER - 1 : 1;
+    const int j = lane & 15, g = lane >> 4;
+    float ar[NR][KT];
+    if constexpr (PER > 1) {
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i) tl_time_fetch<V, TP, NB, NGRP>(ar[i], tqm, wave + (i + 1) * NWAVES, lane, grp);
+    }
+    // (all LDS reads of the wave's units first, the later units' behind the first one's: they run under its MFMAs.  The same
+    // order in tl_joint_mix costs registers the 16- and 32-frame kernels do not have: -1.2 % / +0.4 %, not taken)
+    struct Unit { int v, m, c; };
+    auto unit_of = [&](int r) {
+        const int u0 = wave + r * NWAVES, u = u0 < UNITS ? u0 : UNITS - 1;          // (a wave past the end repeats the last unit, unstored)
+        return Unit{u % V, (u / V) % G::MTG, u / (V * G::MTG)};
+    };
+    auto read_b = [&](const Unit& un, float (&b)[CB][KT]) {
+        const int chain = NB >= NGRP ? grp * G::NCH + un.c : 0;                      // chain of the flat frame list
+        const float* xp = X + __mul24((chain * TP + g) * V + un.v, cs) + j;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) b[cb][ks] = xp[ks * 4 * V * cs + cb * 16];
+    };
+    auto write_y = [&](int r, const Unit& un, const f32x4 (&acc)[CB]) {
+        if (wave + r * NWAVES >= UNITS) return;
+        const int fl = un.c * G::FGC + un.m * 16 + 4 * g;             // first of the lane's 4 output frames, group-local
+        float* yp = Y + __mul24(fl * V + un.v, csy) + j;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                if (G::FGC % 16 == 0 || un.m * 16 + 4 * g + r4 < G::FGC) yp[r4 * V * csy + cb * 16] = acc[cb][r4];
+    };
+    Unit u0 = unit_of(0), ur[NR];
+    float b0[CB][KT], br[NR][CB][KT];
+    read_b(u0, b0);
+    if constexpr (PER > 1) {
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i) { ur[i] = unit_of(i + 1); read_b(ur[i], br[i]); }
+    }
+    f32x4 acc0[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc0[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(first[ks], b0[cb][ks], acc0[cb], 0, 0, 0);
+    write_y(0, u0, acc0);
+    if constexpr (PER > 1) {
+        f32x4 accr[NR][CB];
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) accr[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+            for (int i = 0; i < PER - 1; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) accr[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i][ks], br[i][cb][ks], accr[i][cb], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i) write_y(i + 1, ur[i], accr[i]);
+    }
+}
+template <int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_joint_fetch(float (&aop)[(V + 15) / 16][(V + 3) / 4], const float* __restrict__ af, int fl, int lane, int grp) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int KS = (V + 3) / 4, MT = (V + 15) / 16;
+    if (fl >= G::FG) fl = G::FG - 1;
+    const int q = (grp * G::FG + fl) % TP;               // the frame in its chain (the coefficient tables are per chain)
+    gfloat* af_g = as_global(af);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) aop[mt][ks] = af_g[((q * MT + mt) * KS + ks) * 64 + lane];
+}
+template <int CINV, int V, int TP, int NB, int NGRP>
+__device__ __forceinline__ void tl_joint_mix(float* __restrict__ YZ, int cs, const float* __restrict__ af, int wave, int lane, int grp,
+                                             const float (&first)[(V + 15) / 16][(V + 3) / 4]) {
+    using G = TlGroups<TP, NB, NGRP>;
+    constexpr int CB = CINV / 16, KS = (V + 3) / 4, KP = 2 * (KS / 2), MT = (V + 15) / 16;
+    constexpr bool J16 = V == 17;
+    constexpr int MTM = J16 ? 1 : MT;
+    constexpr int UNITS = G::FG, PER = (UNITS + NWAVES - 1) / NWAVES, NR = PER > 1 ? PER - 1 : 1;
+    const int j = lane & 15, g = lane >> 4;
+    const int vp = 4 * (g & 1) + (g >> 1);              // mix_vmap: joint of this lane group in a paired k-step
+    float ar[NR][MT][KS];
+    if constexpr (PER > 1) {
+#pragma unroll
+        for (int i = 0; i < PER - 1; ++i) tl_joint_fetch<V, TP, NB, NGRP>(ar[i], af, wave + (i + 1) * NWAVES, lane, grp);
+    }
+    auto run = [&](auto r0c, auto nic, const auto& aop) {
+        constexpr int r0 = decltype(r0c)::value, NI = decltype(nic)::value;
+        float y[NI][CB][KS];
+        f32x4 acc[NI][CB][MTM];
+        float part[NI][CB];
+        float* base[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f0 = wave + (r0 + i) * NWAVES, fl = f0 < UNITS ? f0 : UNITS - 1;       // frame of the group
+            base[i] = YZ + __mul24(fl * V, cs) + j;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                part[i][cb] = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MTM; ++mt) acc[i][cb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    y[i][cb][ks] = base[i][(ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + vp : 4 * KP + g) * cs + cb * 16];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                    for (int mt = 0; mt < MTM; ++mt)
+                        acc[i][cb][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[i][mt][ks], y[i][cb][ks], acc[i][cb][mt], 0, 0, 0);
+                    if constexpr (J16) part[i][cb] = fmaf(aop[i][1][ks], y[i][cb][ks], part[i][cb]);
+                }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (wave + (r0 + i) * NWAVES >= UNITS) continue;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                for (int mt = 0; mt < MTM; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mt * 16 + 4 * g + r < V) base[i][(mt * 16 + 4 * g + r) * cs + cb * 16] = acc[i][cb][mt][r];
+                if constexpr (J16) {      // joint 16: the four lane groups' partial sums (see mix_long)
+                    const unsigned pu = __float_as_uint(part[i][cb]);
+                    const auto h = __builtin_amdgcn_permlane32_swap(pu, pu, false, false);
+                    const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
+                    const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
+                    if (g == 0) base[i][16 * cs + cb * 16] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                }
+            }
+        }
+    };
+    const float (&f1)[1][MT][KS] = reinterpret_cast<const float (&)[1][MT][KS]>(first);
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f1);
+    if constexpr (PER > 1) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 1>{}, ar);
+}
+
+// partial channel GEMM of a layer of the slab-tiled kernel: acc[i] += A[O1 ..] . B1 (+ A[O2 ..] . B2) over this wave's n-tiles
+// (Tiling<MT, NT>), K = 16 KQ1 (+ 16 KQ2) channels of the LDS operands b1 / b2 ([col][ch]); two tiles' MFMA chains in flight
+// with their B fragments one read ahead, as in gemm_tiles.  The accumulators stay with the caller: a layer with 64 or 128
+// input channels sums its 32-channel halves into them and runs its epilogue once.
+template <int MT, int NT, int KQ1, int KQ2, int O1, int O2, int NA>
+__device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __restrict__ b1, int cs1, const float* __restrict__ b2,
+                                          int cs2, int wave, int lane, f32x4 (&acc)[Tiling<MT, NT>::MAXN]) {
+    constexpr int NG = Tiling<MT, NT>::NG, MAXN = Tiling<MT, NT>::MAXN, KQ = KQ1 + KQ2;
+    const int ng = MT > NWAVES ? 0 : wave / MT;
+    const int j = lane & 15, g = lane >> 4;
+    const float* const p1b = b1 + __mul24(ng * 16 + j, cs1) + 4 * g;
+    const float* const p2b = b2 + __mul24(ng * 16 + j, cs2) + 4 * g;
+    constexpr int NP = (MAXN + 1) / 2;
+    // first B fragment (k-group 0) of tile slot i -- read a pair ahead: the last k-group of a pair fetches the next pair's
+    auto rd0 = [&](int i) { return *reinterpret_cast<const float4*>((KQ1 > 0 ? p1b + i * NG * 16 * cs1 : p2b + i * NG * 16 * cs2)); };
+    float4 nxt[2];
+    auto prime = [&](auto pp) {
+        constexpr int p = decltype(pp)::value;
+        if constexpr (p < NP) {
+            constexpr int i0 = 2 * p, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
+            if (ng + i0 * NG < NT) nxt[0] = rd0(i0);
+            if (i1 != i0 && ng + i1 * NG < NT) nxt[1] = rd0(i1);
+        }
+    };
+    auto chain = [&](auto nn, auto pp, auto ia, auto ib) {
+        constexpr int N = decltype(nn)::value, p = decltype(pp)::value, i0 = decltype(ia)::value, i1 = decltype(ib)::value;
+        const float* p1[2] = {p1b + i0 * NG * 16 * cs1, p1b + i1 * NG * 16 * cs1};
+        const float* p2[2] = {p2b + i0 * NG * 16 * cs2, p2b + i1 * NG * 16 * cs2};
+        auto rd = [&](int h, auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            return *reinterpret_cast<const float4*>(kq < KQ1 ? p1[h] + kq * 16 : p2[h] + (kq - KQ1) * 16);
+        };
+        static_for<KQ>([&](auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            const float4 w = a[kq < KQ1 ? O1 + kq : O2 + kq - KQ1];
+            float4 u[2];
+#pragma unroll
+            for (int h = 0; h < N; ++h) u[h] = nxt[h];
+            if constexpr (kq + 1 < KQ) {
+#pragma unroll
+                for (int h = 0; h < N; ++h) nxt[h] = rd(h, std::integral_constant<int, kq + 1>{});
+            } else {
+                prime(std::integral_constant<int, p + 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4& c0 = acc[i0];
+            f32x4& c1 = acc[i1];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[0].x, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[1].x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, u[0].y, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, u[1].y, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, u[0].z, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, u[1].z, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, u[0].w, c0, 0, 0, 0);
+            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, u[1].w, c1, 0, 0, 0);
+        });
+    };
+    prime(std::integral_constant<int, 0>{});
+    static_for<NP>([&](auto pp) {
+        constexpr int i0 = 2 * decltype(pp)::value, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
+        using I0 = std::integral_constant<int, i0>;
+        using I1 = std::integral_constant<int, i1>;
+        if (i1 != i0 && ng + i1 * NG < NT) chain(std::integral_constant<int, 2>{}, pp, I0{}, I1{});
+        else if (ng + i0 * NG < NT) chain(std::integral_constant<int, 1>{}, pp, I0{}, I0{});
+    });
+}
+
+// profile builds (tools/tiled_stage_profile.py): lane 0 of waves 0 and 7 of workgroup 0 add the cycles since their previous
+// mark to slot 2048 (+ 64 for wave 7) + id of the profile buffer
+#ifdef MCD_PROFILE
+#define TLMARK(id) do { if (tl_prof) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    atomicAdd(P.prof + 2048 + (tid0 ? 64 : 0) + (id), t_ - tl_last); tl_last = t_; } } while (0)
+#else
+#define TLMARK(id) do { } while (0)
+#endif
+template <int TP, int NB>
+__global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
+                                                                  float* __restrict__ slabs) {
+    constexpr int TF = TP * NB;
+    constexpr int R17 = TF * 17, R12 = TF * 12, R10 = TF * 10;
+    constexpr int TL_FC = tl_fc(TF), NFC = TF / TL_FC;
+    static_assert(TP % TL_FC == 0, "a GEMM chunk lies inside one chain (its embedding rows are the chain's)");
+    constexpr int EMBS = EMB_TOTAL + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // LDS: work region RA (mix: 32 channels of all frames; GEMM: z chunk + x chunk), chain state XT[col][4] (+ pad), tables
+    constexpr int RA_F = tl_ra_floats(TF);
+    float* const RA = smem;
+    float* const XT = RA + RA_F;                    // [R17 + 16][4]
+    float* const EMB = XT + (R17 + 16) * 4;         // [NB][EMB_TOTAL + 4]
+    float* const SE = EMB + NB * EMBS;              // [NB][16]
+    float* const ZN = SE + NB * EDIM;               // [R17][2]  this step's noise
+    float* const ZO = ZN + R17 * C0;                // [R17][2]  layer 10's mixed output
+    float* const P4 = ZO + R17 * C0;                // [R17 + 16][4]  layer 10's W-first product (+ zero pad rows: its mix reads 16-channel blocks)
+    float* const RED = P4 + (R17 + 16) * 4;         // [NTHREADS]
+    const int tid0 = threadIdx.x;
+    int tid = tid0, lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* wb = P.wbuf;
+#ifdef MCD_PROFILE
+    const bool tl_prof = P.prof && blockIdx.x == 0 && (tid0 == 0 || tid0 == NTHREADS - 64);
+    unsigned long long tl_last = __builtin_readcyclecounter();
+#endif
+    float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TF);
+    const int Tx = P.n_corrupt, K = P.ns > 2 ? P.ns - 1 : 1, per = C0 * Tx * 17;
+    for (int u = tid; u < (int)tl_slab_floats(TF); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
+    for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
+    if (tid < 64) P4[R17 * 4 + tid] = 0.f;
+    for (int u = tid; u < RA_F; u += NTHREADS) RA[u] = 0.f;           // pad rows meet zero coefficients: they must be finite
+
+    for (long long grp = blockIdx.x; grp * NB < P.n_chains; grp += gridDim.x) {
+        // chain i of the group (the last group of an odd count runs its last chain twice and writes it once)
+        auto chain_of = [&](int i) { const long long c = grp * NB + i; return c < P.n_chains ? c : P.n_chains - 1; };
+        auto b_of = [&](int i) { return (int)(chain_of(i) / P.S); };
+        auto s_of = [&](int i) { return (int)(chain_of(i) % P.S); };
+        auto fixed_of = [&](int i) { return (unsigned)(P.win_mask ? P.win_mask[b_of(i)] : P.fixed_mask); };
+        auto tx_of = [&](unsigned fixed, int t) { return P.win_mask ? __popc(~fixed & ((1u << t) - 1u)) : M.tx_of[t]; };
+        auto src_of = [&](int t) { return P.win_mask ? t : M.src_frame[t]; };
+        __syncthreads();
+        for (int u = tid; u < NB * T * 17; u += NTHREADS) {
+            const int i = u / (T * 17), t = (u / 17) % T, v = u % 17;
+            const int b = b_of(i), s = s_of(i);
+            const unsigned fixed = fixed_of(i);
+#pragma unroll
+            for (int c = 0; c < C0; ++c) {
+                float x;
+                if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
+                else {
+                    const int e = (c * Tx + tx_of(fixed, t)) * 17 + v;
+                    x = P.noise ? P.noise[((size_t)(s * K + 0) * P.B + b) * per + e]
+                                : philox_normal(P.seed, (unsigned)e, 0u, (unsigned)s, (unsigned)(P.first_window + b));
+                }
+                XT[((i * TP + t) * 17 + v) * 4 + c] = x;
+            }
+        }
+        for (int sidx = P.ns - 1; sidx >= 1; --sidx) {
+            const float* srow = P.step_table + sidx * (4 + EDIM);
+            // opaque per step (see score_kernel): otherwise every per-lane address of every stage is hoisted out of the step
+            // loop as loop-invariant and the hundreds of resulting registers are spilled
+            tid = tid0;
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63;
+            wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            wb = P.wbuf;
+            asm volatile("" : "+s"(wb));
+            float* sl = slab;
+            asm volatile("" : "+s"(sl));
+            float* const A0 = sl;
+            float* const A1 = A0 + (R10 + 16) * 132;
+            float* const D1 = A1 + (R10 + 16) * 132;
+            float* const D2 = D1 + (R17 + 16) * 36;
+            __syncthreads();
+            if (tid < NB * EDIM) {
+                float e = srow[4 + tid % EDIM];
+                if (P.cond_emb) e += P.cond_emb[(size_t)b_of(tid / EDIM) * EDIM + tid % EDIM];
+                SE[tid] = e / (1.f + expf(-e));
+            }
+            if (sidx > 1) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
+                const int k = P.ns - sidx;
+                for (int gi = tid; gi < NB * T * 9; gi += NTHREADS) {
+                    const int i = gi / (T * 9), t = (gi / 9) % T, v0 = (gi % 9) * 2;
+                    const int b = b_of(i), s = s_of(i);
+                    const unsigned fixed = fixed_of(i);
+                    float z[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (!((fixed >> t) & 1u)) {
+                        const int tx = tx_of(fixed, t);
+                        if (P.noise) {
+                            const float* zp = P.noise + ((size_t)(s * K + k) * P.B + b) * per + tx * 17 + v0;
+                            z[0] = zp[0]; z[1] = zp[Tx * 17];
+                            if (v0 + 1 < 17) { z[2] = zp[1]; z[3] = zp[Tx * 17 + 1]; }
+                        } else {
+                            philox_normal4(P.seed, (unsigned)(tx * 9 + (v0 >> 1)), (unsigned)k, (unsigned)s, (unsigned)(P.first_window + b), z);
+                        }
+                    }
+                    float* zo = ZN + ((i * TP + t) * 17 + v0) * C0;
+                    zo[0] = z[0]; zo[1] = z[1];
+                    if (v0 + 1 < 17) { zo[2] = z[2]; zo[3] = z[3]; }
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
+                const int i = u / EMB_TOTAL, o = u % EMB_TOTAL;
+                const float* we = wb + N.we + o * EDIM;
+                float a = wb[N.be + o];
+#pragma unroll
+                for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[i * EDIM + k], a);
+                EMB[i * EMBS + o] = a;
+            }
+            __syncthreads();
+
+            // ---- one mix-first ST-GCN layer: xin (slab or XT) -> xout (slab).  Per 32-channel half of the input: X of ALL frames
+            // -> LDS, mix -> z in LDS (never in the slab), the half's share of the channel GEMM into register accumulators
+            // (z . W_t and x . W_r / + x); epilogue -> slab after the last half.  The layers at 17 joints (one half) take their
+            // frames in two groups, z holding one group at a time.
+            // RSI >= 0: the layer's input is joint resampler RSI applied to `xin` (+ `skip`): each 32-channel part of X is built in
+            // LDS from the resampler's input rows, chunk of frames by chunk -- the resampled tensor never exists in the slab
+            auto layer = [&](auto lc, auto rsc, const float* xin, bool xin_lds, float* xout, const float* skip) {
+                constexpr int L = decltype(lc)::value, RSI = decltype(rsc)::value;
+                constexpr int VIN = RSI == 0 ? 17 : RSI == 2 ? 10 : 12;      // joints of the resampler's input (down1, down2, up3, up2)
+                // LDS hand-over between two plain layers at the same joint count (3 -> 4, 5 -> 6, 7 -> 8): the first layer's epilogue
+                // writes output channels 0 .. 31 straight into the X region -- the second layer's first 32-channel part, which then
+                // never touches the slab (its load was the one nothing could hide: stores -> barrier -> loads, 3 - 4 us a layer)
+                constexpr bool HO = L == 3 || L == 5 || L == 7, HI = L == 4 || L == 6 || L == 8;
+                // ... and between the layers at 17 joints (0 -> 1 -> 2, 9 -> 10; one 32-channel part, two frame groups): the whole output
+                // goes to the X region, group 0's once group 1's time mix has read the old rows (its accumulators wait in registers)
+                constexpr bool HO17 = L == 0 || L == 1 || L == 9, HI17 = L == 1 || L == 2;
+                // ... and into a fused resampler (4 -> down2 -> 5, 6 -> up3 -> 7): output channels 0 .. 31 go where the next layer's
+                // resampler takes its input chunks from (that layer's z region), all frames at once
+                constexpr bool HOR = L == 4 || L == 6, HIR = L == 5 || L == 7;
+                constexpr int TNEXT = (TF * (L == 4 ? 10 : L == 8 ? 17 : 12) + 16) * 36;     // offset of the next layer's z region
+                // ... or only the resampler's FIRST chunk where all of it does not fit (2 -> down1 -> 3, 8 -> up2 -> 9); layer 2 keeps
+                // group 0's accumulators until both groups are through (the chunk's place is still its own X rows before)
+                constexpr bool HOC = L == 2 || L == 8, HIC = L == 3 || L == 9;
+                constexpr LDesc D = layer_desc(L);
+                constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
+                constexpr bool RES = D.res != 0;
+                constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSZ = cs_of(CINV);
+                constexpr int CSV = L == 0 ? 4 : L == 1 ? 36 : CSZ;    // layer 0 reads the chain state in place (see score_kernel); layer 1's
+                                                                       // X is layer 0's output, written with the 32-channel row stride
+                constexpr int ROWS = TF * V, FS = V == 17 ? 2 : 1, ROWSG = ROWS / FS;
+                static_assert(FS == 1 || NH == 1, "frame groups and channel halves are not combined");
+                static_assert(!HOR || TNEXT + TF * V * 36 <= RA_F, "the handed-over resampler input fits behind the next layer's X");
+                static_assert(!HOC || TNEXT + TL_FC * V * 36 <= RA_F, "the handed-over first chunk fits behind the next layer's X");
+                static_assert(COUT % 16 == 0 && ROWSG % (NB > 1 ? 1 : 1) == 0, "");
+                constexpr int MT = COUT / 16, NT = ceil16(ROWSG) / 16, KH = CINV / 16;
+                using TI = Tiling<MT, NT>;
+                static_assert(FS == tl_ngrp(V), "the packed time-mix tiles follow the frame groups");
+                // (thread / wave ids opaque per LAYER: the per-lane addresses of a layer's copies and tiles are invariant across
+                // its loops, and hoisted to the top of the pass for all eleven layers at once they spill)
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                float* const XA = RA;                                          // [ROWS + 16][CSV]
+                float* const ZA = RA + (ROWS + 16) * (L <= 1 ? 36 : CSZ);      // [ROWSG + 16][CSZ]  (layer 0: behind the next layer's X)
+                TlStage<ROWS, CINV> sx;                // plain input: a 32-channel part of all frames; resampled input: the skip rows
+                constexpr int IR = TL_FC * VIN, OR = TL_FC * V;
+                TlStage<RSI >= 0 ? IR : 1, 32> si;     // resampled input: a chunk of the resampler's input rows
+                RsCoef<32, VIN, V, TL_FC, 1, false> rc;
+                if constexpr (RSI >= 0) {
+                    static_assert(!HIR || NH >= 2, "");
+                    static_assert(!HIC || (NH == 1 && NFC == 2), "");
+                    if constexpr (HIC) si.issue(tid, xin + (size_t)IR * CSI, CSI, 0);      // (chunk 0 is in the z region already)
+                    else si.issue(tid, xin, CSI, HIR ? CINV : 0);   // (HIR: part 0 is in the z region already, all chunks of it)
+                    rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                    if (skip) sx.issue(tid, skip, CSI, 0);
+                } else if (!xin_lds && !HI17) {
+                    static_assert(!HI || (RSI < 0 && NH >= 2), "");
+                    sx.issue(tid, xin, CSI, HI ? CINV : 0);
+                }
+                float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
+                tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 0);
+                // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
+                constexpr bool AQ = NH > 2;
+                constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
+                const int mt = wave % MT, ng = MT > NWAVES ? 0 : wave / MT, c0 = mt * 16 + 4 * (lane >> 4);
+                LayerAfr<AQ ? 1 : KQA> A;
+                float4 aq[AQ ? 2 * KH : 1];
+                const float* wfr = wb + N.wp[L] + ((size_t)mt * KQA * 64 + lane) * 4;
+                if constexpr (!AQ) {
+                    LayerW lw;
+                    lw.wp = N.wp[L]; lw.bias = N.bias[L];
+                    A.template load<MT>(wb, lw, wave, lane);
+                } else {
+                    A.bcur = load_global4(wb + N.bias[L] + c0);
+                }
+                const float slope = N.slope[L], pinf = prelu_bound(slope);
+                f32x4 acc[TI::MAXN];
+                static_for<NH>([&](auto hh) {
+                    constexpr int h = decltype(hh)::value;
+                    const float* Xl = xin;
+                    if constexpr (RSI >= 0) {
+                        static_assert(RSI < 0 || (CINV == 32 && L != 0), "");
+                        static_assert(RSI < 0 || IR <= ROWSG + 16, "the resampler's input chunk fits the z region");
+                        float nosk[1] = {0.f};
+                        if constexpr (HIR && h == 0) {
+#pragma unroll
+                            for (int fc = 0; fc < NFC; ++fc)
+                                resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA + fc * IR * CSZ, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                        } else {
+#pragma unroll
+                            for (int fc = 0; fc < NFC; ++fc) {
+                                if (!(HIC && fc == 0)) {
+                                    __syncthreads();      // (the previous stage / part / chunk is done with XA and the chunk region)
+                                    si.commit(tid, ZA, CSZ);
+                                    __syncthreads();
+                                    if (!HIC && fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
+                                    else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
+                                }
+                                resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                            }
+                        }
+                        if (skip) {                       // + the U-Net skip (d2 / d1), this part's channels
+                            __syncthreads();
+#pragma unroll
+                            for (int i = 0; i < decltype(sx)::N; ++i) {
+                                const int u = tid + i * NTHREADS;
+                                if (u < ROWS * 8) {
+                                    float4* xp = reinterpret_cast<float4*>(XA + (u >> 3) * CSV + (u & 7) * 4);
+                                    const float4 a = *xp, b = sx.v[i];
+                                    *xp = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                                }
+                            }
+                            if constexpr (h + 1 < NH) sx.issue(tid, skip, CSI, (h + 1) * CINV);
+                        }
+                        Xl = XA;
+                    } else if (HI17) {
+                        Xl = XA;                          // (the previous layer's epilogue left it there)
+                    } else if (!xin_lds) {
+                        if constexpr (!(HI && h == 0)) {  // (HI: part 0 is in XA already, part 1 on its way)
+                            __syncthreads();              // (the previous stage / half is done with XA)
+                            sx.commit(tid, XA, CSV);
+                            if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
+                        }
+                        Xl = XA;
+                    }
+                    if constexpr (AQ) {
+                        static_assert(!AQ || RES, "");
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) {
+                            aq[k] = load_global4(wfr + (h * KH + k) * 256);
+                            aq[KH + k] = load_global4(wfr + (CIN / 16 + h * KH + k) * 256);
+                        }
+                    }
+                    __syncthreads();
+                    TLMARK(4 * L);
+                    auto gemm_fg = [&](int fg, f32x4 (&ac)[TI::MAXN]) {
+                        const float* xg = Xl + fg * ROWSG * CSV;
+                        if (h == 0) {
+#pragma unroll
+                            for (int i = 0; i < TI::MAXN; ++i) ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH>(aq, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        else gemm_part<MT, NT, KH, 0, h * KH, 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        if constexpr (!RES) {             // identity residual: the tile's own 4 channels of x, when they lie in this half
+                            if ((mt * 16) / CINV == h) {
+                                const float* xr = xg + __mul24(ng * 16 + (lane & 15), CSV) + c0 - h * CINV;
+                                static_for<TI::MAXN>([&](auto ii) {
+                                    constexpr int i = decltype(ii)::value;
+                                    if (ng + i * TI::NG < NT) {
+                                        const float4 r = *reinterpret_cast<const float4*>(xr + i * TI::NG * 16 * CSV);
+                                        ac[i] += f32x4{r.x, r.y, r.z, r.w};
+                                    }
+                                });
+                            }
+                        }
+                    };
+                    // epilogue: bias, PReLU, embedding -> slab, or -> the X region (the next layer's input, row stride 36)
+                    auto epi_fg = [&](int fg, const f32x4 (&ac)[TI::MAXN]) {
+                        const float4 bcur = A.bcur;
+                        static_for<TI::MAXN>([&](auto ii) {
+                            constexpr int i = decltype(ii)::value;
+                            const int col = ng * 16 + (lane & 15) + i * TI::NG * 16;
+                            if (ng + i * TI::NG < NT && col < ROWSG) {
+                                const int gcol = fg * ROWSG + col;
+                                const float4 e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
+                                const f32x2 t0 = f32x2{ac[i][0] + bcur.x, ac[i][1] + bcur.y}, t1 = f32x2{ac[i][2] + bcur.z, ac[i][3] + bcur.w};
+                                const f32x2 m0 = t0 * slope, m1 = t1 * slope;
+                                const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
+                                                             __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
+                                if (HO17 || (HO && mt < 2)) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
+                                else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;      // (layer 4's is the skip d2 as well)
+                                if (HOR && mt < 2) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
+                                if (HOC && gcol < TL_FC * V) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
+                            }
+                        });
+                    };
+                    if constexpr (HO17 || L == 2) {
+                        static_assert(!(HO17 || L == 2) || (FS == 2 && NH == 1 && COUT <= 32), "");
+                        f32x4 acc0[TI::MAXN];
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 0);
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 0, tqa);
+                        tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 1);
+                        __syncthreads();
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 0, aja);
+                        TLMARK(4 * L + 1);
+                        __syncthreads();
+                        TLMARK(4 * L + 2);
+                        gemm_fg(0, acc0);
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 1);
+                        TLMARK(4 * L + 3);
+                        __syncthreads();                  // (z is free)
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 1, tqa);
+                        __syncthreads();                  // (nobody reads the X rows of group 0 any more)
+                        if constexpr (HO17) epi_fg(0, acc0);
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 1, aja);
+                        TLMARK(4 * L + 1);
+                        __syncthreads();
+                        TLMARK(4 * L + 2);
+                        gemm_fg(1, acc);
+                        __syncthreads();                  // (... nor those of group 1)
+                        if constexpr (!HO17) epi_fg(0, acc0);
+                        epi_fg(1, acc);
+                        TLMARK(4 * L + 3);
+                    } else {
+#pragma unroll
+                        for (int fg = 0; fg < FS; ++fg) {
+                            tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, fg);
+                            tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, fg, tqa);
+                            if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
+                            __syncthreads();
+                            tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, fg, aja);
+                            TLMARK(4 * L + 1);
+                            __syncthreads();
+                            TLMARK(4 * L + 2);
+                            gemm_fg(fg, acc);
+                            if constexpr (h == NH - 1) {
+                                static_assert(!(HO || HOR) || (FS == 1 && CSV == 36), "");
+                                if constexpr (HO || HOR || L == 8) __syncthreads();    // (every wave is done with XA / z: the m-tiles 0, 1 go there)
+                                epi_fg(fg, acc);
+                            }
+                            if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
+                            TLMARK(4 * L + 3);
+                        }
+                    }
+                });
+                __syncthreads();
+            };
+#define TL_C(x) std::integral_constant<int, x>{}
+            TLMARK(60);                                                     // pass prologue (noise, embeddings)
+#define TL_NORS std::integral_constant<int, -1>{}
+            layer(TL_C(0), TL_NORS, XT, true, A0, nullptr);
+            layer(TL_C(1), TL_NORS, A0, false, A1, nullptr);
+            layer(TL_C(2), TL_NORS, A1, false, D1, nullptr);                // -> d1
+            layer(TL_C(3), TL_C(0), D1, false, A0, nullptr);                // down1 on the way in
+            layer(TL_C(4), TL_NORS, A0, false, D2, nullptr);                // -> d2
+            layer(TL_C(5), TL_C(1), D2, false, A0, nullptr);                // down2 on the way in; 64 -> 128
+            layer(TL_C(6), TL_NORS, A0, false, A1, nullptr);                // 128 -> 64, mix-first here (four 32-channel quarters)
+            layer(TL_C(7), TL_C(2), A1, false, A0, D2);                     // up3 + d2 on the way in
+            layer(TL_C(8), TL_NORS, A0, false, A1, nullptr);
+            layer(TL_C(9), TL_C(3), A1, false, A0, D1);                     // up2 + d1 on the way in
+            TLMARK(61);
+            {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                MixLongCoef<16, 17, TP, NB> mc10;      // (the mix's first coefficients: in flight behind the product)
+                mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
+                const float* w4 = wb + N.wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
+                for (int col = tid; col < R17; col += NTHREADS) {
+                    const float* xp = RA + col * 36;          // layer 9's output, handed over in LDS
+                    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 x = *reinterpret_cast<const float4*>(xp + 4 * q);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a[r] = fmaf(w4[r * 32 + 4 * q + 0], x.x, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 1], x.y, a[r]);
+                            a[r] = fmaf(w4[r * 32 + 4 * q + 2], x.z, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 3], x.w, a[r]);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(P4 + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
+                }
+                __syncthreads();
+                // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
+                mix_long<16, 17, TP, NB>(P4, 4, mc10, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
+                                     [&](int q, int w0, int c, auto v) {
+                                         if (c < C0) {
+                                             float* zp = ZO + ((q * 17 + w0)) * C0 + c;
+                                             if constexpr (std::is_same_v<decltype(v), f32x4>) {
+#pragma unroll
+                                                 for (int r = 0; r < 4; ++r)
+                                                     if (w0 + r < 17) zp[r * C0] = v[r];
+                                             } else {
+                                                 *zp = v;
+                                             }
+                                         }
+                                     });
+                __syncthreads();
+                // eps = layer 10 + x; DDPM update of the frame each prediction drives (mocodad.py:172-178,829-838)
+                const float slope10 = N.slope[10], ca = srow[0], cb = srow[1], csg = srow[2];
+                const bool zadd = sidx > 1;
+                constexpr int NIT = (C0 * TF * 17 + NTHREADS - 1) / NTHREADS;
+                float xn[NIT];
+                int dst[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int u = tid + it * NTHREADS;
+                    dst[it] = -1; xn[it] = 0.f;
+                    if (u < TF * 17 * C0) {
+                        const int c = u % C0, col = u / C0, f = col / 17, i = f / TP, t = f % TP, v = col % 17;
+                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[N.bias[10] + c], slope10) + EMB[i * EMBS + emb_off(10) + c];
+                        const float eps = l10 + XT[col * 4 + c];
+                        const int k = t >= T ? -1 : P.win_mask ? (((fixed_of(i) >> t) & 1u) ? -1 : 0) : M.upd_of[t];
+                        if (k >= 0) {
+                            const int tp = P.win_mask ? t : M.pos_of[k];
+                            const int colp = (i * TP + tp) * 17 + v;
+                            xn[it] = ca * (XT[colp * 4 + c] - cb * eps) + csg * (zadd ? ZN[colp * C0 + c] : 0.f);
+                            dst[it] = colp * 4 + c;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (dst[it] >= 0) XT[dst[it]] = xn[it];
+                TLMARK(54);                            // layer 10 + DDPM update
+            }
+        }
+        __syncthreads();
+        // ---- loss over the corrupt frames (mocodad.py:484)
+        for (int i = 0; i < NB; ++i) {
+            if (grp * NB + i >= P.n_chains) break;
+            const long long chain = grp * NB + i;
+            const int b = b_of(i), s = s_of(i);
+            const unsigned fixed = fixed_of(i);
+            float part = 0.f;
+            for (int e = tid; e < per; e += NTHREADS) {
+                const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
+                int tu = M.pos_of[tx];
+                if (P.win_mask) { int cnt = 0; for (int t = 0; t < T; ++t) if (!((fixed >> t) & 1u)) { if (cnt == tx) tu = t; ++cnt; } }
+                const float x0 = XT[((i * TP + tu) * 17 + v) * 4 + c];
+                const float gt = load_coord(P.dv, b, c, src_of(tu), v, P.seg_len);
+                part += loss_elem(x0, gt, P.loss_fn);
+                if (P.pose_out) P.pose_out[(size_t)(b * P.S + s) * per + e] = x0;
+            }
+            RED[tid] = part;
+            __syncthreads();
+            for (int o = NTHREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
+            if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
+            __syncthreads();
+        }
+    }
+}
+
+
+}  // namespace mcd

@@ -91,7 +91,7 @@ class HipScorer:
             self.set_option(name, value)
 
     def set_option(self, name: str, value: int) -> None:
-        """Per-handle switch of the library (include/mocodad_hip.h MCD_OPT_*): 'bf16x3', 'variant', 'cond_generic',
+        """Per-handle switch of the library (include/mocodad_hip.h MCD_OPT_*): 'variant', 'cond_generic',
         'generic_unet', 'split', 'phase'."""
         if name not in _lib.OPT:
             raise ValueError(f"unknown option {name!r} (known: {sorted(_lib.OPT)})")

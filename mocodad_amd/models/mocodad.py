@@ -194,7 +194,7 @@ class MoCoDAD(_Base):
         self._scorer_key = None
         self._calls = 0
         self.shard = None  # optional mocodad_amd.parallel.WindowShard set by the multi-GPU driver
-        self.hip_options: Dict[str, int] = {}   # per-handle library switches (engine.HipScorer.set_option), e.g. {"bf16x3": 1}
+        self.hip_options: Dict[str, int] = {}   # per-handle library switches (engine.HipScorer.set_option), e.g. {"split": 1}
 
     # -------------------------------------------------------------- construction
     def build_model(self) -> None:

@@ -9,9 +9,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.environ.get("MCD_PROF_LIB") or os.path.join(ROOT, "mocodad_amd", "libmocodad_hip_prof.so")
-if not os.path.exists(so):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMCD_PROFILE",
-                           "-o", so, os.path.join(ROOT, "mocodad_amd", "csrc", "mocodad_hip.hip")])
+if not os.environ.get("MCD_PROF_LIB"):
+    from mocodad_amd import build as _build
+    _build.build_library(so, ["MCD_PROFILE"] + (["MCD_TUNING_VARIANTS"] if len(sys.argv) > 1 and sys.argv[1] != "0" else []))
 VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 import torch
 from mocodad_amd import _lib
