@@ -11,9 +11,8 @@
  *   - the CALLER owns every buffer (device pointers unless stated "host"); the library owns only
  *     mcd_weights_t.  All tensors are dense row-major float32 in the reference's own layouts.
  *   - compute entry points are asynchronous on the caller's hipStream_t (passed as void*), perform no
- *     allocation and no host synchronisation, and are re-entrant across streams and devices.  (Exceptions, both
- *     test / diagnostic entries: mcd_unet_forward on a frame count without a specialised kernel takes its scratch
- *     from the stream-ordered allocator, and mcd_debug_set_prof sets one process-wide pointer.)
+ *     allocation and no host synchronisation, and are re-entrant across streams and devices.  (One exception, a diagnostic
+ *     entry: mcd_debug_set_prof sets one process-wide pointer.)
  *   - there is NO CPU fallback: without a gfx950 device these calls fail with MCD_EDEVICE.
  */
 #ifndef MOCODAD_HIP_H
@@ -99,23 +98,35 @@ void mcd_free_weights(mcd_weights_t* w);
 /* Replaces: MoCoDAD._encode_condition -> STSAE/STSE.encode (mocodad.py:546-560, stsae.py:59-92).
  * cond_data (B,C,t_cond,V) -> emb_out (B,emb_dim).  The AE decoder (dead work at eval) is not run.
  * (A test / diagnostic entry without a workspace argument: encoders that need scratch memory -- 'E_unet' above 12 condition
- * frames, any encoder at 26 .. 31 -- return MCD_EUNSUPPORTED here and run inside mcd_score / mcd_score_fused.) */
+ * frames, the shipped encoder at 25 .. 31 (three 32-channel activation buffers no longer fit LDS) -- return MCD_EUNSUPPORTED here and run inside mcd_score / mcd_score_fused.) */
 int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_windows, float* emb_out,
                     void* stream);
 
-/* Replaces: STSAE_Unet.forward (stsae_unet.py:406-438) for one timestep shared by the batch.
- * x (B,C,t_unet,V), step_table row `t` (see mcd_score), cond (B,emb_dim) or NULL -> eps_out (B,C,t_unet,V). */
-int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table,
-                     int32_t t, int32_t n_windows, float* eps_out, void* stream);
+/* Scratch of the two single-pass entries below for n_windows windows: 0 for 1 .. 12 U-Net frames (everything lives in LDS), the
+ * activation slabs of the slab-tiled kernel for 13 .. 32 frames (or of the runtime-shape kernel under MCD_OPT_GENERIC_UNET). */
+int64_t mcd_pass_workspace_bytes(const mcd_weights_t* w, int32_t n_windows);
 
-/* TEST ENTRY.  One stage of the U-Net alone, run by the production stage functions inside the trajectory kernel's LDS plan:
+/* Replaces: STSAE_Unet.forward (stsae_unet.py:406-438) for one timestep shared by the batch.
+ * x (B,C,t_unet,V), step_table row `t` (see mcd_score), cond (B,emb_dim) or NULL -> eps_out (B,C,t_unet,V).
+ * Runs the production kernel of the frame count in single-pass mode: score_kernel<T_u,...> (1 .. 12 frames) or
+ * score_tiled_kernel (13 .. 32; workspace = mcd_pass_workspace_bytes, else may be NULL). */
+int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table,
+                     int32_t t, int32_t n_windows, float* eps_out, void* workspace, void* stream);
+
+/* TEST ENTRY.  One stage of the U-Net alone, run by the production stage functions inside the trajectory kernel:
  * stage 0..10 = ST_GCNN_layer.forward of the 11 layers in execution order (stsgcn.py:94-116; st_gcnnsp1a.0, sd1.0, sd1.1,
  * sd2.0, sd2.1, sd3.0, sd3.1, su4.0, su4.1, su3.0, su3.1), 11..14 = CNN_layer over the joint axis as called at
  * stsae_unet.py:205,213,381,391 (down1, down2, up3, up2; without the skip add).
  * x (B,Cin,t_unet,Vin), emb (B,emb_dim) = the layer's `t` argument (the layer adds Linear(SiLU(emb)); required),
- * out (B,Cout,t_unet,Vout).  Instantiated for 3, 6 and 12 U-Net frames. */
-int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* emb, int32_t n_windows,
-                      float* out, void* stream);
+ * out (B,Cout,t_unet,Vout).  Instantiated for 3, 5, 6, 7, 10, 12 U-Net frames (score_kernel's LDS plan) and for 13 .. 32
+ * (score_tiled_kernel: the stage's input is put where the previous layer's epilogue leaves it -- slab and LDS hand-over
+ * regions -- and its output read from where its own epilogue puts it; workspace = mcd_pass_workspace_bytes).  In the slab-tiled
+ * kernel the joint resamplers are not stages of their own: stages 3, 5, 7, 9 are (down1 | down2 | up3 | up2) + the layer, x is
+ * the RESAMPLER's input (B,Cin,t_unet,17|12|10|12) and `skip` (stages 7, 9; or NULL) the U-Net skip tensor d2 (B,64,t_unet,12) /
+ * d1 (B,32,t_unet,17) added behind the resampler (stsae_unet.py:381-383,391-393); stages 11..14 return MCD_EUNSUPPORTED there.
+ * `skip` must be NULL otherwise. */
+int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* skip, const float* emb,
+                      int32_t n_windows, float* out, void* workspace, void* stream);
 
 /* The noise tensor the perf mode (noise == NULL) of mcd_score draws in-kernel, in mcd_score's `noise` layout
  * (S, max(ns-1,1), B, C=2, Tx, V=17): mcd_score(noise = this tensor) reproduces mcd_score(noise = NULL, seed,

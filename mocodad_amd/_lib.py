@@ -49,12 +49,13 @@ _SIGS = {
     "mcd_pack_weights": (C.c_int, [C.POINTER(Tensor), C.c_int32, C.POINTER(ModelCfg), C.c_int32, C.POINTER(C.c_void_p)]),
     "mcd_free_weights": (None, [C.c_void_p]),
     "mcd_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
-    "mcd_layer_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mcd_layer_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcd_pass_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32]),
     "mcd_philox_noise": (C.c_int, [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcd_debug_set_prof": (None, [C.c_void_p]),
     "mcd_debug_poison_lds": (C.c_int, [C.c_void_p]),
     "mcd_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mcd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mcd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcd_score_workspace_bytes": (C.c_int64, [C.c_void_p, C.POINTER(ScoreCfg)]),
     "mcd_plan_split": (C.c_int32, [C.c_void_p, C.POINTER(ScoreCfg)]),
     "mcd_score": (C.c_int, [C.c_void_p, C.POINTER(ScoreCfg), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p,

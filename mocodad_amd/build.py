@@ -23,7 +23,7 @@ CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(ROOT, "include", "mocodad_hip.h")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 DEFAULT_OUT = os.path.join(HERE, "libmocodad_hip.so")
-BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-pass-failed"]
 
 
 def n_units() -> int:

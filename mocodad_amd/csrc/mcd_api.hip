@@ -856,24 +856,28 @@ int launch_score_generic(const mcd_weights* w, const ScoreParams& P, const Frame
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
-int tiled_wgs(int64_t chains, int TP) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+int tiled_wgs(const mcd_weights* w, int64_t chains, int TP) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device);     // the handle's device, whatever the caller's current one
+    if (cus < 1) cus = 256;
     const int64_t units = (chains + tl_nb(TP) - 1) / tl_nb(TP);
     return (int)(units < cus ? units : cus);         // one workgroup per CU (110 - 135 KB of LDS), persistent over the chains
 }
-int64_t tiled_scratch_bytes(int64_t chains, int TP) { return (int64_t)tiled_wgs(chains, TP) * tl_slab_floats(TP * tl_nb(TP)) * 4; }
-int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st) {
-    const int wgs = tiled_wgs(P.n_chains, w->tiled_tp);
+int64_t tiled_scratch_bytes(const mcd_weights* w, int64_t chains, int TP) { return (int64_t)tiled_wgs(w, chains, TP) * tl_slab_floats(TP * tl_nb(TP)) * 4; }
+int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, hipStream_t st, bool layer_test = false) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != w->device) return fail(MCD_EINVAL, "the current device is not the handle's device (the workspace slabs are sized for it)");
+    const int wgs = tiled_wgs(w, P.n_chains, w->tiled_tp);
 #ifdef MCD_FAST_T
 #ifdef MCD_FAST_TILED
     if (w->tiled_tp == MCD_FAST_TILED) return launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED)>(w, P, M, scratch, wgs, st);
 #endif
-    (void)wgs;
+    (void)wgs; (void)layer_test;
     return fail(MCD_EUNSUPPORTED, "fast build");
 #else
-    switch (w->tiled_tp) {
-#define MCD_CASE(unit, TP, NB) case TP: return launch_score_tiled_t<TP, NB>(w, P, M, scratch, wgs, st);
+    switch (layer_test ? -w->tiled_tp : w->tiled_tp) {
+#define MCD_CASE(unit, TP, NB, LT) case (LT ? -TP : TP): return launch_score_tiled_t<TP, NB, LT>(w, P, M, scratch, wgs, st);
         MCD_TILED_INSTANCES(MCD_CASE)
 #undef MCD_CASE
         default: return fail(MCD_EUNSUPPORTED, "tiled kernel: frame count");
@@ -1282,8 +1286,17 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
     return launch_cond_plain(w, cond_data, n_windows, emb_out, nullptr, (hipStream_t)stream);
 }
 
+// scratch of the single-pass entries: the slabs of the slab-tiled kernel (13 .. 32 U-Net frames) or of the runtime-shape kernel
+int64_t mcd_pass_workspace_bytes(const mcd_weights_t* w, int32_t n_windows) {
+    if (!w || n_windows <= 0) return 0;
+    int64_t b = 0;
+    if (!w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET]) b = gen_scratch_bytes(n_windows, w->cfg.t_unet);
+    if (!w->fast_unet && w->tiled_tp) { const int64_t t = tiled_scratch_bytes(w, n_windows, w->tiled_tp); if (t > b) b = t; }
+    return b;
+}
+
 int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table, int32_t t,
-                     int32_t n_windows, float* eps_out, void* stream) {
+                     int32_t n_windows, float* eps_out, void* workspace, void* stream) {
     if (!w) return fail(MCD_EINVAL, "null argument");
     if (n_windows <= 0) return MCD_OK;
     if (!x || !step_table || !eps_out) return fail(MCD_EINVAL, "null argument");
@@ -1292,20 +1305,18 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     P.wbuf = w->dbuf; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
     P.B = n_windows; P.S = 1; P.ns = t + 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet; P.fixed_mask = 0;
     P.mode = 1; P.step_single = t; P.n_chains = n_windows;
-    if (w->fast_unet && !w->opt[MCD_OPT_GENERIC_UNET]) return launch_score(w, w->cfg.t_unet, P, (hipStream_t)stream);
-    // runtime-shape kernel (a test entry here): its scratch slabs come from the stream-ordered allocator
     hipStream_t st = (hipStream_t)stream;
-    float* scratch = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)gen_scratch_bytes(n_windows, w->cfg.t_unet), st));
+    if (w->fast_unet && !w->opt[MCD_OPT_GENERIC_UNET]) return launch_score(w, w->cfg.t_unet, P, st);
+    // 13 .. 32 frames: the slab-tiled kernel in single-pass mode; MCD_OPT_GENERIC_UNET: the runtime-shape kernel
+    if (!workspace) return fail(MCD_EINVAL, "workspace required (mcd_pass_workspace_bytes)");
     FrameMaps M;
     memset(&M, 0, sizeof(M));
-    const int rc = launch_score_generic(w, P, M, scratch, st);
-    HIP_TRY(hipFreeAsync(scratch, st));
-    return rc;
+    if (w->tiled_tp && !w->opt[MCD_OPT_GENERIC_UNET]) return launch_score_tiled(w, P, M, reinterpret_cast<float*>(workspace), st);
+    return launch_score_generic(w, P, M, reinterpret_cast<float*>(workspace), st);
 }
 
-int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* emb, int32_t n_windows, float* out,
-                      void* stream) {
+int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, const float* skip, const float* emb, int32_t n_windows,
+                      float* out, void* workspace, void* stream) {
     if (!w) return fail(MCD_EINVAL, "null argument");
     if (stage < 0 || stage > 14) return fail(MCD_EINVAL, "stage must be 0..10 (ST-GCN layers) or 11..14 (down1, down2, up3, up2)");
     if (n_windows <= 0) return MCD_OK;
@@ -1315,16 +1326,29 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
     P.wbuf = w->dbuf; P.cond_emb = emb; P.step_table = w->dbuf + w->zero_row;   // pe = 0: the layers see SiLU(emb)
     P.B = n_windows; P.S = 1; P.ns = 1; P.seg_len = w->cfg.t_unet; P.n_corrupt = w->cfg.t_unet;
     P.mode = 1; P.step_single = 0; P.n_chains = n_windows;
-    P.lt_stage = stage; P.lt_in = x; P.lt_out = out;
+    P.lt_stage = stage; P.lt_in = x; P.lt_out = out; P.lt_skip = skip;
     P.x_in = stage == 0 ? x : nullptr;     // layer 0 reads the chain state itself; the other stages start from x = 0
 #ifdef MCD_FAST_T
     return fail(MCD_EUNSUPPORTED, "fast build");
 #else
+    hipStream_t st = (hipStream_t)stream;
+    if (w->tiled_tp) {      // 13 .. 32 frames: the joint resamplers are fused into layers 3, 5, 7, 9 (no stages of their own)
+        if (stage > 10) return fail(MCD_EUNSUPPORTED, "13 .. 32 U-Net frames: the joint resamplers are part of stages 3, 5, 7, 9");
+        if (skip && stage != 7 && stage != 9) return fail(MCD_EINVAL, "skip tensor: stages 7 (d2) and 9 (d1) only");
+        if (!workspace) return fail(MCD_EINVAL, "workspace required (mcd_pass_workspace_bytes)");
+        FrameMaps M;
+        memset(&M, 0, sizeof(M));
+        return launch_score_tiled(w, P, M, reinterpret_cast<float*>(workspace), st, true);
+    }
+    if (skip) return fail(MCD_EINVAL, "skip tensor: only the fused stages of 13 .. 32 U-Net frames take one");
     switch (w->cfg.t_unet) {
-        case 3: return launch_score_t<3, 2, 4, true>(P, (hipStream_t)stream, nullptr);
-        case 6: return launch_score_t<6, 1, 4, true>(P, (hipStream_t)stream, nullptr);
-        case 12: return launch_score_t<12, 1, 2, true>(P, (hipStream_t)stream, nullptr);
-        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3, 6 and 12 U-Net frames (the fixtures' shapes)");
+        case 3: return launch_score_t<3, 2, 4, true>(P, st, nullptr);
+        case 6: return launch_score_t<6, 1, 4, true>(P, st, nullptr);
+        case 12: return launch_score_t<12, 1, 2, true>(P, st, nullptr);
+        case 5: return launch_score_t<5, 2, 2, true>(P, st, nullptr);
+        case 7: return launch_score_t<7, 1, 2, true>(P, st, nullptr);
+        case 10: return launch_score_t<10, 1, 2, true>(P, st, nullptr);
+        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3, 5, 6, 7, 10, 12 and 13 .. 32 U-Net frames (the fixtures' shapes)");
     }
 #endif
 }
@@ -1390,7 +1414,7 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
     int64_t gen = 0;
     if (!w->fast_unet || w->opt[MCD_OPT_GENERIC_UNET]) gen = gen_scratch_bytes((int64_t)cfg->n_windows * cfg->n_samples, w->cfg.t_unet);
     if (!w->fast_unet && w->tiled_tp) {
-        const int64_t g3 = tiled_scratch_bytes((int64_t)cfg->n_windows * cfg->n_samples, w->tiled_tp);
+        const int64_t g3 = tiled_scratch_bytes(w, (int64_t)cfg->n_windows * cfg->n_samples, w->tiled_tp);
         if (g3 > gen) gen = g3;
     }
     if (w->cond_unet) { const int64_t g2 = gen_scratch_bytes(cfg->n_windows, w->cond.Tc); if (g2 > gen) gen = g2; }
@@ -1463,10 +1487,15 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
     // (mocodad.py:672-683), inject / no_condition = the corrupt frames only
     FrameMaps M;
     memset(&M, 0, sizeof(M));
+    // data frames the kernels read (load_coord) must lie inside the window
+    for (int k = 0; k < cfg->n_cond; ++k)
+        if (cfg->cond_idx[k] < 0 || cfg->cond_idx[k] >= cfg->seg_len) return fail(MCD_EINVAL, "cond_idx outside [0, seg_len)");
+    for (int k = 0; k < cfg->n_corrupt; ++k)
+        if (cfg->corrupt_idx[k] < 0 || cfg->corrupt_idx[k] >= cfg->seg_len) return fail(MCD_EINVAL, "corrupt_idx outside [0, seg_len)");
     for (int k = 0; k < tf && !rnd; ++k) {
         const int t = strat == MCD_STRATEGY_INBETWEEN_IMP ? cfg->cond_idx[k] : k;
         if (t < 0 || t >= Tu || ((P.fixed_mask >> t) & 1)) return fail(MCD_EINVAL, "bad cond_idx");
-        P.fixed_mask |= 1 << t;
+        P.fixed_mask |= 1u << t;
         M.src_frame[t] = cfg->cond_idx[k];
     }
     for (int k = 0; k < cfg->n_corrupt && !rnd; ++k) {

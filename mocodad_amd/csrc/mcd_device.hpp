@@ -225,7 +225,7 @@ struct ScoreParams {
     float* loss_agg;          // (B,) aggregated loss, or null
     int cond_idx[12];         // cond_inkernel: data frames the condition encoder reads
     int upd_shift;            // some prediction updates a frame other than the one it is read at (element-wise tail: barrier between reads and writes)
-    int fixed_mask;           // bit t: U-Net frame t is a condition frame copied from the window (concat / imputation)
+    unsigned fixed_mask;      // bit t: U-Net frame t is a condition frame copied from the window (concat / imputation)
     int src_frame[12];        // data frame feeding U-Net frame t (condition frame, or ground truth of a denoised one)
     int tx_of[12];            // denoised U-Net frame t -> its index among the corrupt frames
     int pos_of[12];           // corrupt frame k -> its U-Net frame
@@ -237,6 +237,7 @@ struct ScoreParams {
     int lt_stage;
     const float* lt_in;
     float* lt_out;
+    const float* lt_skip;     // slab-tiled kernel, stages 7 / 9: the U-Net skip tensor added behind the fused resampler (or null)
 };
 // frame layout of one window: `fixed` = its condition-frame bitmask (P.fixed_mask, or the window's own for random_imp)
 __device__ __forceinline__ int fm_tx(const ScoreParams& P, int fixed, int t) {

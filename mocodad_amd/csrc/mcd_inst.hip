@@ -66,7 +66,27 @@
 #else
 #define MCD_U12(...)
 #endif
-#if MCD_INST_UNITS != 12
+#if MCD_UNIT_IS(13)
+#define MCD_U13(...) __VA_ARGS__
+#else
+#define MCD_U13(...)
+#endif
+#if MCD_UNIT_IS(14)
+#define MCD_U14(...) __VA_ARGS__
+#else
+#define MCD_U14(...)
+#endif
+#if MCD_UNIT_IS(15)
+#define MCD_U15(...) __VA_ARGS__
+#else
+#define MCD_U15(...)
+#endif
+#if MCD_UNIT_IS(16)
+#define MCD_U16(...) __VA_ARGS__
+#else
+#define MCD_U16(...)
+#endif
+#if MCD_INST_UNITS != 16
 #error "add the MCD_U<n> selectors of the new units"
 #endif
 
@@ -78,7 +98,7 @@ template int launch_score_t<MCD_FAST_T, MCD_FAST_NB, MCD_FAST_MINW, false>(Score
 template int launch_cond_fast_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
 template int launch_cond_unet_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
 #ifdef MCD_FAST_TILED
-template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED)>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED), false>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
 #endif
 #endif
 #else
@@ -87,8 +107,8 @@ template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED)>(const m
     MCD_U##unit(template int launch_cond_fast_t<T, NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);)
 #define MCD_DEF_COND_UNET(unit, T, NB) \
     MCD_U##unit(template int launch_cond_unet_t<T, NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);)
-#define MCD_DEF_TILED(unit, TP, NB) \
-    MCD_U##unit(template int launch_score_tiled_t<TP, NB>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);)
+#define MCD_DEF_TILED(unit, TP, NB, LT) \
+    MCD_U##unit(template int launch_score_tiled_t<TP, NB, LT>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);)
 MCD_SCORE_INSTANCES(MCD_DEF_SCORE)
 MCD_COND_FAST_INSTANCES(MCD_DEF_COND_FAST)
 MCD_COND_UNET_INSTANCES(MCD_DEF_COND_UNET)

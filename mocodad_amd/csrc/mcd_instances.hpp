@@ -6,10 +6,10 @@
 // build in parallel (mocodad_amd/build.py); their number and the assignment below only balance compile times.
 //   X(unit, T_u, NB, MINW, LT)   score_kernel<T_u, NB, MINW, LT>      (LT: the layer-test form behind mcd_layer_forward)
 //   X(unit, T_c, NB)             cond_fast_kernel / cond_unet_kernel<T_c, NB>
-//   X(unit, TP, NB)              score_tiled_kernel<TP, NB>
+//   X(unit, TP, NB, LT)          score_tiled_kernel<TP, NB, LT>
 #pragma once
 
-#define MCD_INST_UNITS 12
+#define MCD_INST_UNITS 16
 
 #ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only
 #define MCD_SCORE_VARIANT_INSTANCES(X) X(1, 3, 4, 2, false) X(1, 3, 1, 4, false) X(1, 3, 2, 2, false) X(2, 6, 2, 2, false)
@@ -27,6 +27,7 @@
     X(4, 5, 2, 2, false) X(4, 10, 1, 2, false) X(4, 7, 1, 2, false) \
     X(5, 9, 1, 2, false) X(5, 11, 1, 2, false) \
     X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \
+    X(13, 5, 2, 2, true) X(13, 7, 1, 2, true) X(13, 10, 1, 2, true) \
     MCD_SCORE_VARIANT_INSTANCES(X)
 
 #define MCD_COND_FAST_INSTANCES(X) \
@@ -35,4 +36,4 @@
 #define MCD_COND_UNET_INSTANCES(X) \
     X(8, 1, 4) X(8, 2, 3) X(8, 3, 2) X(8, 4, 2) X(8, 5, 2) X(8, 6, 1) X(8, 7, 1) X(10, 8, 1) X(10, 9, 1) X(10, 10, 1) X(10, 11, 1) X(10, 12, 1)
 
-#define MCD_TILED_INSTANCES(X) X(6, 16, 2) X(11, 24, 1) X(12, 32, 1)
+#define MCD_TILED_INSTANCES(X) X(6, 16, 2, false) X(11, 24, 1, false) X(12, 32, 1, false) X(14, 16, 2, true) X(15, 24, 1, true) X(16, 32, 1, true)

@@ -11,7 +11,7 @@ namespace mcd {
 struct CondW {
     const float* base;
     int n_layers, Tc, latent, cmax;
-    int gmode;       // 1: three LDS buffers of cmax x Tc x 17 do not fit (26 .. 31 condition frames): the third one lives in global scratch
+    int gmode;       // 1: three LDS buffers of cmax x Tc x 17 do not fit (25 .. 31 condition frames of the shipped encoder): the third one lives in global scratch
     int cin[MCD_MAX_COND_LAYERS], cout[MCD_MAX_COND_LAYERS];
     int tq[MCD_MAX_COND_LAYERS], am[MCD_MAX_COND_LAYERS], wt[MCD_MAX_COND_LAYERS], wr[MCD_MAX_COND_LAYERS];
     int bias[MCD_MAX_COND_LAYERS];
@@ -148,12 +148,12 @@ int launch_cond_unet_t(const mcd_weights* w, const DataView& data, const FrameId
 // MFMA kernel of the long windows (12 < T <= 32); slabs: tl_slab_floats(TP) floats per workgroup
 // chains per workgroup of the slab-tiled kernel: two 16-frame chains share one (see score_tiled_kernel)
 constexpr int tl_nb(int TP) { return TP <= 16 ? 2 : 1; }
-template <int TP, int NB>
+template <int TP, int NB, bool LT = false>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
     constexpr int TF = TP * NB;
     constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS) * 4;
-    LDS_LIMIT((&score_tiled_kernel<TP, NB>), lds);
-    hipLaunchKernelGGL((score_tiled_kernel<TP, NB>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
+    LDS_LIMIT((&score_tiled_kernel<TP, NB, LT>), lds);
+    hipLaunchKernelGGL((score_tiled_kernel<TP, NB, LT>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
@@ -175,7 +175,7 @@ extern template int launch_score_t<MCD_FAST_T, MCD_FAST_NB, MCD_FAST_MINW, false
 extern template int launch_cond_fast_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
 extern template int launch_cond_unet_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
 #ifdef MCD_FAST_TILED
-extern template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED)>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+extern template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED), false>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
 #endif
 #else
 #define MCD_DECL_SCORE(unit, T, NB, MINW, LT) extern template int launch_score_t<T, NB, MINW, LT>(ScoreParams&, hipStream_t, bool*);
@@ -183,8 +183,8 @@ extern template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED)>(
     extern template int launch_cond_fast_t<T, NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
 #define MCD_DECL_COND_UNET(unit, T, NB) \
     extern template int launch_cond_unet_t<T, NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
-#define MCD_DECL_TILED(unit, TP, NB) \
-    extern template int launch_score_tiled_t<TP, NB>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+#define MCD_DECL_TILED(unit, TP, NB, LT) \
+    extern template int launch_score_tiled_t<TP, NB, LT>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
 MCD_SCORE_INSTANCES(MCD_DECL_SCORE)
 MCD_COND_FAST_INSTANCES(MCD_DECL_COND_FAST)
 MCD_COND_UNET_INSTANCES(MCD_DECL_COND_UNET)

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     auto window_of = [&](int n) { const int b = win0 + n; return b < P.B ? b : P.B - 1; };     // (clamped: empty slots recompute the last window)
     if (threadIdx.x < NB) {
         const int b = window_of(threadIdx.x);
-        WM[threadIdx.x] = P.win_mask ? P.win_mask[b] : P.fixed_mask;
+        WM[threadIdx.x] = P.win_mask ? P.win_mask[b] : (int)P.fixed_mask;
         WM[4 + threadIdx.x] = b;
     }
     // biases the W-first layers add inside their mix store functors: from LDS there, not from global memory (a global
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // for 'concat' with the condition at the END of the window, where the reference reads the prediction at the corrupt
         // frames' ORIGINAL indices, mocodad.py:829-838); with per-window frame sets (random_imp) every clear bit updates itself
         const int i = threadIdx.x - 128, n = i / T, t = i % T;
-        const int fixed = P.win_mask ? P.win_mask[window_of(n)] : P.fixed_mask;
+        const int fixed = P.win_mask ? P.win_mask[window_of(n)] : (int)P.fixed_mask;
         const int k = P.win_mask ? (((fixed >> t) & 1) ? -1 : 0) : P.upd_of[t];
         UPD[i] = k < 0 ? -1 : (n * T + (P.win_mask ? t : P.pos_of[k])) * 17;
     }

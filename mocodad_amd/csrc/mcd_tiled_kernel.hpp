@@ -441,7 +441,12 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
 #else
 #define TLMARK(id) do { } while (0)
 #endif
-template <int TP, int NB>
+// P.mode 1 (mcd_unet_forward): ONE pass at step P.step_single from the caller's x_in, eps-prediction to eps_out, no update.
+// LT = true (layer test, mcd_layer_forward): a single pass in which only stage P.lt_stage runs -- its input tensor lt_in is put
+// where the PREVIOUS layer's epilogue would have left it (the slab and / or the LDS hand-over regions, see `layer` below), its
+// output is copied to lt_out from where the stage's own epilogue puts it.  Stages 3, 5, 7, 9 are the fused (joint resampler +
+// layer) stages of this kernel: their input is the resampler's input (+ lt_skip, the U-Net skip tensor added behind it).
+template <int TP, int NB, bool LT = false>
 __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
     constexpr int TF = TP * NB;
@@ -491,7 +496,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
 #pragma unroll
             for (int c = 0; c < C0; ++c) {
                 float x;
-                if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
+                if (P.mode == 1) x = P.x_in ? P.x_in[((size_t)(b * C0 + c) * T + t) * 17 + v] : 0.f;
+                else if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
                 else {
                     const int e = (c * Tx + tx_of(fixed, t)) * 17 + v;
                     x = P.noise ? P.noise[((size_t)(s * K + 0) * P.B + b) * per + e]
@@ -500,7 +506,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 XT[((i * TP + t) * 17 + v) * 4 + c] = x;
             }
         }
-        for (int sidx = P.ns - 1; sidx >= 1; --sidx) {
+        const int i_first = P.mode == 1 ? P.step_single : P.ns - 1, i_last = P.mode == 1 ? P.step_single : 1;
+        for (int sidx = i_first; sidx >= i_last; --sidx) {
             const float* srow = P.step_table + sidx * (4 + EDIM);
             // opaque per step (see score_kernel): otherwise every per-lane address of every stage is hoisted out of the step
             // loop as loop-invariant and the hundreds of resulting registers are spilled
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 if (P.cond_emb) e += P.cond_emb[(size_t)b_of(tid / EDIM) * EDIM + tid % EDIM];
                 SE[tid] = e / (1.f + expf(-e));
             }
-            if (sidx > 1) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
+            if (sidx > 1 && P.mode == 0) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
                 const int k = P.ns - sidx;
                 for (int gi = tid; gi < NB * T * 9; gi += NTHREADS) {
                     const int i = gi / (T * 9), t = (gi / 9) % T, v0 = (gi % 9) * 2;
@@ -597,6 +604,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                if constexpr (LT) {
+                    if (P.lt_stage != L) return;
+                    // the stage's input, placed as the previous layer's epilogue (epi_fg of layer L - 1) places its output
+                    if constexpr (L > 0) {
+                        constexpr int LP = L - 1;
+                        constexpr LDesc DP = layer_desc(LP);
+                        constexpr bool HO17p = LP == 0 || LP == 1 || LP == 9, HOp = LP == 3 || LP == 5 || LP == 7;
+                        constexpr bool HORp = LP == 4 || LP == 6, HOCp = LP == 2 || LP == 8;
+                        constexpr int TNEXTp = (TF * (LP == 4 ? 10 : LP == 8 ? 17 : 12) + 16) * 36;
+                        constexpr int CI = DP.cout, VI = DP.V, CSP = cs_of(CI);
+                        float* xprev = const_cast<float*>(xin);
+                        for (int u = tid; u < NB * CI * T * VI; u += NTHREADS) {
+                            const int v = u % VI, t = (u / VI) % T, c = (u / (VI * T)) % CI, i = u / (VI * T * CI);
+                            const float val = P.lt_in[(((size_t)b_of(i) * CI + c) * T + t) * VI + v];
+                            const int gcol = (i * TP + t) * VI + v;
+                            if (HO17p || (HOp && c < 32)) RA[gcol * 36 + c] = val;
+                            else xprev[(size_t)gcol * CSP + c] = val;
+                            if (HORp && c < 32) RA[TNEXTp + gcol * 36 + c] = val;
+                            if (HOCp && gcol < TL_FC * VI) RA[TNEXTp + gcol * 36 + c] = val;
+                        }
+                        if (skip) {      // the U-Net skip tensor behind the fused resampler (d2 / d1; zeros when the caller gave none)
+                            float* sk = const_cast<float*>(skip);
+                            for (int u = tid; u < NB * CIN * T * V; u += NTHREADS) {
+                                const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % CIN, i = u / (V * T * CIN);
+                                sk[(size_t)((i * TP + t) * V + v) * CSI + c] =
+                                    P.lt_skip ? P.lt_skip[(((size_t)b_of(i) * CIN + c) * T + t) * V + v] : 0.f;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
                 float* const XA = RA;                                          // [ROWS + 16][CSV]
                 float* const ZA = RA + (ROWS + 16) * (L <= 1 ? 36 : CSZ);      // [ROWSG + 16][CSZ]  (layer 0: behind the next layer's X)
                 TlStage<ROWS, CINV> sx;                // plain input: a 32-channel part of all frames; resampled input: the skip rows
@@ -782,6 +820,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                     }
                 });
                 __syncthreads();
+                if constexpr (LT) {      // the stage's output, from where its epilogue put it
+                    for (int u = tid; u < NB * COUT * T * V; u += NTHREADS) {
+                        const int v = u % V, t = (u / V) % T, c = (u / (V * T)) % COUT, i = u / (V * T * COUT);
+                        const int gcol = (i * TP + t) * V + v;
+                        const float val = (HO17 || (HO && c < 32)) ? RA[gcol * 36 + c] : xout[(size_t)gcol * CSO + c];
+                        if (grp * NB + i < P.n_chains) P.lt_out[(((size_t)b_of(i) * COUT + c) * T + t) * V + v] = val;
+                    }
+                    __syncthreads();
+                }
             };
 #define TL_C(x) std::integral_constant<int, x>{}
             TLMARK(60);                                                     // pass prologue (noise, embeddings)
@@ -797,10 +844,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             layer(TL_C(8), TL_NORS, A0, false, A1, nullptr);
             layer(TL_C(9), TL_C(3), A1, false, A0, D1);                     // up2 + d1 on the way in
             TLMARK(61);
-            {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
+            if (!LT || P.lt_stage == 10) {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                if constexpr (LT) {      // layer 9's output as its epilogue hands it over: the X region, row stride 36
+                    for (int u = tid; u < NB * 32 * T * 17; u += NTHREADS) {
+                        const int v = u % 17, t = (u / 17) % T, c = (u / (17 * T)) % 32, i = u / (17 * T * 32);
+                        RA[((i * TP + t) * 17 + v) * 36 + c] = P.lt_in[(((size_t)b_of(i) * 32 + c) * T + t) * 17 + v];
+                    }
+                    __syncthreads();
+                }
                 MixLongCoef<16, 17, TP, NB> mc10;      // (the mix's first coefficients: in flight behind the product)
                 mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
                 const float* w4 = wb + N.wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
@@ -848,6 +902,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
                         const int c = u % C0, col = u / C0, f = col / 17, i = f / TP, t = f % TP, v = col % 17;
                         const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[N.bias[10] + c], slope10) + EMB[i * EMBS + emb_off(10) + c];
                         const float eps = l10 + XT[col * 4 + c];
+                        if constexpr (LT) {      // layer 10 alone: without the U-Net's residual (+ x)
+                            if (t < T && grp * NB + i < P.n_chains) P.lt_out[(((size_t)b_of(i) * C0 + c) * T + t) * 17 + v] = l10;
+                        }
+                        if (P.mode == 1) {
+                            if (t < T && P.eps_out && grp * NB + i < P.n_chains) P.eps_out[(((size_t)b_of(i) * C0 + c) * T + t) * 17 + v] = eps;
+                            continue;
+                        }
                         const int k = t >= T ? -1 : P.win_mask ? (((fixed_of(i) >> t) & 1u) ? -1 : 0) : M.upd_of[t];
                         if (k >= 0) {
                             const int tp = P.win_mask ? t : M.pos_of[k];
@@ -865,6 +926,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScorePar
             }
         }
         __syncthreads();
+        if (P.mode == 1) continue;
         // ---- loss over the corrupt frames (mocodad.py:484)
         for (int i = 0; i < NB; ++i) {
             if (grp * NB + i >= P.n_chains) break;

@@ -162,8 +162,15 @@ class HipScorer:
         tab = self.table(noise_steps if noise_steps is not None else max(int(t) + 1, 2))
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
-            _lib.check(self.L.mcd_unet_forward(self._h, _ptr(x), _ptr(cond), _ptr(tab), int(t), x.shape[0], _ptr(out), _stream()))
+            ws = self._pass_workspace(x.shape[0])
+            _lib.check(self.L.mcd_unet_forward(self._h, _ptr(x), _ptr(cond), _ptr(tab), int(t), x.shape[0], _ptr(out), _ptr(ws), _stream()))
         return out
+
+    def _pass_workspace(self, n_windows: int) -> Optional[torch.Tensor]:
+        """Scratch of the single-pass entries (mcd_pass_workspace_bytes): the slab-tiled kernel's activation slabs; None for
+        1 .. 12 U-Net frames.  Call inside `torch.cuda.device(self.device)`."""
+        nbytes = int(self.L.mcd_pass_workspace_bytes(self._h, int(n_windows)))
+        return torch.empty(nbytes, device=self.device, dtype=torch.uint8) if nbytes > 0 else None
 
     def score(self, data, *, n_samples: int, noise_steps: int, noise: Optional[torch.Tensor] = None,
               seed: int = 0, first_window_id: int = 0, loss_fn: str = "smooth_l1", want_poses: bool = False,
@@ -255,16 +262,31 @@ class HipScorer:
                5: (64, 10, 128, 10), 6: (128, 10, 64, 10), 7: (64, 12, 64, 12), 8: (64, 12, 32, 12), 9: (32, 17, 32, 17),
                10: (32, 17, 2, 17), 11: (32, 17, 32, 12), 12: (64, 12, 64, 10), 13: (64, 10, 64, 12), 14: (32, 12, 32, 17)}
 
-    def layer_forward(self, stage: int, x: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    # the fused (joint resampler + layer) stages of the slab-tiled kernel (13 .. 32 U-Net frames): the stage's input is the
+    # RESAMPLER's input (Cin, Vin); the skip tensor of stages 7 / 9 has the layer's own (Cin, V)
+    _FUSED_IN = {3: (32, 17), 5: (64, 12), 7: (64, 10), 9: (32, 12)}
+
+    def layer_forward(self, stage: int, x: torch.Tensor, emb: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
         """TEST ENTRY: one U-Net stage alone (0..10 ST-GCN layers, 11..14 down1/down2/up3/up2), x (B,Cin,T,Vin),
-        emb (B,emb_dim) -> (B,Cout,T,Vout)."""
+        emb (B,emb_dim) -> (B,Cout,T,Vout).  13 .. 32 U-Net frames (slab-tiled kernel): stages 3, 5, 7, 9 are joint resampler +
+        layer (x = the resampler's input; `skip` = d2 / d1 for stages 7 / 9), stages 11..14 do not exist on their own."""
         cin, vin, cout, vout = self._STAGES[int(stage)]
+        tiled = self.t_unet > 12
+        if tiled and int(stage) in self._FUSED_IN:
+            lcin, lvin = cin, vin
+            cin, vin = self._FUSED_IN[int(stage)]
+            if skip is not None:
+                self._check_shape("skip", skip, (lcin, self.t_unet, lvin))
+                skip = _f32c(skip, self.device)
+        elif skip is not None:
+            raise ValueError("skip: only the fused stages 7 and 9 of the slab-tiled kernel (13 .. 32 U-Net frames) take one")
         self._check_shape("x", x, (cin, self.t_unet, vin))
         self._check_shape("emb", emb, (self.emb_dim,))
         x, emb = _f32c(x, self.device), _f32c(emb, self.device)
         out = torch.empty(x.shape[0], cout, self.t_unet, vout, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            _lib.check(self.L.mcd_layer_forward(self._h, int(stage), _ptr(x), _ptr(emb), x.shape[0], _ptr(out), _stream()))
+            ws = self._pass_workspace(x.shape[0])
+            _lib.check(self.L.mcd_layer_forward(self._h, int(stage), _ptr(x), _ptr(skip), _ptr(emb), x.shape[0], _ptr(out), _ptr(ws), _stream()))
         return out
 
     def philox_noise(self, n_windows: int, *, n_samples: int, noise_steps: int, seed: int = 0, first_window_id: int = 0) -> torch.Tensor:

@@ -414,6 +414,138 @@ def extra5(MoCoDAD):
         save(f"traj_hostile_{vname}_ns{ns}_S{S}.npz", **tr)
 
 
+# `--extra6` (round 4): reference-generated pins for the kernels written in round 3 -- the slab-tiled kernel (13 .. 32 U-Net
+# frames: 16 = seg_len 32 inject, 24 and 32 = concat over the whole window) and the other score_kernel instantiations
+# (5 = seg_len 10 inject, 10 = seg_len 20 inject, 7 = concat over 7 frames) -- each with benign (perturb_ + tame_) and with
+# hostile_ weight statistics: weights, stage I/O, single passes (t = 1, 9), trajectories (ns 10, S 2, every aggregation), and
+# one long chain on the tiled kernel (concat over 24 frames, ns 50).  To keep the files small: stage inputs / pass inputs are
+# fp16-representable and stored as float16 (exact), the stage fixtures of the long windows hold one window, and the condition
+# autoencoder's DECODER (dead at eval: mocodad.py:157 drops the reconstruction) is zeroed so that it compresses away.
+EXTRA6 = {   # name: (strategy, seg_len, conditioning_indices, B_traj, B_layers)
+    "seg10": ("inject", 10, 2, 4, 2), "seg20": ("inject", 20, 2, 4, 2), "cat7": ("concat", 7, [0, 1, 2], 4, 2),
+    "seg32": ("inject", 32, 2, 2, 1), "cat24": ("concat", 24, 2, 2, 1), "cat32": ("concat", 32, 2, 2, 1),
+}
+EXTRA6_LONG = ("cat24", 50, 2, 2)      # variant, ns, S, B
+
+
+def _zero_decoder_(m):
+    ce = m.condition_encoder
+    if ce is None:
+        return
+    for name in ("decoder", "rev_btlnk"):
+        mod = getattr(ce, name, None)
+        if mod is not None:
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                if t.dtype.is_floating_point:
+                    t.zero_()
+
+
+def _traj(m, data, noise, seg_len):
+    B = data.shape[0]
+    S, K = noise.shape[:2]
+    trans = torch.arange(B) % 5
+    meta = torch.stack([torch.ones(B), torch.arange(B) // 4 + 1, torch.arange(B) % 3 + 1, torch.arange(B) * 2 + 1], 1).long()
+    frames = (meta[:, 3:4] + torch.arange(seg_len)[None]).int()
+    batch = [data, trans, meta, frames]
+    tr = dict(data=data, noise=noise.half(), trans=trans, meta=meta, frames=frames)
+    orig = torch.randn_like
+    for aggr in ("all", "best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3"):
+        feeder = NoiseFeeder(noise)
+        torch.randn_like = feeder
+        try:
+            o = m.forward(batch, aggr_strategy=aggr, return_="all")
+        finally:
+            torch.randn_like = orig
+        assert feeder.calls == S * K
+        key = aggr.replace(":", "_").replace(".", "p")
+        if aggr == "all":
+            tr["loss_all"], tr["poses_all"] = o[0], o[1]
+        else:
+            tr[f"loss_{key}"] = o[0]
+            if o[1] is not None:
+                tr[f"pose_{key}"] = o[1]
+    if m.condition_encoder is not None:
+        cd, _, _ = m._select_frames(data)
+        tr["cond_emb"] = m.condition_encoder(cd, t=None)[0]
+    assert torch.isfinite(tr["poses_all"]).all()
+    return tr
+
+
+def extra6(MoCoDAD):
+    ns, S = 10, 2
+    for vname, (strategy, seg_len, cond_idx, B, BL) in EXTRA6.items():
+        for hostile in (False, True):
+            name = ("hostile_" if hostile else "") + vname
+            gen = torch.Generator().manual_seed(6000 + 17 * len(vname) + seg_len + (500 if hostile else 0))
+            args, cfg = make_args(strategy=strategy, seg_len=seg_len, cond_idx=cond_idx, noise_steps=ns, n_gen=S, aggr="all", ret="all")
+            torch.manual_seed(60 + seg_len + (1 if hostile else 0))
+            m = MoCoDAD(args).eval()
+            Tu = m.input_n_frames
+            if hostile:
+                hostile_(m, gen)
+                xc = torch.randn(8, 2, Tu, 17, generator=gen)
+                cdat = (synth_windows(8, m.n_frames_condition, gen) * 3).clamp_(-5, 5) if m.condition_encoder is not None else None
+
+                def run():
+                    cond = m.condition_encoder(cdat, t=None)[0] if cdat is not None else None
+                    m.model(xc, torch.full((8,), 5, dtype=torch.long), condition_data=cond)
+                calibrate_(m, run)
+            else:
+                perturb_(m, gen)
+                tame_(m, 0.25)
+            _zero_decoder_(m)
+            save(f"weights_{name}.npz", __cfg__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **state_to_np(m))
+            # stage I/O (inputs fp16-representable, stored as float16)
+            unet = m.model
+            lay = {"emb_in": fp16_round(torch.randn(BL, 16, generator=gen))}
+            blocks = [("st_gcnnsp1a", 0), ("st_gcnnsd1", 0), ("st_gcnnsd1", 1), ("st_gcnnsd2", 0), ("st_gcnnsd2", 1), ("st_gcnnsd3", 0),
+                      ("st_gcnnsd3", 1), ("st_gcnnsu4", 0), ("st_gcnnsu4", 1), ("st_gcnnsu3", 0), ("st_gcnnsu3", 1)]
+            for bi, (bn, li) in enumerate(blocks):
+                layer = getattr(unet, bn)[li]
+                x = fp16_round(torch.randn(BL, layer.in_channels, Tu, layer.joints_dim, generator=gen))
+                lay[f"L{bi}_in"] = x.half()
+                lay[f"L{bi}_out"] = layer(x, lay["emb_in"])
+            for rn in ("down1", "down2", "up3", "up2"):
+                cl = getattr(unet, rn)
+                ch = {"down1": 32, "down2": 64, "up3": 64, "up2": 32}[rn]
+                x = fp16_round(torch.randn(BL, ch, Tu, cl.block[0].in_channels, generator=gen))
+                lay[f"{rn}_in"] = x.half()
+                lay[f"{rn}_out"] = cl(x.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()   # stsae_unet.py:205,213,381,391
+            lay["emb_in"] = lay["emb_in"].half()
+            if m.condition_encoder is not None:
+                ci = fp16_round((synth_windows(BL, m.n_frames_condition, gen) * (3 if hostile else 1)).clamp_(-5, 5))
+                lay["cond_in"] = ci.half()
+                lay["cond_emb"] = m.condition_encoder(ci, t=None)[0]
+            save(f"layers_{name}.npz", **lay)
+            # single passes
+            ps = {"x": fp16_round(torch.randn(B, 2, Tu, 17, generator=gen))}
+            cond = fp16_round(torch.randn(B, 16, generator=gen) * 0.5) if strategy == "inject" else None
+            for tval in (1, 9):
+                ps[f"eps_t{tval}"] = m.model(ps["x"], torch.full((B,), tval, dtype=torch.long), condition_data=cond)[0]
+            ps["x"] = ps["x"].half()
+            if cond is not None:
+                ps["cond"] = cond.half()
+            save(f"pass_{name}.npz", **ps)
+            # trajectories
+            data = (synth_windows(B, seg_len, gen) * 3).clamp_(-5, 5) if hostile else synth_windows(B, seg_len, gen)
+            Tx = m.n_frames_corrupt
+            noise = fp16_round(torch.randn(S, ns - 1, B, 2, Tx, 17, generator=gen))
+            tr = _traj(m, data, noise, seg_len)
+            print(name, "T_u", Tu, "max |pose|", float(tr["poses_all"].abs().max()), "loss range", float(tr["loss_all"].min()),
+                  float(tr["loss_all"].max()), "max |eps|", float(ps["eps_t9"].abs().max()))
+            save(f"traj_{name}_ns{ns}_S{S}.npz", **tr)
+            if not hostile and vname == EXTRA6_LONG[0]:
+                _, nsl, Sl, Bl = EXTRA6_LONG
+                argsl, _ = make_args(strategy=strategy, seg_len=seg_len, cond_idx=cond_idx, noise_steps=nsl, n_gen=Sl, aggr="all", ret="all")
+                ml = MoCoDAD(argsl).eval()
+                ml.load_state_dict(m.state_dict())
+                datal = synth_windows(Bl, seg_len, gen)
+                noisel = fp16_round(torch.randn(Sl, nsl - 1, Bl, 2, Tx, 17, generator=gen))
+                trl = _traj(ml, datal, noisel, seg_len)
+                print(name, "long chain: max |pose|", float(trl["poses_all"].abs().max()), "loss range", float(trl["loss_all"].min()), float(trl["loss_all"].max()))
+                save(f"traj_{name}_ns{nsl}_S{Sl}.npz", **trl)
+
+
 def extra2():
     """Test-time affine transforms of the reference's dataset (utils/dataset_utils.py:255-310; applied in
     utils/dataset.py:67-76): `python tests/golden/gen_golden.py --extra2`."""
@@ -450,6 +582,9 @@ def main():
         return
     if "--extra5" in sys.argv:
         extra5(MoCoDAD)
+        return
+    if "--extra6" in sys.argv:
+        extra6(MoCoDAD)
         return
 
     # ---------------------------------------------------------------- 5. schedules

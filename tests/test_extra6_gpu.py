@@ -1,0 +1,153 @@
+"""GPU: the kernels written in round 3 against REFERENCE-generated vectors (tests/golden/gen_golden.py --extra6): the slab-tiled
+kernel (16, 24 and 32 U-Net frames: seg_len 32 inject, concat over 24 / 32 frames) and the other score_kernel instantiations
+(5, 10 = seg_len 10 / 20 inject, 7 = concat over 7 frames), each with benign and with hostile weight statistics:
+  * every stage alone through mcd_layer_forward (reference: ST_GCNN_layer.forward stsgcn.py:94-116, CNN_layer stsgcn.py:187-199
+    as called at stsae_unet.py:205,213,381,391) -- for 13 .. 32 frames with the joint resamplers fused into the following layer,
+    as that kernel runs them (the reference's composition of the two stages on the same input is recomputed by the ORACLE's
+    stage functions from the fixture's tensors, and both of its factors are pinned to the reference in test_oracle_golden.py);
+  * single passes (STSAE_Unet.forward, stsae_unet.py:406-438) through mcd_unet_forward -- the production kernel in single-pass
+    mode, slab-tiled included -- and through the plain-FMA runtime-shape kernel;
+  * whole trajectories (MoCoDAD.forward, mocodad.py:129-184), every aggregation, the MFMA kernel and the plain-FMA cross-check;
+  * one long chain on the slab-tiled kernel (concat over 24 frames, ns 50: cumulative gain 1014x).
+Bound: 1e-4 relative to max(1, largest reference value) of the compared tensor (north_star: scores within 1e-4)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+EXTRA6 = ["seg10", "seg20", "cat7", "seg32", "cat24", "cat32"]
+EXTRA6_ALL = EXTRA6 + ["hostile_" + v for v in EXTRA6]
+
+
+def _f32(g):
+    return {k: (v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in g.items()}
+
+
+def _scorer(variant):
+    from mocodad_amd.engine import HipScorer
+    from oracle import mocodad_oracle as O
+    w = load_golden(f"weights_{variant}.npz")
+    cfg = json.loads(bytes(w.pop("__cfg__")).decode())
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    strat = cfg["conditioning_strategy"]
+    ci, xi = O.split_indices(cfg["seg_len"], cfg["conditioning_indices"], strat)
+    sc = HipScorer(sd, strategy=strat, seg_len=cfg["seg_len"], cond_idx=ci, corrupt_idx=xi,
+                   cond_channels=list(cfg["channels"]) + [cfg["h_dim"]], device="cuda:0")
+    return sc, sd, cfg
+
+
+def _close(out, ref, what, rel=1e-4):
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(out - ref).max()) / scale
+    assert np.isfinite(out).all(), what
+    assert err <= rel, f"{what}: scaled error {err:.3e} (largest reference value {scale:.2f})"
+    return err
+
+
+@pytest.mark.parametrize("variant", EXTRA6_ALL)
+def test_every_stage_vs_reference_layer_io(variant):
+    from oracle import mocodad_oracle as O
+    sc, sd, _ = _scorer(variant)
+    sdo = O.to_torch_state({k: v.numpy() for k, v in sd.items()})
+    g = _f32(load_golden(f"layers_{variant}.npz"))
+    e = torch.from_numpy(g["emb_in"])
+    tiled = sc.t_unet > 12
+    worst = 0.0
+    blocks = O.UNET_DOWN + O.UNET_MID1 + O.UNET_MID2 + O.UNET_UP4 + O.UNET_UP3
+    fused = {3: "down1", 5: "down2", 7: "up3", 9: "up2"}
+    for i in range(11):
+        if tiled and i in fused:
+            # the fused stage of the slab-tiled kernel: resampler input (+ skip) -> layer output; expected value = the oracle's
+            # layer applied to the oracle's resampler output (each pinned to the reference's own I/O on these very tensors)
+            rn = fused[i]
+            xr = torch.from_numpy(g[f"{rn}_in"])
+            mid = O.joint_resample(sdo, f"model.{rn}", xr)
+            np.testing.assert_allclose(mid.numpy(), g[f"{rn}_out"], atol=2e-6 * max(1.0, float(np.abs(g[f"{rn}_out"]).max())), rtol=1e-6)
+            skip = None
+            if i in (7, 9):          # + the U-Net skip tensor: the fixture's input of the layer serves as d2 / d1
+                skip = torch.from_numpy(g[f"L{i}_in"])
+                mid = mid + skip
+            b, li = blocks[i]
+            ref = O.st_gcnn_layer(sdo, f"model.{b}.{li}", mid, e).numpy()
+            out = sc.layer_forward(i, xr, e, skip=skip).cpu().numpy()
+            worst = max(worst, _close(out, ref, f"{variant} fused stage {rn} + layer {i}", 2e-5))
+            if i in (7, 9):          # ... and without a skip tensor
+                ref0 = O.st_gcnn_layer(sdo, f"model.{b}.{li}", O.joint_resample(sdo, f"model.{rn}", xr), e).numpy()
+                worst = max(worst, _close(sc.layer_forward(i, xr, e).cpu().numpy(), ref0, f"{variant} fused stage {rn} + layer {i}, no skip", 2e-5))
+        else:
+            out = sc.layer_forward(i, torch.from_numpy(g[f"L{i}_in"]), e).cpu().numpy()
+            worst = max(worst, _close(out, g[f"L{i}_out"], f"{variant} layer {i}", 2e-5))
+    if not tiled:
+        for sid, rn in ((11, "down1"), (12, "down2"), (13, "up3"), (14, "up2")):
+            out = sc.layer_forward(sid, torch.from_numpy(g[f"{rn}_in"]), e).cpu().numpy()
+            worst = max(worst, _close(out, g[f"{rn}_out"], f"{variant} {rn}", 2e-5))
+    else:
+        with pytest.raises(RuntimeError):
+            sc.layer_forward(11, torch.from_numpy(g["down1_in"]), e)
+    if "cond_in" in g:
+        emb = sc.cond_encode(torch.from_numpy(g["cond_in"])).cpu().numpy()
+        worst = max(worst, _close(emb, g["cond_emb"], f"{variant} condition encoder"))
+    print(f"{variant} (T_u = {sc.t_unet}): max scaled |stage output - reference| = {worst:.3e}")
+
+
+@pytest.mark.parametrize("variant", EXTRA6_ALL)
+def test_unet_pass_vs_reference(variant):
+    sc, _, _ = _scorer(variant)
+    g = _f32(load_golden(f"pass_{variant}.npz"))
+    x = torch.from_numpy(g["x"])
+    cond = torch.from_numpy(g["cond"]) if "cond" in g else None
+    worst = 0.0
+    for generic in (0, 1):
+        sc.set_option("generic_unet", generic)
+        for tv in (1, 9):
+            eps = sc.unet_forward(x, tv, cond, noise_steps=10).cpu().numpy()
+            worst = max(worst, _close(eps, g[f"eps_t{tv}"], f"{variant} pass t={tv} generic={generic}"))
+    sc.set_option("generic_unet", 0)
+    # a ragged batch: fewer windows than a workgroup holds chains, and one more than that
+    for nb in (1, 3):
+        xs = torch.cat([x, x])[:nb]
+        cs = None if cond is None else torch.cat([cond, cond])[:nb]
+        ref = np.concatenate([g["eps_t9"], g["eps_t9"]])[:nb]
+        _close(sc.unet_forward(xs, 9, cs, noise_steps=10).cpu().numpy(), ref, f"{variant} pass, {nb} windows")
+    print(f"{variant} (T_u = {sc.t_unet}): max scaled |eps - reference| = {worst:.3e}")
+
+
+def _check_trajectory(variant, ns, S):
+    sc, _, _ = _scorer(variant)
+    g = load_golden(f"traj_{variant}_ns{ns}_S{S}.npz")
+    data = torch.from_numpy(g["data"])
+    noise = torch.from_numpy(g["noise"].astype(np.float32))
+    worst = 0.0
+    if "cond_emb" in g:
+        _close(sc.cond_encode(data[:, :, sc.cond_idx, :]).cpu().numpy(), g["cond_emb"], f"{variant} condition embedding")
+    for generic in (0, 1):
+        sc.set_option("generic_unet", generic)
+        loss, poses = sc.score(data, n_samples=S, noise_steps=ns, noise=noise, want_poses=True)
+        worst = max(worst, _close(loss.cpu().numpy(), g["loss_all"], f"{variant} scores generic={generic}"))
+        _close(poses.cpu().numpy(), g["poses_all"], f"{variant} poses generic={generic}")
+        for aggr in ("best", "worst", "mean", "median", "mean_pose", "median_pose", "quantile:0.3"):
+            key = aggr.replace(":", "_").replace(".", "p")
+            sel, l = sc.aggregate(data, loss, poses, aggr, noise_steps=ns)
+            _close(l.cpu().numpy(), g[f"loss_{key}"], f"{variant} {aggr}")
+            if sel is not None:
+                _close(sel.cpu().numpy(), g[f"pose_{key}"], f"{variant} {aggr} pose")
+    sc.set_option("generic_unet", 0)
+    for split in (0, 1, S):
+        sc.set_option("split", split)
+        agg, all_, _ = sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation="best", noise=noise, want_all=True)
+        _close(agg.cpu().numpy(), g["loss_best"], f"{variant} fused best, split {split}")
+        _close(all_.cpu().numpy(), g["loss_all"], f"{variant} fused all, split {split}")
+    print(f"{variant} ns={ns} S={S} (T_u = {sc.t_unet}): max scaled |score - reference| = {worst:.3e} on scores up to {float(np.abs(g['loss_all']).max()):.2f}")
+
+
+@pytest.mark.parametrize("variant", EXTRA6_ALL)
+def test_trajectory_vs_reference(variant):
+    _check_trajectory(variant, 10, 2)
+
+
+def test_long_chain_on_the_tiled_kernel():
+    _check_trajectory("cat24", 50, 2)

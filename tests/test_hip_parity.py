@@ -237,8 +237,9 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     # 13 .. 32 U-Net frames: the slab-tiled MFMA kernel (frame count padded to 16 / 24 / 32), cross-checked with the plain-FMA kernel
     ("inject", 32, 2, "AE"), ("concat", 24, [0, 1, 2, 3], "AE"), ("concat", 13, [0, 1, 2], "AE"), ("inject", 26, 2, "E_unet"),
     ("concat", 20, [0, 1], "AE"), ("inbetween_imp", 30, 3, "AE"), ("no_condition", 17, None, "AE"), ("concat", 32, [28, 29, 30, 31], "AE"),
-    # 26 .. 31 condition frames: the plain condition encoder with one of its three activation buffers in global scratch
-    ("inject", 32, list(range(28)), "AE"), ("inject", 30, list(range(4, 30)), "AE"), ("inject", 32, list(range(31)), "E_unet")])
+    # 25 .. 31 condition frames: the plain condition encoder with one of its three activation buffers in global scratch
+    ("inject", 32, list(range(28)), "AE"), ("inject", 30, list(range(4, 30)), "AE"), ("inject", 32, list(range(31)), "E_unet"),
+    ("inject", 32, list(range(25)), "AE")])
 def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 1, 2, 4, 5, 7 .. 11 frames on the
     specialised kernels (seg_len 10 split 5 + 5, seg_len 20 split 10 + 10, concat over 10 frames, a 1-frame window, ...); 13 .. 32
@@ -257,7 +258,10 @@ def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     with torch.no_grad():
         p_ref, corrupt = O.reverse_diffusion(sd, data, noise, noise_steps=ns, strategy=strategy, conditioning_indices=ci)
         l_ref = O.window_losses(p_ref, corrupt)
-    scale = max(1.0, float(p_ref.abs().max()))
+    # the bound is the absolute 1e-4 everywhere except on the long chains of predictions (concat / imputation over more than 12
+    # U-Net frames, where a prediction's error feeds the next frame's input): relative to the largest pose there
+    long_chain = strategy in ("concat", "inbetween_imp") and m.input_n_frames > 12
+    scale = max(1.0, float(p_ref.abs().max())) if long_chain else 1.0
     np.testing.assert_allclose(out[1].cpu().numpy(), p_ref.transpose(0, 1).numpy(), atol=ATOL * scale, rtol=1e-5)
     np.testing.assert_allclose(out[0].cpu().numpy(), l_ref.t().numpy(), atol=ATOL * scale, rtol=0)
     # perf mode (in-kernel Philox) == the same kernel fed with the exported draws

@@ -108,7 +108,9 @@ def test_random_configuration_vs_oracle(seed):
     noise = torch.randn(S, max(ns - 1, 1), B, 2, Tx, 17, generator=gen)
     mask = None
     if c["strategy"] == "random_imp":
-        mask = torch.tensor([sum(1 << f for f in random.Random(abs(seed) * 100 + b + (50000 if seed < 0 else 0)).sample(range(T), c["ci"])) for b in range(B)], dtype=torch.int32)
+        # (built in int64 and wrapped to int32: bit 31 -- frame 31 of a 32-frame window as a condition frame -- is the sign bit)
+        mask = torch.tensor([sum(1 << f for f in random.Random(abs(seed) * 100 + b + (50000 if seed < 0 else 0)).sample(range(T), c["ci"])) for b in range(B)], dtype=torch.int64)
+        mask = torch.where(mask >= 2 ** 31, mask - 2 ** 32, mask).to(torch.int32)
     batch = [data, torch.zeros(B), torch.zeros(B, 4), torch.zeros(B, T)]
     out = m.forward(batch, aggr_strategy=c["aggr"], return_="all", noise=noise, cond_mask=mask)
     only = m.forward(batch, aggr_strategy=c["aggr"], return_="loss", noise=noise, cond_mask=mask)      # loss only: the fused call
@@ -124,3 +126,31 @@ def test_random_configuration_vs_oracle(seed):
     np.testing.assert_allclose(only[0].cpu().numpy(), loss.numpy(), atol=ATOL * scale, rtol=0, err_msg=msg)
     if sel is not None and out[1] is not None:
         np.testing.assert_allclose(out[1].cpu().numpy(), sel.numpy(), atol=ATOL * max(1.0, float(sel.abs().max())), rtol=1e-5, err_msg=msg)
+
+
+def test_random_imp_with_frame_31_as_condition():
+    """'random_imp' over a 32-frame window whose per-window condition sets include frame 31: bit 31 of the int32 mask (the sign
+    bit) -- the kernels treat the mask as unsigned."""
+    from mocodad_amd.models.mocodad import MoCoDAD
+    from oracle import mocodad_oracle as O
+    _, cfg = golden_weights("inject")
+    torch.manual_seed(31)
+    m = MoCoDAD(make_args(cfg, conditioning_strategy="random_imp", seg_len=32, conditioning_indices=5, noise_steps=3, n_generated_samples=2))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda:0")
+    gen = torch.Generator().manual_seed(3131)
+    B, S, ns, T = 3, 2, 3, 32
+    data = torch.randn(B, 2, T, 17, generator=gen).clamp_(-3, 3)
+    noise = torch.randn(S, ns - 1, B, 2, m.n_frames_corrupt, 17, generator=gen)
+    sets = [[31, 0, 7, 16, 30], [3, 31, 12, 13, 14], [1, 2, 4, 8, 31]]
+    mask64 = torch.tensor([sum(1 << f for f in fs) for fs in sets], dtype=torch.int64)
+    mask = torch.where(mask64 >= 2 ** 31, mask64 - 2 ** 32, mask64).to(torch.int32)
+    assert (mask < 0).all()
+    batch = [data, torch.zeros(B), torch.zeros(B, 4), torch.zeros(B, T)]
+    out = m.forward(batch, aggr_strategy="all", return_="all", noise=noise, cond_mask=mask)
+    with torch.no_grad():
+        poses, corrupt = O.reverse_diffusion(sd, data, noise, noise_steps=ns, strategy="random_imp", conditioning_indices=5, cond_mask=mask)
+        loss = O.window_losses(poses, corrupt)
+    scale = max(1.0, float(poses.abs().max()))
+    np.testing.assert_allclose(out[0].cpu().numpy(), loss.t().numpy(), atol=ATOL * scale, rtol=0)
+    np.testing.assert_allclose(out[1].cpu().numpy(), poses.transpose(0, 1).numpy(), atol=ATOL * scale, rtol=1e-5)
