@@ -260,6 +260,63 @@ def cpu_baseline(sd, cfg, ns, S, budget_s=20.0):
             "sample": f"one batch of {n} windows, ns={ns}, S={S}, oracle/mocodad_oracle.py (PyTorch CPU, {threads} threads), {dt:.1f}s"}
 
 
+def auc_vs_ref(sc, sd, cfg, ns, S, seeds=200, oracle_seeds=2, with_oracle=True):
+    """`AUC vs ref` of BASELINE.json's metric, next to the throughput (untimed): a fixed synthetic clip set
+    (mocodad_amd.data.synthetic.make_dataset: per-person trajectories with jerkier anomalous intervals, ground-truth frame
+    masks) scored (a) by the benchmarked mode -- in-kernel Philox noise -- and (b) by the SAME kernel fed with torch.randn
+    draws (the parity mode the golden trajectories pin to the reference within 1e-4 per score), `seeds` seeds each (the
+    seed-to-seed spread of the AUC on a small clip set is ~0.03, so the means need that many; replicas of the clip set under
+    distinct window ids share a launch); and (c), for `oracle_seeds` CPU-drawn noise tensors, by the CPU oracle (the reference
+    path restated; checker only) against the kernel on the same draws.  Frame scores by mcd_frame_scores (mocodad.py:362-425 on
+    device), AUC by sklearn's roc_auc_score (mocodad.py:428)."""
+    from sklearn.metrics import roc_auc_score
+    from mocodad_amd.data import synthetic
+    from mocodad_amd.engine import FrameScoreAssembler
+    seg_len, strat, ci = cfg["seg_len"], cfg["conditioning_strategy"], cfg["conditioning_indices"]
+    _, xi = frame_split(seg_len, ci, strat)
+    data, trans, meta, frames, gts = synthetic.make_dataset(n_clips=3, frames_per_clip=max(80, 3 * seg_len), persons_per_clip=2,
+                                                            seg_len=seg_len, num_transform=2)
+    N = data.shape[0]
+    dev = sc.device
+    asm = FrameScoreAssembler(gts, {}, num_transform=2, pad_size=-1, filter_kernel_size=3, frames_shift=2, device=dev)
+    ddata, dtrans, dmeta, dframes = data.to(dev), trans.to(dev), meta.to(dev), frames.to(dev)
+    auc = lambda best: float(roc_auc_score(asm.gt, asm(best, dtrans, dmeta, dframes)))
+    # replicas per launch: bounded by the noise tensor of the parity mode (S x (ns-1) x N R x 2 x Tx x 17 floats <= ~1 GB)
+    per_rep = S * max(ns - 1, 1) * N * 2 * len(xi) * 17 * 4
+    R = int(max(1, min(50, seeds, (1 << 30) // per_rep)))
+    calls = (seeds + R - 1) // R
+    rep = ddata.repeat(R, 1, 1, 1)
+    gen = torch.Generator(device=dev).manual_seed(2026)
+    philox, randn = [], []
+    for c in range(calls):
+        z = torch.randn(S, max(ns - 1, 1), N * R, 2, len(xi), 17, device=dev, generator=gen)
+        runs = (sc.score(rep, n_samples=S, noise_steps=ns, seed=4242, first_window_id=c * N * R)[0], sc.score(rep, n_samples=S, noise_steps=ns, noise=z)[0])
+        for dst, loss in zip((philox, randn), runs):
+            best = loss.min(1)[0].view(R, N)
+            dst.extend(auc(best[r]) for r in range(R))
+        del z
+    a, b = np.array(philox), np.array(randn)
+    n = len(a)
+    se = float(np.sqrt((a.var(ddof=1) + b.var(ddof=1)) / n))
+    out = {"hip": round(float(a.mean()), 5), "ref_noise": round(float(b.mean()), 5), "abs_diff": round(abs(float(a.mean() - b.mean())), 5),
+           "std_err_of_diff": round(se, 5), "seeds": n, "seed_std": round(float(np.concatenate([a, b]).std(ddof=1)), 5), "windows": N,
+           "note": "hip = benchmarked mode (in-kernel Philox); ref_noise = same kernel on torch.randn draws (the mode pinned to the "
+                   "reference); means over the seeds of the AUC on a fixed synthetic clip set"}
+    if with_oracle and oracle_seeds > 0:
+        from oracle import mocodad_oracle as O
+        ao, ah, same = [], [], []
+        for k in range(oracle_seeds):
+            g = torch.Generator().manual_seed(k)
+            noise = torch.randn(S, max(ns - 1, 1), N, 2, len(xi), 17, generator=g)
+            best = sc.score(ddata, n_samples=S, noise_steps=ns, noise=noise)[0].min(1)[0]
+            with torch.no_grad():
+                ref = O.score(sd, data, noise, noise_steps=ns, strategy=strat, conditioning_indices=ci, aggregation="best")[1]
+            ao.append(round(auc(ref), 6)); ah.append(round(auc(best), 6)); same.append(float((best.cpu() - ref).abs().max()))
+        out["oracle_same_noise"] = {"auc_oracle": ao, "auc_hip": ah, "max_abs_score_diff": float(f"{max(same):.3e}"), "seeds": oracle_seeds,
+                                    "note": "CPU oracle (reference path restated) and the kernel on the same CPU-drawn noise: same scores, same AUC"}
+    return out
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -301,6 +358,7 @@ def main():
                     "when the workgroups own whole windows (MCD_OPT_COND_GENERIC)")
     ap.add_argument("--phase", type=int, default=0, help="tuning experiment: start offset of the second half of the grid, x 1024 cycles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auc", action="store_true", help="skip the (untimed) AUC-vs-reference leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational H2D-inclusive and opt-in legs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample (all threads + one thread)")
     ap.add_argument("--dist-backend", default="nccl", help="'nccl' (= RCCL over xGMI, the default) or 'gloo' (tests that "
@@ -464,7 +522,7 @@ def main():
         if args.variant:
             kname += f" variant {args.variant}"
         out = {
-            "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} samples",
+            "metric": f"pose-clips/sec (whole node) @ noise_steps={ns}, {S} seeds; AUC vs ref",
             "value": round(total / dt, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -505,6 +563,9 @@ def main():
             out["ref_value_1gpu"] = args.ref_value
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, ns, S, args.cpu_budget)
+        if world == 1 and not args.no_extras and not args.no_auc:
+            # `AUC vs ref` (BASELINE.json metric), untimed: see auc_vs_ref
+            out["auc"] = auc_vs_ref(sc, sd, cfg, ns, S, with_oracle=not args.no_cpu_baseline and S * (ns - 1) <= 64)
         if world == 1 and not use_dist and not args.no_extras:
             # informational only (never `value`): the same steps fed from pinned HOST windows, the H2D copy inside the timed loop
             n_x = min(args.steps, 10)

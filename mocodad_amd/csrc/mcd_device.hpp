@@ -137,7 +137,29 @@ constexpr int PROF_TRACE = 128;                          // time-stamp slots of 
 #endif
 // Everything the instrumentation needs lives in registers of the profiled workgroup (block 0): the timing adds are
 // fire-and-forget LDS atomics, no global memory access, no LDS round trip on the waves' paths.
+// Wave priority by PHASE (MCD_PHPRIO, a tuning experiment): the stages of a pass alternate between latency-bound ones (mixes,
+// resamplers, the tail: short dependent chains, a few instructions per wave) and throughput-bound ones (the channel GEMMs).  Two
+// workgroups share a CU; the issue arbiter picks by priority, then age.  `lat()` / `thr()` are called at the top of the
+// stages: a wave in a latency-bound stage outranks the other workgroup's GEMM waves (it needs few issue slots, but needs them
+// promptly), a GEMM wave takes what is left.  `slice` = the time-slice bit of the alternating scheme (see score_kernel).
+#ifndef MCD_PHPRIO
+#define MCD_PHPRIO 0
+#endif
+struct PhasePrio {
+    int slice;      // 0 / 1, wave-uniform
+    __device__ __forceinline__ void lat() const {
+        if constexpr (MCD_PHPRIO == 1 || MCD_PHPRIO == 3) __builtin_amdgcn_s_setprio(3);
+        else if constexpr (MCD_PHPRIO == 2) { if (slice) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+        else if constexpr (MCD_PHPRIO == 4) __builtin_amdgcn_s_setprio(0);
+    }
+    __device__ __forceinline__ void thr() const {
+        if constexpr (MCD_PHPRIO == 1 || MCD_PHPRIO == 2) { if (slice) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        else if constexpr (MCD_PHPRIO == 3) __builtin_amdgcn_s_setprio(0);
+        else if constexpr (MCD_PHPRIO == 4) __builtin_amdgcn_s_setprio(3);
+    }
+};
 struct Prof {
+    PhasePrio pp;
 #ifdef MCD_PROFILE
     unsigned* acc;               // LDS, PROF_SLOTS words
     unsigned long long tlast;
@@ -166,12 +188,12 @@ struct Prof {
             __hip_atomic_fetch_add(acc + PROF_STAGE + PROF_NW + bidx * PROF_NW + wv, (unsigned)(t1 - t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ++bidx;
     }
-    __device__ __forceinline__ void off() { on = false; won = false; acc = nullptr; tlast = 0; bidx = 0; wv = 0; tr = nullptr; tr_on = false; }
+    __device__ __forceinline__ void off() { pp.slice = 0; on = false; won = false; acc = nullptr; tlast = 0; bidx = 0; wv = 0; tr = nullptr; tr_on = false; }
 #else
     __device__ __forceinline__ void trace(int) {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void sync() { __syncthreads(); }
-    __device__ __forceinline__ void off() {}
+    __device__ __forceinline__ void off() { pp.slice = 0; }
 #endif
 };
 // workgroup barrier: every scope that synchronises has a `Prof prof` in reach
@@ -971,6 +993,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     float4 afr[KQ1 + KQ2];
     const int trs = 8 + 8 * ((prof_id - 32) / 3);      // trace slots of this layer (profile builds)
     prof.trace(trs + 0);
+    prof.pp.lat();
     const float* bias = wb + lw.bias;
     float4 bcur;
     if (pre_afr != nullptr) {
@@ -1006,6 +1029,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
     // 3 frames +1.1 %: profiles/r03k_prebar_ab.txt).
     pre_gemm();
     bsync();
+    prof.pp.thr();
     prof.trace(trs + 2);
     prof.mark(prof_id);
     const float slope = lw.slope;
@@ -1090,6 +1114,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 #endif
     prof.trace(trs + 5);
     bsync();
+    prof.pp.lat();
     prof.trace(trs + 6);
     prof.mark(prof_id + 1);
 }

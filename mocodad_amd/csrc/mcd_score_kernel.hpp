@@ -334,8 +334,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 unsigned hwid;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
                 const unsigned slice = (unsigned)(__builtin_amdgcn_s_memrealtime() >> sh);
-                if (((hwid >> 16) ^ slice) & 1u) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
+                prof.pp.slice = (int)(((hwid >> 16) ^ slice) & 1u);
+                if constexpr (MCD_PHPRIO == 0) {
+                    if (prof.pp.slice) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
             }
         }
         // ---- step prologue: this step's noise z (layer 0's mix coefficients were fetched at the end of the previous pass)
@@ -480,6 +483,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             lt_dump(5, RG + PL::L5_out, 132, 128, 10);
             lt_inject(6, RG + PL::L6_in, 132, 128, 10);
             float* Pb = RG + PL::L6_p;
+            prof.pp.thr();
             if constexpr (!EARLY2) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
             auto epi6 = [&](auto ti, int col, int c0, f32x4 acc, int col0, int) {
                 constexpr int STEP = Tiling<8, NT>::NG * 16 * 132;
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             }
             if constexpr (EARLY2) { rs_early(rc3, 2); mix_early(mc7, 7); }      // up3's fragments, layer 7's mix coefficients
             bsync();
+            prof.pp.lat();
             STAGE(10);
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);

@@ -447,7 +447,7 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
 // output is copied to lt_out from where the stage's own epilogue puts it.  Stages 3, 5, 7, 9 are the fused (joint resampler +
 // layer) stages of this kernel: their input is the resampler's input (+ lt_skip, the U-Net skip tensor added behind it).
 template <int TP, int NB, bool LT = false>
-__global__ __launch_bounds__(NTHREADS, 2) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
+__global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
     constexpr int TF = TP * NB;
     constexpr int R17 = TF * 17, R12 = TF * 12, R10 = TF * 10;
