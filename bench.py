@@ -489,13 +489,22 @@ def main():
     rank_info = None
     if use_dist:
         gms = gather_ev[0].elapsed_time(gather_ev[1])
-        mine = torch.tensor([dt_local, kern_ms, gms, float(B)], dtype=torch.float64, device=coll_dev)
-        allr = torch.empty(world * 4, dtype=torch.float64, device=coll_dev)
+        # per rank, so that a slow rank is attributable: first / fastest / slowest timed step and the shader clock right after
+        # the timed region (amdsmi through torch when it is importable; 0 = unknown)
+        try:
+            clk = float(torch.cuda.clock_rate(dev))
+        except Exception:
+            clk = 0.0
+        sm = step_ms if step_ms else [0.0]
+        mine = torch.tensor([dt_local, kern_ms, gms, float(B), sm[0], min(sm), max(sm), clk], dtype=torch.float64, device=coll_dev)
+        allr = torch.empty(world * 8, dtype=torch.float64, device=coll_dev)
         dist.all_gather_into_tensor(allr, mine)
-        allr = allr.view(world, 4).cpu().numpy()
+        allr = allr.view(world, 8).cpu().numpy()
         dt = float(allr[:, 0].max())          # the job's time = the slowest rank's
         rank_info = {"kernel_ms": [round(float(v), 4) for v in allr[:, 1]], "wall_s": [round(float(v), 5) for v in allr[:, 0]],
-                     "all_gather_ms": [round(float(v), 4) for v in allr[:, 2]], "windows_per_step": [int(v) for v in allr[:, 3]]}
+                     "all_gather_ms": [round(float(v), 4) for v in allr[:, 2]], "windows_per_step": [int(v) for v in allr[:, 3]],
+                     "first_step_ms": [round(float(v), 4) for v in allr[:, 4]], "min_step_ms": [round(float(v), 4) for v in allr[:, 5]],
+                     "max_step_ms": [round(float(v), 4) for v in allr[:, 6]], "clock_mhz": [int(v) for v in allr[:, 7]]}
     if streams:
         # launches on different streams overlap, so a launch's own start-to-end time counts its neighbour's work too;
         # the roofline then uses the timed region's average time per launch instead

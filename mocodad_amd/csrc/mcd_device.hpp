@@ -243,6 +243,14 @@ struct ScoreParams {
     int plan_only;            // host only: choose `split`, do not launch
     int phase;                // tuning experiment (MCD_OPT_PHASE): the second half of the grid starts `phase` x 1024 cycles late
     int prio_shift;           // host: log2 of the priority time slice in 100 MHz ticks (see the top of the step loop); 0 = off
+                              // (an ESTIMATE from the shapes; the kernel replaces it by a sixth of the measured duration of the
+                              // previous launch of the same grid when `tune` holds one)
+    int prio_rounds;          // host: rounds of workgroups of this launch (grid / resident slots, rounded up)
+    float* stash;             // per-handle device slab where the two-workgroups-per-CU kernels park U-Net skip tensors that do not
+                              // fit their 128 registers: [64 words: slot bitmap][slot][chunk][thread] float4 (see score_kernel); or null
+    int stash_slots;          // slots of the slab (>= the workgroups that can be resident on the device at once)
+    int* tune;                // per-handle device words: [0] signature (grid, S, ns) of the launch that wrote [1] = lifetime of its
+                              // workgroup 0 in 100 MHz ticks; or null
     float aggr_q;
     float* loss_agg;          // (B,) aggregated loss, or null
     int cond_idx[12];         // cond_inkernel: data frames the condition encoder reads
@@ -1243,7 +1251,7 @@ struct Plan {
     static constexpr int LOSS = NB * 64;        // per-sample losses of the workgroup's windows [NB][S <= 64] (in-kernel aggregation)
     static constexpr int EXW = EMB_EXTRA * 20;  // embedding rows beyond the first NTHREADS: [row][16 weights, bias, pad]
 #ifdef MCD_PROFILE
-    static constexpr int PROFTR = NB * T >= 10 ? PROF_TRACE * PROF_NW : 0;      // time stamps: the one-workgroup-per-CU shapes have the room
+    static constexpr int PROFTR = (NB * T >= 10 && NWAVES <= 8) ? PROF_TRACE * PROF_NW : 0;     // time stamps: the one-workgroup-per-CU shapes have the room
     static constexpr int PROF = PROF_SLOTS + PROFTR;
 #else
     static constexpr int PROF = 0;

@@ -40,6 +40,9 @@ struct mcd_weights {
     mcd::GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
     mcd::GenCond gcond;    // ... and of the 'E_unet' condition encoder
     int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
+    float* stash;     // slab where the two-workgroups-per-CU kernels of 3 / 6 frames park skip tensors (ScoreParams::stash), or null
+    int stash_slots;
+    int* tune;        // 4 device words: the trajectory kernel's own measurement of its previous launch (ScoreParams::tune)
     int opt[MCD_OPT_COUNT];   // mcd_set_option values (plain ints: set before the calls they affect, like any other argument)
 };
 
@@ -119,6 +122,7 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
         const double ticks = rounds * traj * (double)(P.ns > 2 ? P.ns - 1 : 1) * 7.5 * NB * T * 100.0;
         int sh = (int)floor(log2(ticks / 6.0) + 0.5);
         P.prio_shift = sh < 10 ? 10 : (sh > 26 ? 26 : sh);
+        P.prio_rounds = (int)rounds;
     }
     hipLaunchKernelGGL((score_kernel<T, NB, MINW, LT>), dim3(groups * P.split), dim3(NTHREADS), PL::BYTES, st, P);
     HIP_TRY(hipGetLastError());

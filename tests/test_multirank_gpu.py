@@ -82,6 +82,9 @@ def test_bench_self_launches_two_ranks(scaling, backend, ranks):
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
     assert len(d["ranks"]["kernel_ms"]) == ranks and len(d["ranks"]["all_gather_ms"]) == ranks
+    for key in ("first_step_ms", "min_step_ms", "max_step_ms", "clock_mhz"):      # what makes a slow rank attributable
+        assert len(d["ranks"][key]) == ranks
+    assert all(lo <= hi for lo, hi in zip(d["ranks"]["min_step_ms"], d["ranks"]["max_step_ms"]))
     total = 256 * ranks if scaling == "weak" else 256
     assert d["config"]["windows_per_step_total"] == total
     assert sum(d["ranks"]["windows_per_step"]) == total
@@ -107,3 +110,23 @@ def test_missing_checkpoint_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "eval_MoCoDAD.py"), "-c", cfg, "--synthetic", "1"],
                        capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
     assert r.returncode != 0 and "--random-init" in (r.stdout + r.stderr)
+
+
+def test_scale_check_script_output_format():
+    """tools/scale_check.sh on the GPUs that exist (one here): a header and one line per (scaling mode, N) in the format the
+    8-GPU run will be read in -- the script must not rot before such a box appears."""
+    import re
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_check.sh"), "5"], capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    n = _n_gpus()
+    per_mode = sum(1 for k in (1, 2, 4, 8) if k <= n)
+    assert lines[0] == f"# {n} GPU(s) visible" and len(lines) == 1 + 2 * per_mode, r.stdout
+    pat = re.compile(r"^(weak|strong) N=(\d+): (\d+) clips/s  eff ([0-9.]+)  rccl_ranks (\d+)  kernel ms/rank (None|\[[0-9., ]+\])  all_gather ms (None|\[[0-9., ]+\])$")
+    seen = []
+    for l in lines[1:]:
+        m = pat.match(l)
+        assert m, l
+        seen.append((m.group(1), int(m.group(2))))
+        assert int(m.group(3)) > 0 and (int(m.group(2)) > 1 or float(m.group(4)) == 1.0)
+    assert seen == [(mode, k) for mode in ("weak", "strong") for k in (1, 2, 4, 8) if k <= n]
