@@ -1248,26 +1248,9 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     e = hipMemcpy(w->dbuf, B.buf.data(), B.buf.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(w->dbuf); delete w; return fail(MCD_EDEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
-    w->stash = nullptr; w->stash_slots = 0;
-    if (T == 6 || T == 3) {
-        // skip-tensor slab of score_kernel<6,1,4> (and of tuning builds of <3,2,4>): 16 XCD ids x wpx bitmap words x 64 slots, a
-        // slot = 24 floats per thread of a workgroup (48 KB); wpx from the workgroups one XCD can hold (2 per CU, 8 XCDs)
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        const int wpx = (2 * ((cus + 7) / 8) + 63) / 64;
-        if (wpx > 2) { delete w; return fail(MCD_EUNSUPPORTED, "skip-tensor slab: more than 128 resident workgroups per XCD"); }
-        w->stash_slots = 16 * wpx * 64;
-        const size_t bytes = 256 + (size_t)w->stash_slots * 24 * NTHREADS * sizeof(float);
-        if (hipMalloc(reinterpret_cast<void**>(&w->stash), bytes) != hipSuccess || hipMemset(w->stash, 0, 256) != hipSuccess) {
-            if (w->stash) (void)hipFree(w->stash);
-            delete w;
-            return fail(MCD_EDEVICE, "hipMalloc (skip-tensor slab)");
-        }
-    }
     w->tune = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&w->tune), 4 * sizeof(int)) != hipSuccess || hipMemset(w->tune, 0, 4 * sizeof(int)) != hipSuccess) {
         if (w->tune) (void)hipFree(w->tune);
-        if (w->stash) (void)hipFree(w->stash);
         (void)hipFree(w->dbuf); delete w;
         return fail(MCD_EDEVICE, "hipMalloc (tuning words)");
     }
@@ -1288,7 +1271,6 @@ void mcd_free_weights(mcd_weights_t* w) {
     if (!w) return;
     if (w->dbuf) (void)hipFree(w->dbuf);
     if (w->tune) (void)hipFree(w->tune);
-    if (w->stash) (void)hipFree(w->stash);
     delete w;
 }
 
@@ -1496,7 +1478,6 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
     ScoreParams P;
     memset(&P, 0, sizeof(P));
     P.wbuf = w->dbuf; P.prof = g_prof; P.dv.data = data;
-    P.stash = w->stash; P.stash_slots = w->stash_slots;
     P.tune = w->opt[MCD_OPT_PHASE] == -2 ? nullptr : w->tune;      // (phase -2: the host's estimate only -- A/B of the self-calibration)
     if (view) {
         if (view->trans && !view->affine) return fail(MCD_EINVAL, "window view: trans given without an affine table");

@@ -246,9 +246,6 @@ struct ScoreParams {
                               // (an ESTIMATE from the shapes; the kernel replaces it by a sixth of the measured duration of the
                               // previous launch of the same grid when `tune` holds one)
     int prio_rounds;          // host: rounds of workgroups of this launch (grid / resident slots, rounded up)
-    float* stash;             // per-handle device slab where the two-workgroups-per-CU kernels park U-Net skip tensors that do not
-                              // fit their 128 registers: [64 words: slot bitmap][slot][chunk][thread] float4 (see score_kernel); or null
-    int stash_slots;          // slots of the slab (>= the workgroups that can be resident on the device at once)
     int* tune;                // per-handle device words: [0] signature (grid, S, ns) of the launch that wrote [1] = lifetime of its
                               // workgroup 0 in 100 MHz ticks; or null
     float aggr_q;

@@ -40,8 +40,6 @@ struct mcd_weights {
     mcd::GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
     mcd::GenCond gcond;    // ... and of the 'E_unet' condition encoder
     int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
-    float* stash;     // slab where the two-workgroups-per-CU kernels of 3 / 6 frames park skip tensors (ScoreParams::stash), or null
-    int stash_slots;
     int* tune;        // 4 device words: the trajectory kernel's own measurement of its previous launch (ScoreParams::tune)
     int opt[MCD_OPT_COUNT];   // mcd_set_option values (plain ints: set before the calls they affect, like any other argument)
 };

@@ -260,72 +260,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #endif
     constexpr bool STASH2 = !LT && MINW >= 4 && ((T == 6 && (MCD_STASH & 1)) || (T == 3 && (MCD_STASH & 4)));
     constexpr bool STASH1 = !LT && MINW >= 4 && ((T == 6 && (MCD_STASH & 2)) || (T == 3 && (MCD_STASH & 8)));
-    // Parked where?  Private memory is laid out per wave SLOT of the device (3 - 6 MB per XCD, more than its 4 MB L2): the 24 KB a
-    // workgroup parks 45 times per launch kept leaving L2 -- 1.4 GB of write-back per 1024-window launch (profiles/
-    // r03z_ubnormal_concat_pmc.txt).  GSTASH (default): a slab of the weights handle instead, one 24 / 48 KB slot per RESIDENT
-    // workgroup (a slot is taken from a bitmap when the workgroup starts and given back when it ends: at most 2 x CUs are
-    // live, 1.5 MB per XCD, rewritten in place in L2): [slot][chunk][thread] float4, coalesced.
-#ifndef MCD_GSTASH
-#define MCD_GSTASH 1
-#endif
-    constexpr bool GSTASH = (STASH1 || STASH2) && MCD_GSTASH != 0;
-    constexpr int ST_CH2 = (RS2::PER * RS2::SK + 3) / 4, ST_CH1 = (RS1::PER * RS1::SK + 3) / 4;      // float4 chunks per thread
-    float stash1_mem[STASH1 && !GSTASH ? RS1::PER * RS1::SK : 1];
-    float stash2_mem[STASH2 && !GSTASH ? RS2::PER * RS2::SK : 1];
+    float stash1_mem[STASH1 ? RS1::PER * RS1::SK : 1];
+    float stash2_mem[STASH2 ? RS2::PER * RS2::SK : 1];
     typedef float __attribute__((address_space(5))) priv_float;         // (explicit private address space: scratch_*, not flat_*)
-    typedef f32x4 __attribute__((address_space(1))) gf32x4w;
-    // this thread's first float4 of chunk `ch0` in the workgroup's slot (slot id in LDS, slab pointer re-read from the kernarg
-    // segment: neither is kept in registers across the stages in between)
-    auto stash_at = [&](int ch0) -> gf32x4w* {
-        typedef const ScoreParams __attribute__((address_space(4))) KSP;
-        KSP* Qs = (KSP*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(Qs));
-        float* base = Qs->stash + 64 + (size_t)UPD[13] * ((ST_CH1 + ST_CH2) * NTHREADS * 4);
-        return (gf32x4w*)(base + ((size_t)ch0 * NTHREADS + threadIdx.x) * 4);
-    };
-    if constexpr (GSTASH) {
-        // take a slot of this XCD's share of the slab (HW_REG_XCC_ID: a slot only ever holds data of workgroups of ONE XCD, so the
-        // XCD's own L2 is the only cache that sees it -- the eight L2s are not coherent with each other)
-        if (threadIdx.x == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc &= 15u;
-            const int wpx = P.stash_slots >> 10;          // bitmap words per XCD (16 XCD ids x wpx words x 64 slots)
-            unsigned long long* bm = reinterpret_cast<unsigned long long*>(P.stash) + xcc * wpx;
-            int slot = -1;
-            while (slot < 0) {
-                for (int wi = 0; wi < wpx && slot < 0; ++wi) {
-                    unsigned long long fr = ~__hip_atomic_load(bm + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while (fr && slot < 0) {
-                        const int b = __ffsll((long long)fr) - 1;
-                        const unsigned long long old = __hip_atomic_fetch_or(bm + wi, 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!((old >> b) & 1ull)) slot = (int)((xcc * wpx + wi) * 64 + b);
-                        else fr &= ~(1ull << b);
-                    }
-                }
-                if (slot < 0) __builtin_amdgcn_s_sleep(64);      // (cannot last: the slab has a slot for every resident workgroup)
-            }
-            UPD[13] = slot;
-        }
-    }
-    auto stash_put = [&](auto nc, int ch0, const float* regs, int n) {
-        constexpr int NC = decltype(nc)::value;
-        gf32x4w* p = stash_at(ch0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            p[c * NTHREADS] = f32x4{regs[4 * c], 4 * c + 1 < n ? regs[4 * c + 1] : 0.f, 4 * c + 2 < n ? regs[4 * c + 2] : 0.f, 4 * c + 3 < n ? regs[4 * c + 3] : 0.f};
-    };
-    auto stash_get = [&](auto nc, int ch0, float* regs, int n) {
-        constexpr int NC = decltype(nc)::value;
-        gf32x4w* p = stash_at(ch0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const f32x4 v = p[c * NTHREADS];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * c + e < n) regs[4 * c + e] = v[e];
-        }
-    };
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
@@ -510,9 +447,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
         if constexpr (!EARLY2) mix_early(mc3, 3);
         resample_stage<32, 17, 12, T, NB, true, false, (MINW <= 2)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
-        if constexpr (STASH1 && GSTASH) {
-            stash_put(std::integral_constant<int, ST_CH1>{}, ST_CH2, skip1, RS1::PER * RS1::SK);
-        } else if constexpr (STASH1) {
+        if constexpr (STASH1) {
             priv_float* sp = (priv_float*)stash1_mem;
             asm volatile("" : "+v"(sp));
 #pragma unroll
@@ -538,9 +473,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_inject(12, RG + PL::L4_out, 68, 64, 12);
         if constexpr (!EARLY2) mix_early(mc5, 5);
         resample_stage<64, 12, 10, T, NB, true, false, (MINW <= 2)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
-        if constexpr (STASH2 && GSTASH) {
-            stash_put(std::integral_constant<int, ST_CH2>{}, 0, skip2, RS2::PER * RS2::SK);
-        } else if constexpr (STASH2) {
+        if constexpr (STASH2) {
             priv_float* sp = (priv_float*)stash2_mem;
             asm volatile("" : "+v"(sp));            // opaque: the array stays in memory, plain (cached) scratch accesses
 #pragma unroll
@@ -607,9 +540,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                          if (w0 + 2 < 10) { pp[264] = r1[0]; pp[396] = r1[1]; }
                                      });
         }
-        if constexpr (STASH2 && GSTASH) {
-            stash_get(std::integral_constant<int, ST_CH2>{}, 0, skip2, RS2::PER * RS2::SK);
-        } else if constexpr (STASH2) {
+        if constexpr (STASH2) {
             const priv_float* sp = (const priv_float*)stash2_mem;
             asm volatile("" : "+v"(sp));
 #pragma unroll
@@ -644,9 +575,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                             [&] { rs_early(rc4, 3); },
                             [&] {
                                 if constexpr (EARLY2) mix_early(mc9, 9);
-                                if constexpr (STASH1 && GSTASH) {
-                                    stash_get(std::integral_constant<int, ST_CH1>{}, ST_CH2, skip1, RS1::PER * RS1::SK);
-                                } else if constexpr (STASH1) {
+                                if constexpr (STASH1) {
                                     const priv_float* sp = (const priv_float*)stash1_mem;
                                     asm volatile("" : "+v"(sp));
 #pragma unroll
@@ -860,13 +789,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     // ---- aggregation over the samples (mocodad.py:454-520; loss-based strategies), when this workgroup has seen them all
     int te = tid0;
     asm volatile("" : "+v"(te));       // (opaque: win0 + tid from the prologue would otherwise be kept -- spilled -- until here)
-    if constexpr (GSTASH) {
-        if (te == 0) {      // give the slot back (every read of it lies in front of the last barrier)
-            const int slot = UPD[13];
-            __hip_atomic_fetch_and(reinterpret_cast<unsigned long long*>(P.stash) + (slot >> 6), ~(1ull << (slot & 63)), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if constexpr (MINW >= 4) {
         if (P.mode == 0 && P.tune && blockIdx.x == 0 && te == 0) {      // this launch's measurement for the next one's time slice
             P.tune[1] = (int)((unsigned)__builtin_amdgcn_s_memrealtime() - (unsigned)UPD[14]);
