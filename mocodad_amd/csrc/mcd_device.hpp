@@ -1016,7 +1016,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                              [&](int n, int q, int w0, int c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
                                  // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store)
-                                 float* zp = z + __mul24((n * T + q) * V + w0, CSI) + c;
+                                 float* zp = z + __mul24(n * (T * V) + w0, CSI) + c + q * (V * CSI);      // (q = the unit's first frame + a constant: one address per unit, the frames at constant offsets)
                                  if constexpr (std::is_same_v<decltype(v), f32x4>) {
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)
