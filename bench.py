@@ -56,9 +56,9 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/profile_set.sh): per-launch counter averages
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
-PMC_PROFILES = {"avenue": ("profiles/r03z_avenue_pmc.txt", 1024, 10, 5), "stc": ("profiles/r03z_avenue_pmc.txt", 1024, 10, 5),      # (stc: the same kernel, 2048 windows -- scaled)
-                "ubnormal_concat": ("profiles/r03z_ubnormal_concat_pmc.txt", 1024, 10, 5),
-                "seq24": ("profiles/r03z_seq24_pmc.txt", 1024, 50, 8), "concat32": ("profiles/r03z_concat32_pmc.txt", 1024, 10, 5)}
+PMC_PROFILES = {"avenue": ("profiles/r04z_avenue_pmc.txt", 1024, 10, 5), "stc": ("profiles/r04z_avenue_pmc.txt", 1024, 10, 5),      # (stc: the same kernel, 2048 windows -- scaled)
+                "ubnormal_concat": ("profiles/r04z_ubnormal_concat_pmc.txt", 1024, 10, 5),
+                "seq24": ("profiles/r04z_seq24_pmc.txt", 1024, 50, 8), "concat32": ("profiles/r04z_concat32_pmc.txt", 1024, 10, 5)}
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
 
 
@@ -74,7 +74,7 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
             if line.startswith("#") or not line.strip():
                 continue
             if not line.startswith(" "):
-                cur = kernels.setdefault(line.strip(), {})
+                cur = kernels.setdefault(line.strip().replace("mcd::", ""), {})
             else:
                 f = line.split()
                 cur[f[0]] = float(f[1])

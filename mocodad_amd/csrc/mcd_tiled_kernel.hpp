@@ -441,6 +441,13 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
 #else
 #define TLMARK(id) do { } while (0)
 #endif
+// the kernel's argument list as the kernarg segment lays it out (arguments in order at their natural alignment = C struct
+// layout): the per-layer table offsets of TiledNet are read through a pointer into the segment that is made opaque per step and
+// per layer -- read as plain kernel arguments they are loop-invariant, the compiler hoists all ~80 of them above the step loop,
+// and they came back as 441 v_writelane + 985 v_readlane of SGPR spills (round 3: 427 spilled SGPRs at 32 frames)
+struct TiledKernArgs { ScoreParams P; FrameMaps M; TiledNet N; int T; float* slabs; };
+typedef const TiledNet __attribute__((address_space(4))) KTiledNet;
+
 // P.mode 1 (mcd_unet_forward): ONE pass at step P.step_single from the caller's x_in, eps-prediction to eps_out, no update.
 // LT = true (layer test, mcd_layer_forward): a single pass in which only stage P.lt_stage runs -- its input tensor lt_in is put
 // where the PREVIOUS layer's epilogue would have left it (the slab and / or the LDS hand-over regions, see `layer` below), its
@@ -519,6 +526,8 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
             asm volatile("" : "+s"(wb));
             float* sl = slab;
             asm volatile("" : "+s"(sl));
+            KTiledNet* Ns = (KTiledNet*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TiledKernArgs, N));
+            asm volatile("" : "+s"(Ns));
             float* const A0 = sl;
             float* const A1 = A0 + (R10 + 16) * 132;
             float* const D1 = A1 + (R10 + 16) * 132;
@@ -554,8 +563,8 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
             __syncthreads();
             for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
                 const int i = u / EMB_TOTAL, o = u % EMB_TOTAL;
-                const float* we = wb + N.we + o * EDIM;
-                float a = wb[N.be + o];
+                const float* we = wb + Ns->we + o * EDIM;
+                float a = wb[Ns->be + o];
 #pragma unroll
                 for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[i * EDIM + k], a);
                 EMB[i * EMBS + o] = a;
@@ -604,6 +613,8 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                KTiledNet* Nl = Ns;
+                asm volatile("" : "+s"(Nl));
                 if constexpr (LT) {
                     if (P.lt_stage != L) return;
                     // the stage's input, placed as the previous layer's epilogue (epi_fg of layer L - 1) places its output
@@ -646,29 +657,29 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                     static_assert(!HIC || (NH == 1 && NFC == 2), "");
                     if constexpr (HIC) si.issue(tid, xin + (size_t)IR * CSI, CSI, 0);      // (chunk 0 is in the z region already)
                     else si.issue(tid, xin, CSI, HIR ? CINV : 0);   // (HIR: part 0 is in the z region already, all chunks of it)
-                    rc.load(wb + N.rsw[RSI], wb + N.rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                    rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     if (skip) sx.issue(tid, skip, CSI, 0);
                 } else if (!xin_lds && !HI17) {
                     static_assert(!HI || (RSI < 0 && NH >= 2), "");
                     sx.issue(tid, xin, CSI, HI ? CINV : 0);
                 }
                 float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
-                tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 0);
+                tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, 0);
                 // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
                 constexpr bool AQ = NH > 2;
                 constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
                 const int mt = wave % MT, ng = MT > NWAVES ? 0 : wave / MT, c0 = mt * 16 + 4 * (lane >> 4);
                 LayerAfr<AQ ? 1 : KQA> A;
                 float4 aq[AQ ? 2 * KH : 1];
-                const float* wfr = wb + N.wp[L] + ((size_t)mt * KQA * 64 + lane) * 4;
+                const float* wfr = wb + Nl->wp[L] + ((size_t)mt * KQA * 64 + lane) * 4;
                 if constexpr (!AQ) {
                     LayerW lw;
-                    lw.wp = N.wp[L]; lw.bias = N.bias[L];
+                    lw.wp = Nl->wp[L]; lw.bias = Nl->bias[L];
                     A.template load<MT>(wb, lw, wave, lane);
                 } else {
-                    A.bcur = load_global4(wb + N.bias[L] + c0);
+                    A.bcur = load_global4(wb + Nl->bias[L] + c0);
                 }
-                const float slope = N.slope[L], pinf = prelu_bound(slope);
+                const float slope = Nl->slope[L], pinf = prelu_bound(slope);
                 f32x4 acc[TI::MAXN];
                 static_for<NH>([&](auto hh) {
                     constexpr int h = decltype(hh)::value;
@@ -773,22 +784,22 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                     if constexpr (HO17 || L == 2) {
                         static_assert(!(HO17 || L == 2) || (FS == 2 && NH == 1 && COUT <= 32), "");
                         f32x4 acc0[TI::MAXN];
-                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 0);
-                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 0, tqa);
-                        tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, 1);
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + Nl->am[L], wave, lane, 0);
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + Nl->tqm[L], wave, lane, 0, tqa);
+                        tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, 1);
                         __syncthreads();
-                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 0, aja);
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + Nl->am[L], wave, lane, 0, aja);
                         TLMARK(4 * L + 1);
                         __syncthreads();
                         TLMARK(4 * L + 2);
                         gemm_fg(0, acc0);
-                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, 1);
+                        tl_joint_fetch<V, TP, NB, FS>(aja, wb + Nl->am[L], wave, lane, 1);
                         TLMARK(4 * L + 3);
                         __syncthreads();                  // (z is free)
-                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, 1, tqa);
+                        tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + Nl->tqm[L], wave, lane, 1, tqa);
                         __syncthreads();                  // (nobody reads the X rows of group 0 any more)
                         if constexpr (HO17) epi_fg(0, acc0);
-                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, 1, aja);
+                        tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + Nl->am[L], wave, lane, 1, aja);
                         TLMARK(4 * L + 1);
                         __syncthreads();
                         TLMARK(4 * L + 2);
@@ -800,11 +811,11 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                     } else {
 #pragma unroll
                         for (int fg = 0; fg < FS; ++fg) {
-                            tl_joint_fetch<V, TP, NB, FS>(aja, wb + N.am[L], wave, lane, fg);
-                            tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + N.tqm[L], wave, lane, fg, tqa);
-                            if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + N.tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
+                            tl_joint_fetch<V, TP, NB, FS>(aja, wb + Nl->am[L], wave, lane, fg);
+                            tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + Nl->tqm[L], wave, lane, fg, tqa);
+                            if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
                             __syncthreads();
-                            tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + N.am[L], wave, lane, fg, aja);
+                            tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + Nl->am[L], wave, lane, fg, aja);
                             TLMARK(4 * L + 1);
                             __syncthreads();
                             TLMARK(4 * L + 2);
@@ -856,8 +867,8 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                     __syncthreads();
                 }
                 MixLongCoef<16, 17, TP, NB> mc10;      // (the mix's first coefficients: in flight behind the product)
-                mc10.load(wb + N.tq[10], wb + N.am[10], wave, lane);
-                const float* w4 = wb + N.wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
+                mc10.load(wb + Ns->tq[10], wb + Ns->am[10], wave, lane);
+                const float* w4 = wb + Ns->wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
                 for (int col = tid; col < R17; col += NTHREADS) {
                     const float* xp = RA + col * 36;          // layer 9's output, handed over in LDS
                     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -874,7 +885,7 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                 }
                 __syncthreads();
                 // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
-                mix_long<16, 17, TP, NB>(P4, 4, mc10, wb + N.tq[10], wb + N.am[10], wave, lane, ZeroInitL{},
+                mix_long<16, 17, TP, NB>(P4, 4, mc10, wb + Ns->tq[10], wb + Ns->am[10], wave, lane, ZeroInitL{},
                                      [&](int q, int w0, int c, auto v) {
                                          if (c < C0) {
                                              float* zp = ZO + ((q * 17 + w0)) * C0 + c;
@@ -889,7 +900,7 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                                      });
                 __syncthreads();
                 // eps = layer 10 + x; DDPM update of the frame each prediction drives (mocodad.py:172-178,829-838)
-                const float slope10 = N.slope[10], ca = srow[0], cb = srow[1], csg = srow[2];
+                const float slope10 = Ns->slope[10], ca = srow[0], cb = srow[1], csg = srow[2];
                 const bool zadd = sidx > 1;
                 constexpr int NIT = (C0 * TF * 17 + NTHREADS - 1) / NTHREADS;
                 float xn[NIT];
@@ -900,7 +911,7 @@ __global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const
                     dst[it] = -1; xn[it] = 0.f;
                     if (u < TF * 17 * C0) {
                         const int c = u % C0, col = u / C0, f = col / 17, i = f / TP, t = f % TP, v = col % 17;
-                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[N.bias[10] + c], slope10) + EMB[i * EMBS + emb_off(10) + c];
+                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[Ns->bias[10] + c], slope10) + EMB[i * EMBS + emb_off(10) + c];
                         const float eps = l10 + XT[col * 4 + c];
                         if constexpr (LT) {      // layer 10 alone: without the U-Net's residual (+ x)
                             if (t < T && grp * NB + i < P.n_chains) P.lt_out[(((size_t)b_of(i) * C0 + c) * T + t) * 17 + v] = l10;
