@@ -53,13 +53,15 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
     tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
     obj_dir = obj_dir or os.path.join(CSRC, "_obj", tag)
     os.makedirs(obj_dir, exist_ok=True)
-    newest_src = max(os.path.getmtime(p) for p in sources())
+    # an object depends on its own .hip, every header of csrc and the public header (not on the other .hip)
+    hdr_m = max(os.path.getmtime(p) for p in sources() if not p.endswith(".hip"))
+    newest = lambda src: max(hdr_m, os.path.getmtime(src))
     fast = any(d.split("=")[0] == "MCD_FAST_T" for d in defines)
     units = [1] if fast else list(range(1, n_units() + 1))
     jobs_l = [("mcd_api.o", os.path.join(CSRC, "mcd_api.hip"), [])]
     jobs_l += [(f"mcd_inst_{u}.o", os.path.join(CSRC, "mcd_inst.hip"), [f"-DMCD_INST_UNIT={u}"]) for u in units]
     todo = [(o, s, f) for o, s, f in jobs_l
-            if force or not os.path.exists(os.path.join(obj_dir, o)) or os.path.getmtime(os.path.join(obj_dir, o)) < newest_src]
+            if force or not os.path.exists(os.path.join(obj_dir, o)) or os.path.getmtime(os.path.join(obj_dir, o)) < newest(s)]
     t0 = time.perf_counter()
     if todo:
         workers = jobs or min(len(todo), os.cpu_count() or 4)

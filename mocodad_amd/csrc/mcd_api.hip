@@ -179,68 +179,77 @@ struct AggrParams {
 };
 
 
-__device__ __forceinline__ void sort_small(float* a, int n) {
-    for (int i = 1; i < n; ++i) {
-        const float x = a[i];
-        int k = i - 1;
-        while (k >= 0 && a[k] > x) { a[k + 1] = a[k]; --k; }
-        a[k + 1] = x;
+// One 64-lane wave per window, lane k = sample k (S <= 64): sums and best / worst run in sample order on wave-uniform values
+// (bit-identical to the sequential loops of aggregate_losses in the fused kernel), order statistics by rank counting -- no
+// per-thread array (the first version sorted a float[64] per thread in private memory: 272 B of scratch per lane).
+__device__ __forceinline__ float wave_get(float v, int k) { return __shfl(v, k, 64); }
+// rank of this lane's value among the first S lanes (ties broken by lane index): a permutation of 0 .. S-1
+__device__ __forceinline__ int wave_rank(float x, int lane, int S) {
+    int r = 0;
+    for (int k = 0; k < S; ++k) {
+        const float y = wave_get(x, k);
+        r += (y < x || (y == x && k < lane)) ? 1 : 0;
     }
+    return r;
+}
+// the value of the lane whose rank is r (lanes >= S never match)
+__device__ __forceinline__ float wave_select(float x, int rank, int lane, int S, int r) {
+    const unsigned long long m = __ballot(lane < S && rank == r);
+    return wave_get(x, m ? __ffsll((long long)m) - 1 : 0);
+}
+__device__ __forceinline__ float wave_order_stat(float x, int lane, int S, int strategy, float q) {
+    const int rank = wave_rank(x, lane, S);
+    if (strategy == MCD_AGGR_MEDIAN) return wave_select(x, rank, lane, S, (S - 1) / 2);      // torch.median: the lower middle value
+    const float pos = fminf(fmaxf(q, 0.f), 1.f) * (float)(S - 1);
+    const int lo = (int)floorf(pos);
+    const int hi = lo + 1 < S ? lo + 1 : S - 1;
+    const float wgt = pos - (float)lo;
+    const float a = wave_select(x, rank, lane, S, lo), c = wave_select(x, rank, lane, S, hi);
+    return wgt < 0.5f ? a + wgt * (c - a) : c - (c - a) * (1.f - wgt);                          // torch.lerp
 }
 
-__global__ void aggregate_kernel(const AggrParams P) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= P.B) return;
-    const int S = P.S, per = P.C * P.Tx * P.V;
-    const float* L = P.loss_all + (size_t)b * S;
-    float tmp[64];
-    if (P.strategy == MCD_AGGR_BEST || P.strategy == MCD_AGGR_WORST) {
-        const bool best = P.strategy == MCD_AGGR_BEST;
-        float cur = best ? 1e10f : -1.f;
-        int sel = -1;
-        for (int s = 0; s < S; ++s) {
-            const bool m = best ? (L[s] < cur) : (L[s] > cur);
-            if (m) { cur = L[s]; sel = s; }
-        }
-        P.loss_agg[b] = cur;
-        if (P.pose_agg) for (int e = 0; e < per; ++e)
-            P.pose_agg[(size_t)b * per + e] = sel >= 0 ? P.pose_all[((size_t)b * S + sel) * per + e] : 0.f;
-    } else if (P.strategy == MCD_AGGR_MEAN) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += L[k];
-        P.loss_agg[b] = s / (float)S;
-    } else if (P.strategy == MCD_AGGR_MEDIAN || P.strategy == MCD_AGGR_QUANTILE) {
-        for (int k = 0; k < S; ++k) tmp[k] = L[k];
-        sort_small(tmp, S);
-        if (P.strategy == MCD_AGGR_MEDIAN) {
-            P.loss_agg[b] = tmp[(S - 1) / 2];  // torch.median: lower of the two middle values
-        } else {
-            const float pos = fminf(fmaxf(P.q, 0.f), 1.f) * (float)(S - 1);
-            const int lo = (int)floorf(pos);
-            const int hi = lo + 1 < S ? lo + 1 : S - 1;
-            const float wgt = pos - (float)lo;
-            const float a = tmp[lo], c = tmp[hi];
-            P.loss_agg[b] = wgt < 0.5f ? a + wgt * (c - a) : c - (c - a) * (1.f - wgt);  // torch.lerp
-        }
-    } else {  // mean_pose / median_pose
-        float acc = 0.f;
-        for (int e = 0; e < per; ++e) {
-            float val;
-            if (P.strategy == MCD_AGGR_MEAN_POSE) {
-                float s = 0.f;
-                for (int k = 0; k < S; ++k) s += P.pose_all[((size_t)b * S + k) * per + e];
-                val = s / (float)S;
-            } else {
-                for (int k = 0; k < S; ++k) tmp[k] = P.pose_all[((size_t)b * S + k) * per + e];
-                sort_small(tmp, S);
-                val = tmp[(S - 1) / 2];
+__global__ __launch_bounds__(64) void aggregate_kernel(const AggrParams P) {
+    const int lane = threadIdx.x, S = P.S, per = P.C * P.Tx * P.V;
+    for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
+        const float x = lane < S ? P.loss_all[(size_t)b * S + lane] : 0.f;
+        if (P.strategy == MCD_AGGR_BEST || P.strategy == MCD_AGGR_WORST) {
+            const bool best = P.strategy == MCD_AGGR_BEST;
+            float cur = best ? 1e10f : -1.f;       // mocodad.py:504-512: strict comparisons from 1e10 / -1
+            int sel = -1;
+            for (int k = 0; k < S; ++k) {
+                const float y = wave_get(x, k);
+                if (best ? (y < cur) : (y > cur)) { cur = y; sel = k; }
             }
-            if (P.pose_agg) P.pose_agg[(size_t)b * per + e] = val;
-            const int c = e / (P.Tx * P.V), tx = (e / P.V) % P.Tx, v = e % P.V;
-            const float gt = P.data[(((size_t)b * P.C + c) * P.seg_len + P.corrupt_idx[tx]) * P.V + v];
-            acc += loss_elem(val, gt, P.loss_fn);
+            if (lane == 0) P.loss_agg[b] = cur;
+            if (P.pose_agg)
+                for (int e = lane; e < per; e += 64)
+                    P.pose_agg[(size_t)b * per + e] = sel >= 0 ? P.pose_all[((size_t)b * S + sel) * per + e] : 0.f;
+        } else if (P.strategy == MCD_AGGR_MEAN) {
+            float sum = 0.f;
+            for (int k = 0; k < S; ++k) sum += wave_get(x, k);
+            if (lane == 0) P.loss_agg[b] = sum / (float)S;
+        } else if (P.strategy == MCD_AGGR_MEDIAN || P.strategy == MCD_AGGR_QUANTILE) {
+            const float r = wave_order_stat(x, lane, S, P.strategy, P.q);
+            if (lane == 0) P.loss_agg[b] = r;
+        } else {  // mean_pose / median_pose: per element over the S generated poses, then the loss of that pose (mocodad.py:493-503)
+            float acc = 0.f;      // (every lane carries the same running sum: the per-element values are wave-uniform)
+            for (int e = 0; e < per; ++e) {
+                const float pv = lane < S ? P.pose_all[((size_t)b * S + lane) * per + e] : 0.f;
+                float val;
+                if (P.strategy == MCD_AGGR_MEAN_POSE) {
+                    float sum = 0.f;
+                    for (int k = 0; k < S; ++k) sum += wave_get(pv, k);
+                    val = sum / (float)S;
+                } else {
+                    val = wave_order_stat(pv, lane, S, MCD_AGGR_MEDIAN, 0.f);
+                }
+                if (P.pose_agg && lane == 0) P.pose_agg[(size_t)b * per + e] = val;
+                const int c = e / (P.Tx * P.V), tx = (e / P.V) % P.Tx, v = e % P.V;
+                const float gt = P.data[(((size_t)b * P.C + c) * P.seg_len + P.corrupt_idx[tx]) * P.V + v];
+                acc += loss_elem(val, gt, P.loss_fn);
+            }
+            if (lane == 0) P.loss_agg[b] = acc / (float)per;
         }
-        P.loss_agg[b] = acc / (float)per;
     }
 }
 
@@ -1438,7 +1447,7 @@ __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out,
 }
 
 static int launch_aggregate(const AggrParams& A, hipStream_t st) {
-    hipLaunchKernelGGL(aggregate_kernel, dim3((A.B + 63) / 64), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(aggregate_kernel, dim3(A.B < 65536 ? A.B : 65536), dim3(64), 0, st, A);      // one wave per window
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
