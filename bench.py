@@ -127,6 +127,8 @@ CONFIGS = {
     # shapes the reference accepts (mocodad.py:780-796) beyond BASELINE's configurations -- seeded random-init weights built here
     # (no reference-generated fixture holds these frame counts): ("rand:<strategy>:<seg_len>:<conditioning_indices>", ...)
     "seg10": ("rand:inject:10:2", 1024, 10, 5, "seg_len 10 = 5 cond + 5 denoised frames (inject), Avenue-shaped windows"),
+    "seg16": ("rand:inject:16:2", 1024, 10, 5, "seg_len 16 = 8 cond + 8 denoised frames (inject; U-Net on 8 frames)"),
+    "seg18": ("rand:inject:18:2", 1024, 10, 5, "seg_len 18 = 9 cond + 9 denoised frames (inject; U-Net on 9 frames)"),
     "seg20": ("rand:inject:20:2", 1024, 10, 5, "seg_len 20 = 10 cond + 10 denoised frames (inject), Avenue-shaped windows"),
     "seg4": ("rand:inject:4:2", 1024, 10, 5, "seg_len 4 = 2 cond + 2 denoised frames (inject; U-Net on 2 frames)"),
     "seg14": ("rand:inject:14:2", 1024, 10, 5, "seg_len 14 = 7 cond + 7 denoised frames (inject; U-Net on 7 frames)"),

@@ -733,8 +733,9 @@ bool pack_mix_mfma(TensorMap& tm, const std::string& p, int T, int V, Builder& B
     if (TP < T) TP = T;
     const int KS = (V + 3) / 4, MT = (V + 15) / 16;
     const int NR = (KS * TP + 15) / 16;
-    tqf = B.alloc((size_t)TP * NR * 64);
-    af = B.alloc((size_t)TP * MT * KS * 64);
+    // (+ MIX_QPAD zero rows: the ragged frame groups of 5 / 7 / 11 frames compute up to one output frame beyond the last)
+    tqf = B.alloc((size_t)(TP + MIX_QPAD) * NR * 64);
+    af = B.alloc((size_t)(TP + MIX_QPAD) * MT * KS * 64);
     for (int q = 0; q < T; ++q) for (int r = 0; r < NR; ++r) for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, g = lane >> 4, idx = r * 16 + i, s = idx / TP, t = idx % TP, v = mix_vmap(V, s, g);
         B.buf[tqf + (q * NR + r) * 64 + lane] = (idx < KS * TP && v < V && t < T) ? Tm[(v * T + t) * T + q] : 0.f;

@@ -413,6 +413,9 @@ __device__ __forceinline__ float mul_bc(float coef, float y) {
 #define MCD_TM4(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) MCD_DPP(OP, 3) NOP \
                                   : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]), [y3] CON(y[3]) \
                                   : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), MCD_TM_IN(3), [x] "v"(x), [L] "n"(L))
+#define MCD_TM5(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) MCD_DPP(OP, 3) MCD_DPP(OP, 4) NOP \
+                                  : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]), [y3] CON(y[3]), [y4] CON(y[4]) \
+                                  : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), MCD_TM_IN(3), MCD_TM_IN(4), [x] "v"(x), [L] "n"(L))
 #define MCD_TM6(OP, CON, NOP) asm(MCD_DPP(OP, 0) MCD_DPP(OP, 1) MCD_DPP(OP, 2) MCD_DPP(OP, 3) MCD_DPP(OP, 4) MCD_DPP(OP, 5) NOP \
                                   : [y0] CON(y[0]), [y1] CON(y[1]), [y2] CON(y[2]), [y3] CON(y[3]), [y4] CON(y[4]), [y5] CON(y[5]) \
                                   : MCD_TM_IN(0), MCD_TM_IN(1), MCD_TM_IN(2), MCD_TM_IN(3), MCD_TM_IN(4), MCD_TM_IN(5), [x] "v"(x), [L] "n"(L))
@@ -420,7 +423,7 @@ __device__ __forceinline__ float mul_bc(float coef, float y) {
                        else { if constexpr (PAD) MCD_TM##N("v_fmac_f32_dpp", "+v", "s_nop 1"); else MCD_TM##N("v_fmac_f32_dpp", "+v", ""); } } while (0)
 template <int QC, int L, bool INIT, bool PAD>
 __device__ __forceinline__ void tm_step(float (&y)[QC], const float (&c)[QC], float x) {
-    static_assert(QC == 1 || QC == 2 || QC == 3 || QC == 4 || QC == 6, "time-mix group sizes");
+    static_assert(QC >= 1 && QC <= 6, "time-mix group sizes");
     if constexpr (QC == 1) {
         if constexpr (INIT) y[0] = mul_bc<L, PAD>(c[0], x);
         else fmac_bc<L, PAD>(y[0], c[0], x);
@@ -430,6 +433,8 @@ __device__ __forceinline__ void tm_step(float (&y)[QC], const float (&c)[QC], fl
         MCD_TM(3);
     } else if constexpr (QC == 4) {
         MCD_TM(4);
+    } else if constexpr (QC == 5) {
+        MCD_TM(5);
     } else {
         MCD_TM(6);
     }
@@ -440,6 +445,9 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// zero coefficient rows behind the T real output frames of the mix tables (ragged frame groups, MixCfg::RAGGED)
+constexpr int MIX_QPAD = 4;
 
 // Joint handled by lane group g at k-step ks of the mix.  K-steps are paired over 8 consecutive joints so that the two
 // lane groups sharing an LDS access phase (g = 0,1 and g = 2,3) read rows 4 apart: with a row stride of 4*odd floats
@@ -467,18 +475,27 @@ struct MixCfg {
     static constexpr int CB = CIN / 16;
     // output frames computed together by one unit: all of them (shared X reads) when that still gives every wave
     // work, otherwise one frame per unit
-    static constexpr int QALL = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : 1;
+    // (round 4: frame counts that neither 3 nor 2 divides -- 5, 7, 11 -- take RAGGED groups, 3 + 2 / 4 + 3 / 4 + 4 + 3 frames: the
+    // last unit computes one output frame too many, with zero coefficients (the tables hold MIX_QPAD zero rows behind the
+    // real frames), and does not store it.  One output frame per unit, as before, meant T reads of every X value: +4.9 / +5.3 /
+    // +6.7 % at 5 / 7 / 11 frames, profiles/r04m_ragged_ab.txt.)
+    static constexpr int QALL = (T % 3 == 0) ? 3 : (T % 2 == 0) ? 2 : T == 5 ? 3 : (T == 7 || T == 11) ? 4 : 1;
     // the largest chunk (3, 2, 1 frames) that still gives every wave a unit; failing that, the largest one that keeps more
     // than half of them busy in a single round (e.g. 32 channels at 6 frames: 6 two-frame units -- one round, X reads shared
     // by the pair, no mid-stage coefficient fetch -- instead of 12 single-frame units in two rounds)
-    static constexpr int Q2 = (T % 2 == 0) ? 2 : 1;
-    static constexpr int units_of(int qc) { return NB * CB * (T / qc); }
+    static constexpr int Q2 = (T % 2 == 0 || T == 5 || T == 7 || T == 11) ? 2 : 1;
+    static constexpr int units_of(int qc) { return NB * CB * ((T + qc - 1) / qc); }
     // 12 frames, 64 channels: six frames per unit -- one round of 8 units instead of two of 16, every X value read once
     // per half of the output frames (the shape has no register cap)
     static constexpr int Q6 = (T == 12) ? 6 : 1;
-    static constexpr int QC = (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
+    // 10 / 8 frames, 64 channels: five / four frames per unit -- one round of 8 units (+2 %, profiles/r04m_ragged_ab2.txt)
+    static constexpr int Q5 = (T == 10) ? 5 : 1, Q4 = (T == 8) ? 4 : 1;      // (9 frames as 5 + 4: measured equal to 3 x 3, not taken)
+    static constexpr int QC = (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
+                            : (Q4 > 1 && units_of(Q4) >= NWAVES) ? Q4 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
-    static constexpr int NQ = T / QC;
+    static constexpr int NQ = (T + QC - 1) / QC;
+    static constexpr bool RAGGED = NQ * QC != T;                // the last chunk of a chain holds fewer than QC frames
+    static_assert(NQ * QC - T < MIX_QPAD, "zero rows behind the coefficient tables");
     static constexpr int UNITS = NB * CB * NQ;                  // one unit = (chain, 16-channel block, frame chunk)
     static constexpr int PER = (UNITS + NWAVES - 1) / NWAVES;   // rounds
     static constexpr int NR = (KS * T + 15) / 16;               // VGPRs holding the time-mix coefficients of one q
@@ -564,7 +581,9 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             part[qi] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt)
-                if constexpr (std::is_invocable_v<Init, int, int, int, int, std::true_type>) {
+                if (M::RAGGED && q0 + qi >= T) {
+                    acc[qi][mt] = f32x4{0.f, 0.f, 0.f, 0.f};      // (the frame behind a ragged chain's last: computed on zero coefficients, never stored)
+                } else if constexpr (std::is_invocable_v<Init, int, int, int, int, std::true_type>) {
                     acc[qi][mt] = init(n, q0 + qi, mt * 16 + 4 * g, cb * 16 + j, std::true_type{});   // whole fragment (masks joints >= V)
                 } else {
 #pragma unroll
@@ -597,6 +616,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         });
 #pragma unroll
         for (int qi = 0; qi < QC; ++qi) {
+            if (M::RAGGED && q0 + qi >= T) continue;
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt) {
                 // a store functor that takes the whole 4-joint fragment can issue all its LDS reads before its first

@@ -151,3 +151,32 @@ def test_trajectory_vs_reference(variant):
 
 def test_long_chain_on_the_tiled_kernel():
     _check_trajectory("cat24", 50, 2)
+
+
+def test_single_pass_entries_error_behaviour():
+    """The two single-pass entries on the slab-tiled kernel: a missing workspace, a skip tensor where none belongs and a stage that
+    does not exist there are errors (MCD_EINVAL / MCD_EUNSUPPORTED through the C ABI), not silent fallbacks."""
+    import ctypes as C
+    from mocodad_amd import _lib
+    sc, _, _ = _scorer("cat24")
+    L = _lib.lib()
+    g = _f32(load_golden("pass_cat24.npz"))
+    x = torch.from_numpy(g["x"]).cuda()
+    out = torch.empty_like(x)
+    tab = sc.table(10)
+    assert L.mcd_pass_workspace_bytes(sc._h, x.shape[0]) > 0
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    with torch.cuda.device(0):
+        rc = L.mcd_unet_forward(sc._h, ptr(x), None, ptr(tab), 9, x.shape[0], ptr(out), None, None)
+    assert rc == -1 and b"workspace" in L.mcd_last_error()           # MCD_EINVAL
+    gl = _f32(load_golden("layers_cat24.npz"))
+    e = torch.from_numpy(gl["emb_in"])
+    with pytest.raises(ValueError):                                   # skip tensor: fused stages 7 / 9 only
+        sc.layer_forward(4, torch.from_numpy(gl["L4_in"]), e, skip=torch.from_numpy(gl["L4_in"]))
+    with pytest.raises(RuntimeError):                                 # the resamplers are not stages of their own above 12 frames
+        sc.layer_forward(12, torch.from_numpy(gl["down2_in"]), e)
+    sc6, _, _ = _scorer("cat7")
+    assert L.mcd_pass_workspace_bytes(sc6._h, 8) == 0                 # 1 .. 12 frames: everything lives in LDS
+    with pytest.raises(ValueError):
+        gl7 = _f32(load_golden("layers_cat7.npz"))
+        sc6.layer_forward(7, torch.from_numpy(gl7["L7_in"]), torch.from_numpy(gl7["emb_in"]), skip=torch.from_numpy(gl7["L7_in"]))
