@@ -490,6 +490,8 @@ struct MixCfg {
     static constexpr int Q6 = (T == 12) ? 6 : 1;
     // 10 / 8 frames, 64 channels: five / four frames per unit -- one round of 8 units (+2 %, profiles/r04m_ragged_ab2.txt)
     static constexpr int Q5 = (T == 10) ? 5 : 1, Q4 = (T == 8) ? 4 : 1;      // (9 frames as 5 + 4: measured equal to 3 x 3, not taken)
+    // (all three frames per unit for the 32-channel mixes of the 3-frame kernel -- 4 units, one round -- measured: 0 at 12 joints,
+    // -1 % with the 17-joint layers included, profiles/r04n_q32_ab.txt)
     static constexpr int QC = (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
                             : (Q4 > 1 && units_of(Q4) >= NWAVES) ? Q4 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
