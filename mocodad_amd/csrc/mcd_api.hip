@@ -1,31 +1,13 @@
-// mcd_api.hip — MI355X (gfx950 / CDNA4) kernels + C ABI for the MoCoDAD anomaly-scoring path.
-//
-// What runs here (reference: /root/reference, Python/PyTorch):
-//   MoCoDAD.forward hot loop            models/mocodad.py:155-180      -> score_kernel<T_u, ...> for 1 .. 12 U-Net frames (persistent,
-//   STSAE_Unet.forward                  models/stsae/stsae_unet.py:406-438   one launch for all S*(ns-1) passes), score_tiled_kernel
-//                                                                       for 13 .. 32 (activations in an L2 slab, stages through LDS);
-//                                                                       score_generic_kernel (plain FMAs, any count) cross-checks both
-//   ST_GCNN_layer / ConvTemporalGraphical / CNN_layer  models/gcae/stsgcn.py:94-199
-//   DDPM ancestral update + SmoothL1    models/mocodad.py:172-178,484
-//   STSE.encode (condition encoder)     models/stsae/stsae.py:59-92    -> cond_fast_kernel (1 .. 12 frames) / cond_encode_kernel;
-//   STSE_Unet ('E_unet' encoder)        models/stsae/stsae_unet.py:62-146     cond_unet_kernel (1 .. 12) / cond_unet_generic_kernel
-//   _aggregation_strategy               models/mocodad.py:454-520      -> aggregate_kernel
-//
-// Design: one 512-thread workgroup owns NB reverse-diffusion chains (a chain = one
-// (window, sample) pair) for their whole trajectory.  Activations live in LDS as [column][channel]
-// (column = (chain, frame, joint), channel fastest, row stride = C+4 floats = 4*odd: conflict-free
-// MFMA-operand reads and b128 epilogue stores).  Every dense contraction runs on v_mfma_f32_16x16x4_f32
-// (exact fp32 = fmaf chain), with weights pre-packed in fragment order and streamed from L2 into registers:
-//   mix       joint mix A_q^T x Y_q per (chain, 16-channel block); Y_q (the time mix) is built in registers with
-//             DPP-broadcast coefficients as the B operand
-//   GEMM      the 1x1 channel convolutions (tcn + residual, BatchNorm folded) as one K-concatenated
-//             [W_t | W_r] x [Z ; X] product; the epilogue (+bias, PReLU, +SiLU-Linear embedding, b128 store)
-//             runs right behind each 16x16 tile
-//   resample  joint down/up-sampling per (frame, 16-channel block); the down-samplers' B operands double as the
-//             register-resident U-Net skip tensors d1/d2 that the up-samplers add back
-//   W-first   layers 6 and 10: GEMM first, then the mix on the (fewer) output channels with the layer epilogue
-//             (layer 10: + U-Net residual + DDPM update) in the mix's store functor
-// Everything is fp32 (the reverse chain amplifies error by up to 1e3).
+// mcd_api.hip — host side of libmocodad_hip.so: the C ABI of include/mocodad_hip.h, the weight packer (BatchNorm folding, MFMA
+// fragment order), dispatch to the kernel instantiations of mcd_inst.hip (declared `extern template` in mcd_launch.hpp), and the
+// kernels that are not templates:
+//   cond_encode_kernel          STSE.encode for any channel list / 13 .. 31 condition frames   models/stsae/stsae.py:59-92
+//   cond_unet_generic_kernel    'E_unet' condition encoder at any frame count                  models/stsae/stsae_unet.py:62-146
+//   score_generic_kernel        plain-FMA runtime-shape trajectory kernel: the CROSS-CHECK of the MFMA kernels (MCD_OPT_GENERIC_UNET)
+//   aggregate_kernel            MoCoDAD._aggregation_strategy                                  models/mocodad.py:454-520
+//   scatter_max / frame_scatter / frame_scores kernels   post_processing                       models/mocodad.py:362-425
+// The device code shared by the trajectory kernels (stage functions, LDS plan) is mcd_device.hpp; the kernels themselves are
+// mcd_score_kernel.hpp (1 .. 12 U-Net frames) and mcd_tiled_kernel.hpp (13 .. 32).  See DESIGN.md section 2.
 
 #include "mcd_launch.hpp"
 
