@@ -787,7 +787,7 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
         case 6: return launch_score_t<6, 1, 4>(P, st, fused);                 // 1 chain / WG, 2 WGs per CU
         case 12: return launch_score_t<12, 1, 2>(P, st, fused);               // 1 chain / WG, 1 WG per CU (no register cap)
         case 4: return launch_score_t<4, 1, 4>(P, st, fused);                 // e.g. seg_len 8 split in halves
-        case 5: return launch_score_t<5, 2, 2>(P, st, fused);                 // e.g. seg_len 10 split in halves (2 chains / WG, 1 WG per CU)
+        case 5: return launch_score_t<5, 1, 4>(P, st, fused);                 // e.g. seg_len 10 split in halves (1 chain / WG, 2 WGs per CU: +4.7 % over <5,2,2>, profiles/r04r_t5_shape_ab.txt)
         case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
         case 10: return launch_score_t<10, 1, 2>(P, st, fused);               // e.g. seg_len 20 split in halves / seg_len 10 concat
         case 7: return launch_score_t<7, 1, 2>(P, st, fused);                 // odd frame counts: one output frame per mix unit
@@ -1344,7 +1344,7 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
         case 3: return launch_score_t<3, 2, 4, true>(P, st, nullptr);
         case 6: return launch_score_t<6, 1, 4, true>(P, st, nullptr);
         case 12: return launch_score_t<12, 1, 2, true>(P, st, nullptr);
-        case 5: return launch_score_t<5, 2, 2, true>(P, st, nullptr);
+        case 5: return launch_score_t<5, 1, 4, true>(P, st, nullptr);
         case 7: return launch_score_t<7, 1, 2, true>(P, st, nullptr);
         case 10: return launch_score_t<10, 1, 2, true>(P, st, nullptr);
         default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3, 5, 6, 7, 10, 12 and 13 .. 32 U-Net frames (the fixtures' shapes)");

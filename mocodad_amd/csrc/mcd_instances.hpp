@@ -24,10 +24,10 @@
     X(2, 4, 1, 4, false) \
     X(3, 12, 1, 2, false) /* seg_len 24 split in halves: 1 workgroup per CU, no register cap */ \
     X(3, 8, 1, 2, false) \
-    X(4, 5, 2, 2, false) X(4, 10, 1, 2, false) X(4, 7, 1, 2, false) \
+    X(4, 5, 1, 4, false) X(4, 10, 1, 2, false) X(4, 7, 1, 2, false) \
     X(5, 9, 1, 2, false) X(5, 11, 1, 2, false) \
     X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \
-    X(13, 5, 2, 2, true) X(13, 7, 1, 2, true) X(13, 10, 1, 2, true) \
+    X(13, 5, 1, 4, true) X(13, 7, 1, 2, true) X(13, 10, 1, 2, true) \
     MCD_SCORE_VARIANT_INSTANCES(X)
 
 #define MCD_COND_FAST_INSTANCES(X) \
