@@ -880,8 +880,14 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
     const float* const p1b = b1 + __mul24(col0, cs1) + 4 * g;
     const float* const p2b = b2 + __mul24(col0, cs2) + 4 * g;
     constexpr int KQ = KQ1 + KQ2;
-    constexpr int DEPTH = KQ < 3 ? KQ : 3;
-    // one 16x16 output tile: B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH reads ahead of the MFMAs that consume
+#ifndef MCD_PIPE_DEPTH
+#define MCD_PIPE_DEPTH 1
+#endif
+#ifndef MCD_PIPE_SEED
+#define MCD_PIPE_SEED 0
+#endif
+    constexpr int DEPTH0 = KQ < 3 ? KQ : 3;
+    // one 16x16 output tile: B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH0 reads ahead of the MFMAs that consume
     // them -- read right before its use each fragment exposes an LDS round trip per 4 MFMAs on this wave's matrix-pipe stream
     auto one_tile = [&](auto ii) {
         constexpr int i = decltype(ii)::value;
@@ -897,15 +903,15 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
             constexpr int kq = decltype(kk)::value;
             return *reinterpret_cast<const float4*>(kq < KQ1 ? p1 + kq * 16 : p2 + (kq - KQ1) * 16);
         };
-        float4 buf[DEPTH];
-        static_for<DEPTH>([&](auto dd) { buf[decltype(dd)::value] = rd(dd); });
+        float4 buf[DEPTH0];
+        static_for<DEPTH0>([&](auto dd) { buf[decltype(dd)::value] = rd(dd); });
         float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (HASPRE) pe = pre(ii, col, ng);
         if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
         static_for<KQ>([&](auto kk) {
             constexpr int kq = decltype(kk)::value;
-            const float4 u = buf[kq % DEPTH];
-            if constexpr (kq + DEPTH < KQ) buf[kq % DEPTH] = rd(std::integral_constant<int, kq + DEPTH>{});
+            const float4 u = buf[kq % DEPTH0];
+            if constexpr (kq + DEPTH0 < KQ) buf[kq % DEPTH0] = rd(std::integral_constant<int, kq + DEPTH0>{});
             if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
             c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u.x, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u.y, c, 0, 0, 0);
@@ -936,17 +942,17 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
             constexpr int kq = decltype(kk)::value;
             return *reinterpret_cast<const float4*>(kq < KQ1 ? p1[h] + kq * 16 : p2[h] + (kq - KQ1) * 16);
         };
-        float4 buf[2][DEPTH];
-        static_for<DEPTH>([&](auto dd) { buf[0][decltype(dd)::value] = rd(0, dd); buf[1][decltype(dd)::value] = rd(1, dd); });
+        float4 buf[2][DEPTH0];
+        static_for<DEPTH0>([&](auto dd) { buf[0][decltype(dd)::value] = rd(0, dd); buf[1][decltype(dd)::value] = rd(1, dd); });
         float4 pe0 = make_float4(0.f, 0.f, 0.f, 0.f), pe1 = pe0;
         if constexpr (HASPRE) { pe0 = pre(ia, col0 + i0 * NG * 16, ng); pe1 = pre(ib, col0 + i1 * NG * 16, ng); }
         __builtin_amdgcn_sched_barrier(0);
         static_for<KQ>([&](auto kk) {
             constexpr int kq = decltype(kk)::value;
-            const float4 u0 = buf[0][kq % DEPTH], u1 = buf[1][kq % DEPTH];
-            if constexpr (kq + DEPTH < KQ) {
-                buf[0][kq % DEPTH] = rd(0, std::integral_constant<int, kq + DEPTH>{});
-                buf[1][kq % DEPTH] = rd(1, std::integral_constant<int, kq + DEPTH>{});
+            const float4 u0 = buf[0][kq % DEPTH0], u1 = buf[1][kq % DEPTH0];
+            if constexpr (kq + DEPTH0 < KQ) {
+                buf[0][kq % DEPTH0] = rd(0, std::integral_constant<int, kq + DEPTH0>{});
+                buf[1][kq % DEPTH0] = rd(1, std::integral_constant<int, kq + DEPTH0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
             c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u0.x, c[0], 0, 0, 0);
@@ -966,7 +972,104 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
             epi(ib, col0 + i1 * NG * 16, c0, c[1], col0, ng);
         }
     };
-    if constexpr (DUAL && MAXN >= 2) {
+#ifndef MCD_GEMM_PIPE
+#define MCD_GEMM_PIPE 1
+#endif
+#ifndef MCD_GEMM_PIPE1
+#define MCD_GEMM_PIPE1 0
+#endif
+    constexpr bool PIPE = (DUAL || MCD_GEMM_PIPE1) && MAXN >= 2 && !HASPRE && MCD_GEMM_PIPE;
+    constexpr int PW = DUAL ? 2 : 1;                      // tiles per pipeline step
+#ifndef MCD_PIPE_DEPTH_LONG
+#define MCD_PIPE_DEPTH_LONG MCD_PIPE_DEPTH
+#endif
+    constexpr int PD = KQ >= 8 ? MCD_PIPE_DEPTH_LONG : MCD_PIPE_DEPTH;      // (K = 128: 32 weight registers per wave)
+    constexpr int DEPTH = PIPE ? (KQ < PD ? KQ : PD) : DEPTH0;
+    if constexpr (PIPE) {
+        // The pairs of a wave as ONE software pipeline: a pair's first DEPTH B fragments (and identity-residual seeds) are read
+        // under the previous pair's last MFMAs, and a pair's epilogue is issued behind the NEXT pair's first k-group -- between
+        // two pairs the matrix pipe used to wait for an LDS round trip (reads) plus the MFMA result latency (epilogue).
+        // Buffers and accumulators alternate by the pair's parity (compile-time indices: no copies).  Tile slots past the
+        // wave's last tile are read like the others (never used; LDS reads past the allocation return 0) so that the stream has
+        // no branches.
+        constexpr bool PIN = DUAL || MCD_GEMM_PIPE1 == 2;  // (under the register cap the order is left to the scheduler)
+        constexpr int NP = (MAXN + PW - 1) / PW;
+        const int nv = (NT - ng + NG - 1) / NG;           // this wave's tiles (wave-uniform)
+        float4 bufs[2][2][DEPTH];
+        float4 seed[2][2];
+        f32x4 accs[2][2];
+        auto rdt = [&](int i, auto kk) {
+            constexpr int kq = decltype(kk)::value;
+            return *reinterpret_cast<const float4*>(kq < KQ1 ? p1b + i * NG * 16 * cs1 + kq * 16 : p2b + i * NG * 16 * cs2 + (kq - KQ1) * 16);
+        };
+        auto fetch = [&](auto pp, auto dd) {              // fragment dd of pair pp's tiles (+ the seeds with the last one)
+            constexpr int p = decltype(pp)::value, d = decltype(dd)::value;
+            if constexpr (p < NP) {
+                constexpr int i0 = PW * p, i1 = (PW == 2 && i0 + 1 < MAXN) ? i0 + 1 : i0;
+                bufs[p & 1][0][d] = rdt(i0, dd);
+                if constexpr (i1 != i0) bufs[p & 1][1][d] = rdt(i1, dd);
+                if constexpr (IDRES && d == DEPTH - 1 && MCD_PIPE_SEED) {
+                    seed[p & 1][0] = *reinterpret_cast<const float4*>(p2b + i0 * NG * 16 * cs2 - 4 * g + c0);
+                    if constexpr (i1 != i0) seed[p & 1][1] = *reinterpret_cast<const float4*>(p2b + i1 * NG * 16 * cs2 - 4 * g + c0);
+                }
+            }
+        };
+        auto epi_pair = [&](auto pp, auto nn) {
+            constexpr int p = decltype(pp)::value, N = decltype(nn)::value, i0 = PW * p, i1 = i0 + 1;
+            epi(std::integral_constant<int, i0>{}, col0 + i0 * NG * 16, c0, accs[p & 1][0], col0, ng);
+            if constexpr (N == 2) epi(std::integral_constant<int, i1>{}, col0 + i1 * NG * 16, c0, accs[p & 1][1], col0, ng);
+        };
+        auto chain = [&](auto pp, auto nn) {
+            constexpr int p = decltype(pp)::value, N = decltype(nn)::value, i0 = PW * p, i1 = N == 2 ? i0 + 1 : i0;
+            f32x4 (&c)[2] = accs[p & 1];
+#pragma unroll
+            for (int h = 0; h < N; ++h) {
+                c[h] = f32x4{cinit.x, cinit.y, cinit.z, cinit.w};
+                if (IDRES) {
+                    if constexpr (!MCD_PIPE_SEED) seed[p & 1][h] = *reinterpret_cast<const float4*>(p2b + (h ? i1 : i0) * NG * 16 * cs2 - 4 * g + c0);
+                    c[h] = f32x4{seed[p & 1][h].x, seed[p & 1][h].y, seed[p & 1][h].z, seed[p & 1][h].w};
+                }
+            }
+            static_for<KQ>([&](auto kk) {
+                constexpr int kq = decltype(kk)::value;
+                float4 u[2];
+#pragma unroll
+                for (int h = 0; h < N; ++h) u[h] = bufs[p & 1][h][kq % DEPTH];
+                if constexpr (kq + DEPTH < KQ) {
+                    bufs[p & 1][0][kq % DEPTH] = rdt(i0, std::integral_constant<int, kq + DEPTH>{});
+                    if constexpr (N == 2) bufs[p & 1][1][kq % DEPTH] = rdt(i1, std::integral_constant<int, kq + DEPTH>{});
+                } else if constexpr (N == PW) {           // (a short step is the wave's last)
+                    fetch(std::integral_constant<int, p + 1>{}, std::integral_constant<int, kq + DEPTH - KQ>{});
+                }
+                if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+                c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u[0].x, c[0], 0, 0, 0);
+                if constexpr (N == 2) c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].x, u[1].x, c[1], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u[0].y, c[0], 0, 0, 0);
+                if constexpr (N == 2) c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].y, u[1].y, c[1], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u[0].z, c[0], 0, 0, 0);
+                if constexpr (N == 2) c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].z, u[1].z, c[1], 0, 0, 0);
+                c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u[0].w, c[0], 0, 0, 0);
+                if constexpr (N == 2) c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kq].w, u[1].w, c[1], 0, 0, 0);
+                if constexpr (kq == 0 && p > 0) {         // the previous pair's epilogue, behind this pair's first k-group
+                    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+                    epi_pair(std::integral_constant<int, p - 1>{}, std::integral_constant<int, PW>{});
+                    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            // the wave's last pair runs its epilogue itself; the others leave it to the pair behind them
+            if (PW * (p + 1) >= nv) epi_pair(pp, nn);
+        };
+        static_for<DEPTH>([&](auto dd) { fetch(std::integral_constant<int, 0>{}, dd); });
+        static_for<NP>([&](auto pp) {
+            constexpr int i0 = PW * decltype(pp)::value, i1 = i0 + 1;
+            if constexpr (PW == 2 && i1 < MAXN) {
+                if (i1 < nv) chain(pp, std::integral_constant<int, 2>{});
+                else if (i0 < nv) chain(pp, std::integral_constant<int, 1>{});
+            } else {
+                if (i0 < nv) chain(pp, std::integral_constant<int, 1>{});
+            }
+        });
+    } else if constexpr (DUAL && MAXN >= 2) {
         static_for<(MAXN + 1) / 2>([&](auto pp) {
             constexpr int i0 = 2 * decltype(pp)::value, i1 = i0 + 1;
             if constexpr (i1 < MAXN) {
