@@ -853,6 +853,7 @@ int tiled_wgs(const mcd_weights* w, int64_t chains, int TP) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device);     // the handle's device, whatever the caller's current one
     if (cus < 1) cus = 256;
     const int64_t units = (chains + tl_nb(TP) - 1) / tl_nb(TP);
+    cus *= tl_wgs_per_cu(TP);
     return (int)(units < cus ? units : cus);         // one workgroup per CU (110 - 135 KB of LDS), persistent over the chains
 }
 int64_t tiled_scratch_bytes(const mcd_weights* w, int64_t chains, int TP) { return (int64_t)tiled_wgs(w, chains, TP) * tl_slab_floats(TP * tl_nb(TP)) * 4; }

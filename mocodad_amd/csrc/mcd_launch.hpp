@@ -149,7 +149,12 @@ int launch_cond_unet_t(const mcd_weights* w, const DataView& data, const FrameId
 
 // MFMA kernel of the long windows (12 < T <= 32); slabs: tl_slab_floats(TP) floats per workgroup
 // chains per workgroup of the slab-tiled kernel: two 16-frame chains share one (see score_tiled_kernel)
-constexpr int tl_nb(int TP) { return TP <= 16 ? 2 : 1; }
+#ifndef MCD_TL16_NB
+#define MCD_TL16_NB 1
+#endif
+constexpr int tl_nb(int TP) { return TP <= 16 ? MCD_TL16_NB : 1; }
+// workgroups per CU: a single 16-frame chain (-DMCD_TL16_NB=1) leaves room for two (75 KB of LDS each, 128 registers)
+constexpr int tl_wgs_per_cu(int TP) { return TP * tl_nb(TP) <= 16 ? 2 : 1; }
 template <int TP, int NB, bool LT = false>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
     constexpr int TF = TP * NB;

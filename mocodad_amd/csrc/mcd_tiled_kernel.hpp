@@ -22,7 +22,8 @@ namespace mcd {
 //          accumulators held back until group 1's time mix has read the old rows), or the next layer's resampler input (all of
 //          channels 0..31: 4->5, 6->7; its first chunk: 2->3, 8->9).  The slab keeps the later parts and the skips d1 / d2
 // The frame count is padded to TP = 16, 24 or 32 with zero mixing coefficients (a padded frame's activations are finite
-// garbage that no real frame ever reads); two 16-frame chains share a workgroup (<16, 2>: the stage lengths of 32 frames).
+// garbage that no real frame ever reads).  13 .. 16 frames run as <16, 1>: one chain per workgroup, 79 KB of LDS, TWO workgroups
+// per CU under the 128-register cap (+10.6 % over two chains in one workgroup, profiles/r04v_tl16_nb1_ab.txt).
 // Same noise keys, update, loss and strategies as score_kernel.  Slab traffic: 9 k floats per frame and pass (the first
 // version, every stage through the slab: 37 k -- it ran at the HBM / fabric roofline, 4.6 TB/s, profiles/README.md).
 // ------------------------------------------------------------------------------------------------
@@ -34,7 +35,7 @@ struct TiledNet {
     int we, be;
 };
 // frames per chunk of a fused joint resampler (its input rows of those frames pass through the z region): 16, 12 at 24 frames
-__host__ __device__ constexpr int tl_fc(int TP) { return TP == 24 ? 12 : 16; }
+__host__ __device__ constexpr int tl_fc(int TP) { return TP == 24 ? 12 : TP == 16 ? 8 : 16; }
 __host__ __device__ constexpr int tl_ra_floats(int TP) {
     // LDS work region of a layer: X (32 channels of all frames, + pad rows) and z (the same; half the frames at 17 joints).
     // (A fused resampler's input chunk passes through the z region.)
@@ -454,7 +455,7 @@ typedef const TiledNet __attribute__((address_space(4))) KTiledNet;
 // output is copied to lt_out from where the stage's own epilogue puts it.  Stages 3, 5, 7, 9 are the fused (joint resampler +
 // layer) stages of this kernel: their input is the resampler's input (+ lt_skip, the U-Net skip tensor added behind it).
 template <int TP, int NB, bool LT = false>
-__global__ __launch_bounds__(NTHREADS, NWAVES / 4) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
+__global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
     constexpr int TF = TP * NB;
     constexpr int R17 = TF * 17, R12 = TF * 12, R10 = TF * 10;
