@@ -160,7 +160,19 @@ int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const Frame
     constexpr int TF = TP * NB;
     constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS) * 4;
     LDS_LIMIT((&score_tiled_kernel<TP, NB, LT>), lds);
-    hipLaunchKernelGGL((score_tiled_kernel<TP, NB, LT>), dim3(wgs), dim3(NTHREADS), lds, st, P, M, w->tiled, w->cfg.t_unet, scratch);
+    ScoreParams Q = P;
+    Q.prio_shift = 0;
+    const int phase = w->opt[MCD_OPT_PHASE];      // (-1: no slices; -(16 + shift): a given slice length, tuning)
+    if (TF <= 16 && !LT && P.mode == 0 && phase != -1 && wgs > 0) {
+        // priority time slice of the two co-resident workgroups: about 1/6 of the launch -- chains per workgroup x passes x
+        // ~190 us per pass of a 16-frame chain sharing its CU (2.4 GHz), in ticks of the 100 MHz clock
+        const double per_wg = (double)((P.n_chains + (long long)wgs * NB - 1) / ((long long)wgs * NB));
+        const double ticks = per_wg * (double)(P.ns > 2 ? P.ns - 1 : 1) * 190.0 * 100.0;
+        const int sh = (int)floor(log2(ticks / 6.0) + 0.5);
+        Q.prio_shift = sh < 10 ? 10 : (sh > 26 ? 26 : sh);
+        if (phase < -15) Q.prio_shift = -phase - 16 > 26 ? 26 : (-phase - 16 < 10 ? 10 : -phase - 16);
+    }
+    hipLaunchKernelGGL((score_tiled_kernel<TP, NB, LT>), dim3(wgs), dim3(NTHREADS), lds, st, Q, M, w->tiled, w->cfg.t_unet, scratch);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }

@@ -523,6 +523,18 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             asm volatile("" : "+v"(tid));
             lane = tid & 63;
             wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            if constexpr (TF <= 16) {
+                // two workgroups per CU: they take turns at priority 1 by time slices of the 100 MHz clock XOR their slot on the
+                // CU, as in score_kernel (the arbiter otherwise serves the older one first and the younger one runs its last
+                // chains alone); the host sizes the slice to about a sixth of the launch
+                if (P.prio_shift > 0) {
+                    unsigned hwid;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                    const unsigned slice = (unsigned)(__builtin_amdgcn_s_memrealtime() >> P.prio_shift);
+                    if (((hwid >> 16) ^ slice) & 1u) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+            }
             wb = P.wbuf;
             asm volatile("" : "+s"(wb));
             float* sl = slab;
