@@ -1,8 +1,8 @@
 // mcd_api.hip — host side of libmocodad_hip.so: the C ABI of include/mocodad_hip.h, the weight packer (BatchNorm folding, MFMA
 // fragment order), dispatch to the kernel instantiations of mcd_inst.hip (declared `extern template` in mcd_launch.hpp), and the
 // kernels that are not templates:
-//   cond_encode_kernel          STSE.encode for any channel list / 13 .. 31 condition frames   models/stsae/stsae.py:59-92
-//   cond_unet_generic_kernel    'E_unet' condition encoder at any frame count                  models/stsae/stsae_unet.py:62-146
+//   cond_encode_kernel          STSE.encode for any channel list / 21 .. 31 condition frames   models/stsae/stsae.py:59-92
+//   cond_unet_generic_kernel    'E_unet' condition encoder at any frame count (cross-check)    models/stsae/stsae_unet.py:62-146
 //   score_generic_kernel        plain-FMA runtime-shape trajectory kernel: the CROSS-CHECK of the MFMA kernels (MCD_OPT_GENERIC_UNET)
 //   aggregate_kernel            MoCoDAD._aggregation_strategy                                  models/mocodad.py:454-520
 //   scatter_max / frame_scatter / frame_scores kernels   post_processing                       models/mocodad.py:362-425
@@ -877,7 +877,7 @@ int launch_score_tiled(const mcd_weights* w, const ScoreParams& P, const FrameMa
     }
 #endif
 }
-// plain condition encoder (any channel list; 13 .. 31 condition frames of the shipped one).  scratch: cond_plain_scratch_bytes()
+// plain condition encoder (any channel list; 21 .. 31 condition frames of the shipped one).  scratch: cond_plain_scratch_bytes()
 // of global memory when three LDS buffers do not fit (W.gmode), else unused
 constexpr int CE_MAX_WGS = 512;
 int64_t cond_plain_scratch_bytes(const mcd_weights* w, int64_t B) {
@@ -902,6 +902,27 @@ int launch_cond_mfma(const mcd_weights* w, const DataView& data, const FrameIdx&
     const int Tc = w->cond.Tc;
     if (cond_unet_has_kernel(Tc) && !w->opt[MCD_OPT_COND_GENERIC]) return launch_cond_unet(w, data, fi, seg_len, emb, B, st);
     if (!scratch) return fail(MCD_EINVAL, "workspace required (mcd_score_workspace_bytes) for the runtime-shape condition encoder");
+    if (w->tiled_cond_tp && !w->opt[MCD_OPT_COND_GENERIC]) {      // 13 .. 32 condition frames: the slab-tiled MFMA stages, one window per "chain"
+        ScoreParams P;
+        memset(&P, 0, sizeof(P));
+        P.wbuf = w->dbuf; P.dv = data; P.seg_len = seg_len; P.B = B; P.S = 1; P.n_chains = B; P.ns = 2; P.eps_out = emb;
+        FrameMaps M;
+        memset(&M, 0, sizeof(M));
+        for (int t = 0; t < Tc; ++t) M.src_frame[t] = fi.idx[t];
+        const int wgs = tiled_wgs(w, B, w->tiled_cond_tp);
+        switch (w->tiled_cond_tp) {
+#ifdef MCD_FAST_T
+#ifdef MCD_FAST_TILED_COND
+            case MCD_FAST_TILED_COND: return launch_score_tiled_t<MCD_FAST_TILED_COND, tl_nb(MCD_FAST_TILED_COND), false, true>(w, P, M, scratch, wgs, st);
+#endif
+#else
+#define MCD_CASE(unit, TP, NB) case TP: return launch_score_tiled_t<TP, NB, false, true>(w, P, M, scratch, wgs, st);
+            MCD_TILED_COND_INSTANCES(MCD_CASE)
+#undef MCD_CASE
+#endif
+            default: break;      // (developer builds without this instantiation: the runtime-shape kernel below)
+        }
+    }
     const int wgs = B < GEN_MAX_WGS ? B : GEN_MAX_WGS;
     hipLaunchKernelGGL(cond_unet_generic_kernel, dim3(wgs), dim3(GEN_THREADS), 0, st, w->dbuf, w->gcond, data, fi, seg_len, Tc, B, emb, scratch);
     HIP_TRY(hipGetLastError());
@@ -1081,6 +1102,9 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     const bool has_cond = cfg->strategy == MCD_STRATEGY_INJECT;
     const bool cond_unet = has_cond && cfg->cond_layers == MCD_COND_UNET;
     int utab[TABC_ULB + 1] = {0};   // cond table of the 'E_unet' encoder: 7 layers, 2 resamplers, Linear
+    TiledNet TNc;                   // ... and its tables for score_tiled_kernel<.., COND> (13 .. 32 condition frames)
+    memset(&TNc, 0, sizeof(TNc));
+    int tiled_cond_tp = 0;
     if (cond_unet) {
         const int Tc = cfg->t_cond;
         if (Tc < 1 || Tc > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1.." + std::to_string(MCD_MAX_FRAMES));
@@ -1146,6 +1170,32 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         utab[TABC_ULW] = B.alloc(F * EDIM); memcpy(&B.buf[utab[TABC_ULW]], lw, sizeof(float) * F * EDIM);
         utab[TABC_ULB] = B.alloc(EDIM); memcpy(&B.buf[utab[TABC_ULB]], lb, sizeof(float) * EDIM);
         GC.lw = utab[TABC_ULW]; GC.lb = utab[TABC_ULB];
+        if (Tc > 12) {      // the slab-tiled MFMA stages: mix tables for the padded frame count; GEMM fragments, biases, slopes as above
+            tiled_cond_tp = Tc <= 16 ? 16 : Tc <= 24 ? 24 : 32;
+            for (int l = 0; l < 7; ++l) {
+                const std::string p = std::string("condition_encoder.") + unames[l];
+                if (!pack_mix_mfma(tm, p, Tc, uv[l], B, TNc.tq[l], TNc.am[l], tiled_cond_tp)) return fail(MCD_EMISSING, tm.missing);
+                const float* Tm = tm.get(p + ".gcn.T", (int64_t)uv[l] * Tc * Tc);
+                if (!Tm) return fail(MCD_EMISSING, tm.missing);
+                TNc.tqm[l] = pack_time_mfma(Tm, Tc, uv[l], tiled_cond_tp, tl_nb(tiled_cond_tp), B);
+                TNc.wp[l] = utab[l * F_STRIDE + F_WP]; TNc.bias[l] = utab[l * F_STRIDE + F_BIAS];
+                memcpy(&TNc.slope[l], &utab[l * F_STRIDE + F_SLOPE], sizeof(float));
+            }
+            for (int r = 0; r < 2; ++r) {
+                Folded f;
+                const std::string p = std::string("condition_encoder.") + urs[r];
+                if (!fold_conv_bn(tm, p + ".block.0", p + ".block.1", urout[r], urin[r], f)) return fail(MCD_EMISSING, tm.missing);
+                const int vin = urin[r], vout = urout[r], KS = (vin + 3) / 4, MTr = (vout + 15) / 16;
+                const int wf = B.alloc((size_t)MTr * KS * 64 + 32);
+                for (int mt = 0; mt < MTr; ++mt) for (int ks = 0; ks < KS; ++ks) for (int lane = 0; lane < 64; ++lane) {
+                    const int vo = mt * 16 + (lane & 15), v = rs_vmap(false, vin, ks, lane >> 4);
+                    B.buf[wf + (mt * KS + ks) * 64 + lane] = (vo < vout && v < vin) ? (float)f.w[(size_t)vo * vin + v] : 0.f;
+                }
+                for (int vo = 0; vo < vout; ++vo) B.buf[wf + MTr * KS * 64 + vo] = (float)f.b[vo];
+                TNc.rsw[r] = wf;
+            }
+            TNc.we = utab[TABC_ULW]; TNc.be = utab[TABC_ULB];
+        }
     } else if (has_cond) {
         if (cfg->cond_layers < 1 || cfg->cond_layers > MCD_MAX_COND_LAYERS) return fail(MCD_EINVAL, "bad cond_layers");
         if (cfg->t_cond < 1 || cfg->t_cond > MCD_MAX_FRAMES) return fail(MCD_EUNSUPPORTED, "condition frames must be in 1.." + std::to_string(MCD_MAX_FRAMES));
@@ -1180,7 +1230,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         Cw.lb = B.alloc(EDIM); memcpy(&B.buf[Cw.lb], lb, sizeof(float) * EDIM);
         // fast path (cond_fast_kernel): the shipped architecture at a frame count the MFMA stages are instantiated for
         cond_fast = Cw.n_layers == 4 && Cw.cout[0] == 32 && Cw.cout[1] == 16 && Cw.cout[2] == 32 && Cw.cout[3] == 32 &&
-                    Cw.Tc >= 1 && Cw.Tc <= 12;
+                    Cw.Tc >= 1 && Cw.Tc <= MCD_COND_FAST_MAX_T;
 #ifdef MCD_FAST_T
         cond_fast = cond_fast && Cw.Tc == MCD_FAST_T;     // (developer builds hold one frame count; the rest takes the plain encoder)
 #endif
@@ -1235,7 +1285,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev_dev};
     mcd_weights* w = new mcd_weights();
     memset(w->opt, 0, sizeof(w->opt));
-    w->zero_row = zero_row; w->fast_unet = fast_unet; w->gen = G; w->gcond = GC; w->tiled = TN; w->tiled_tp = tiled_tp;
+    w->zero_row = zero_row; w->fast_unet = fast_unet; w->gen = G; w->gcond = GC; w->tiled = TN; w->tiled_tp = tiled_tp; w->tiled_cond = TNc; w->tiled_cond_tp = tiled_cond_tp;
     w->cfg = *cfg; w->device = device; w->n_floats = B.buf.size(); w->has_cond = has_cond; w->cond_fast = cond_fast; w->cond_unet = cond_unet;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->dbuf), B.buf.size() * sizeof(float));
     if (e != hipSuccess) { delete w; return fail(MCD_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e)); }
@@ -1418,6 +1468,7 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
         if (g3 > gen) gen = g3;
     }
     if (w->cond_unet) { const int64_t g2 = gen_scratch_bytes(cfg->n_windows, w->cond.Tc); if (g2 > gen) gen = g2; }
+    if (w->cond_unet && w->tiled_cond_tp) { const int64_t g5 = tiled_scratch_bytes(w, cfg->n_windows, w->tiled_cond_tp); if (g5 > gen) gen = g5; }
     { const int64_t g4 = cond_plain_scratch_bytes(w, cfg->n_windows); if (g4 > gen) gen = g4; }
     return ws_cond_bytes(w, cfg->n_windows) + ws_loss_bytes(cfg->n_windows, cfg->n_samples) + gen;
 }

@@ -86,7 +86,32 @@
 #else
 #define MCD_U16(...)
 #endif
-#if MCD_INST_UNITS != 16
+#if MCD_UNIT_IS(17)
+#define MCD_U17(...) __VA_ARGS__
+#else
+#define MCD_U17(...)
+#endif
+#if MCD_UNIT_IS(18)
+#define MCD_U18(...) __VA_ARGS__
+#else
+#define MCD_U18(...)
+#endif
+#if MCD_UNIT_IS(19)
+#define MCD_U19(...) __VA_ARGS__
+#else
+#define MCD_U19(...)
+#endif
+#if MCD_UNIT_IS(20)
+#define MCD_U20(...) __VA_ARGS__
+#else
+#define MCD_U20(...)
+#endif
+#if MCD_UNIT_IS(21)
+#define MCD_U21(...) __VA_ARGS__
+#else
+#define MCD_U21(...)
+#endif
+#if MCD_INST_UNITS != 21
 #error "add the MCD_U<n> selectors of the new units"
 #endif
 
@@ -99,6 +124,9 @@ template int launch_cond_fast_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, con
 template int launch_cond_unet_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weights*, const DataView&, const FrameIdx&, int, float*, int, hipStream_t);
 #ifdef MCD_FAST_TILED
 template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED), false>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+#endif
+#ifdef MCD_FAST_TILED_COND
+template int launch_score_tiled_t<MCD_FAST_TILED_COND, tl_nb(MCD_FAST_TILED_COND), false, true>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
 #endif
 #endif
 #else
@@ -113,6 +141,9 @@ MCD_SCORE_INSTANCES(MCD_DEF_SCORE)
 MCD_COND_FAST_INSTANCES(MCD_DEF_COND_FAST)
 MCD_COND_UNET_INSTANCES(MCD_DEF_COND_UNET)
 MCD_TILED_INSTANCES(MCD_DEF_TILED)
+#define MCD_DEF_TILED_COND(unit, TP, NB) \
+    MCD_U##unit(template int launch_score_tiled_t<TP, NB, false, true>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);)
+MCD_TILED_COND_INSTANCES(MCD_DEF_TILED_COND)
 #endif
 
 }  // namespace mcd

@@ -7,9 +7,10 @@
 //   X(unit, T_u, NB, MINW, LT)   score_kernel<T_u, NB, MINW, LT>      (LT: the layer-test form behind mcd_layer_forward)
 //   X(unit, T_c, NB)             cond_fast_kernel / cond_unet_kernel<T_c, NB>
 //   X(unit, TP, NB, LT)          score_tiled_kernel<TP, NB, LT>
+//   X(unit, TP, NB)              score_tiled_kernel<TP, NB, false, true>: the 'E_unet' condition encoder at 13 .. 32 condition frames
 #pragma once
 
-#define MCD_INST_UNITS 16
+#define MCD_INST_UNITS 21
 
 #ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only
 #define MCD_SCORE_VARIANT_INSTANCES(X) X(1, 3, 4, 2, false) X(1, 3, 1, 4, false) X(1, 3, 2, 2, false) X(2, 6, 2, 2, false)
@@ -31,9 +32,12 @@
     MCD_SCORE_VARIANT_INSTANCES(X)
 
 #define MCD_COND_FAST_INSTANCES(X) \
-    X(7, 1, 4) X(7, 2, 3) X(7, 3, 2) X(7, 4, 2) X(7, 5, 2) X(7, 6, 2) X(7, 7, 1) X(7, 8, 1) X(7, 9, 1) X(7, 10, 1) X(7, 11, 1) X(7, 12, 1)
+    X(7, 1, 4) X(7, 2, 3) X(7, 3, 2) X(7, 4, 2) X(7, 5, 2) X(7, 6, 2) X(7, 7, 1) X(7, 8, 1) X(7, 9, 1) X(7, 10, 1) X(7, 11, 1) X(7, 12, 1) \
+    X(20, 13, 1) X(20, 14, 1) X(20, 15, 1) X(20, 16, 1) X(21, 17, 1) X(21, 18, 1) X(21, 19, 1) X(21, 20, 1)   /* 13 .. 20 frames: one window per workgroup, up to 158 KB of LDS */
 
 #define MCD_COND_UNET_INSTANCES(X) \
     X(8, 1, 4) X(8, 2, 3) X(8, 3, 2) X(8, 4, 2) X(8, 5, 2) X(8, 6, 1) X(8, 7, 1) X(10, 8, 1) X(10, 9, 1) X(10, 10, 1) X(10, 11, 1) X(10, 12, 1)
 
 #define MCD_TILED_INSTANCES(X) X(6, 16, 1, false) X(11, 24, 1, false) X(12, 32, 1, false) X(14, 16, 1, true) X(15, 24, 1, true) X(16, 32, 1, true)
+
+#define MCD_TILED_COND_INSTANCES(X) X(17, 16, 1) X(18, 24, 1) X(19, 32, 1)

@@ -37,6 +37,8 @@ struct mcd_weights {
     bool fast_unet;   // a specialised score_kernel<T,...> exists for cfg.t_unet (1 .. 12); otherwise the slab-tiled (13 .. 32) or the runtime-shape kernel
     mcd::TiledNet tiled;   // tables of score_tiled_kernel (12 < t_unet <= 32), frame count padded to tiled_tp
     int tiled_tp;     // 16, 24 or 32; 0 = none
+    mcd::TiledNet tiled_cond;   // ... of its COND form: the 'E_unet' condition encoder at 13 .. 32 condition frames
+    int tiled_cond_tp;
     mcd::GenNet gen;       // plain (unpacked) folded weights of the U-Net for score_generic_kernel
     mcd::GenCond gcond;    // ... and of the 'E_unet' condition encoder
     int zero_row;     // offset (floats) of 32 zero words in dbuf: an all-zero step_table row for mcd_layer_forward
@@ -128,6 +130,8 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
 }
 
 
+// largest frame count of the MFMA encoder of the shipped architecture: its four 17-joint layers need 112 floats of LDS per column
+constexpr int MCD_COND_FAST_MAX_T = 20;
 template <int T, int NB>
 int launch_cond_fast_t(const mcd_weights* w, const DataView& data, const FrameIdx& fi, int seg_len, float* emb, int B, hipStream_t st) {
     constexpr int P17 = ceil16(NB * T * 17);
@@ -155,15 +159,15 @@ int launch_cond_unet_t(const mcd_weights* w, const DataView& data, const FrameId
 constexpr int tl_nb(int TP) { return TP <= 16 ? MCD_TL16_NB : 1; }
 // workgroups per CU: a single 16-frame chain (-DMCD_TL16_NB=1) leaves room for two (75 KB of LDS each, 128 registers)
 constexpr int tl_wgs_per_cu(int TP) { return TP * tl_nb(TP) <= 16 ? 2 : 1; }
-template <int TP, int NB, bool LT = false>
+template <int TP, int NB, bool LT = false, bool COND = false>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
     constexpr int TF = TP * NB;
     constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS) * 4;
-    LDS_LIMIT((&score_tiled_kernel<TP, NB, LT>), lds);
+    LDS_LIMIT((&score_tiled_kernel<TP, NB, LT, COND>), lds);
     ScoreParams Q = P;
     Q.prio_shift = 0;
     const int phase = w->opt[MCD_OPT_PHASE];      // (-1: no slices; -(16 + shift): a given slice length, tuning)
-    if (TF <= 16 && !LT && P.mode == 0 && phase != -1 && wgs > 0) {
+    if (TF <= 16 && !LT && !COND && P.mode == 0 && phase != -1 && wgs > 0) {
         // priority time slice of the two co-resident workgroups: about 1/6 of the launch -- chains per workgroup x passes x
         // ~190 us per pass of a 16-frame chain sharing its CU (2.4 GHz), in ticks of the 100 MHz clock
         const double per_wg = (double)((P.n_chains + (long long)wgs * NB - 1) / ((long long)wgs * NB));
@@ -172,13 +176,14 @@ int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const Frame
         Q.prio_shift = sh < 10 ? 10 : (sh > 26 ? 26 : sh);
         if (phase < -15) Q.prio_shift = -phase - 16 > 26 ? 26 : (-phase - 16 < 10 ? 10 : -phase - 16);
     }
-    hipLaunchKernelGGL((score_tiled_kernel<TP, NB, LT>), dim3(wgs), dim3(NTHREADS), lds, st, Q, M, w->tiled, w->cfg.t_unet, scratch);
+    hipLaunchKernelGGL((score_tiled_kernel<TP, NB, LT, COND>), dim3(wgs), dim3(NTHREADS), lds, st, Q, M, COND ? w->tiled_cond : w->tiled,
+                       COND ? w->cond.Tc : w->cfg.t_unet, scratch);
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
 
 
-// developer builds (-DMCD_FAST_T=3|6|12 [-DMCD_FAST_NB= -DMCD_FAST_MINW= -DMCD_FAST_TILED=16|24|32]): one trajectory kernel only
+// developer builds (-DMCD_FAST_T=3|6|12 [-DMCD_FAST_NB= -DMCD_FAST_MINW= -DMCD_FAST_TILED=16|24|32 -DMCD_FAST_TILED_COND=16|24|32]): one trajectory kernel only
 #ifdef MCD_FAST_T
 #ifndef MCD_FAST_NB
 #define MCD_FAST_NB (MCD_FAST_T == 3 ? 2 : 1)
@@ -196,6 +201,9 @@ extern template int launch_cond_unet_t<MCD_FAST_T, MCD_FAST_NB>(const mcd_weight
 #ifdef MCD_FAST_TILED
 extern template int launch_score_tiled_t<MCD_FAST_TILED, tl_nb(MCD_FAST_TILED), false>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
 #endif
+#ifdef MCD_FAST_TILED_COND
+extern template int launch_score_tiled_t<MCD_FAST_TILED_COND, tl_nb(MCD_FAST_TILED_COND), false, true>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+#endif
 #else
 #define MCD_DECL_SCORE(unit, T, NB, MINW, LT) extern template int launch_score_t<T, NB, MINW, LT>(ScoreParams&, hipStream_t, bool*);
 #define MCD_DECL_COND_FAST(unit, T, NB) \
@@ -208,6 +216,9 @@ MCD_SCORE_INSTANCES(MCD_DECL_SCORE)
 MCD_COND_FAST_INSTANCES(MCD_DECL_COND_FAST)
 MCD_COND_UNET_INSTANCES(MCD_DECL_COND_UNET)
 MCD_TILED_INSTANCES(MCD_DECL_TILED)
+#define MCD_DECL_TILED_COND(unit, TP, NB) \
+    extern template int launch_score_tiled_t<TP, NB, false, true>(const mcd_weights*, const ScoreParams&, const FrameMaps&, float*, int, hipStream_t);
+MCD_TILED_COND_INSTANCES(MCD_DECL_TILED_COND)
 #endif
 
 }  // namespace mcd

@@ -446,6 +446,7 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
 // layout): the per-layer table offsets of TiledNet are read through a pointer into the segment that is made opaque per step and
 // per layer -- read as plain kernel arguments they are loop-invariant, the compiler hoists all ~80 of them above the step loop,
 // and they came back as 441 v_writelane + 985 v_readlane of SGPR spills (round 3: 427 spilled SGPRs at 32 frames)
+constexpr int CU_OUT_TL = 6;               // unet_down_channels[6] of STSE_Unet (CU_OUT of cond_unet_kernel)
 struct TiledKernArgs { ScoreParams P; FrameMaps M; TiledNet N; int T; float* slabs; };
 typedef const TiledNet __attribute__((address_space(4))) KTiledNet;
 
@@ -454,7 +455,11 @@ typedef const TiledNet __attribute__((address_space(4))) KTiledNet;
 // where the PREVIOUS layer's epilogue would have left it (the slab and / or the LDS hand-over regions, see `layer` below), its
 // output is copied to lt_out from where the stage's own epilogue puts it.  Stages 3, 5, 7, 9 are the fused (joint resampler +
 // layer) stages of this kernel: their input is the resampler's input (+ lt_skip, the U-Net skip tensor added behind it).
-template <int TP, int NB, bool LT = false>
+// COND = true: the 'E_unet' condition encoder at 13 .. 32 condition frames (STSE_Unet, stsae_unet.py:62-146,182-251) on the same
+// stages -- one "chain" per window, its condition frames M.src_frame[0 .. T) as input, layers 0 .. 6 with the ENCODER's tables
+// (N; layer 6 is 128 -> 6 channels there, padded to one 16-row m-tile), no embeddings (t = None), then
+// to_time_dim: Linear(6 * T * 10 -> 16) over the (c, t, v) flattening -> P.eps_out[window][16].
+template <int TP, int NB, bool LT = false, bool COND = false>
 __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) void score_tiled_kernel(const ScoreParams P, const FrameMaps M, const TiledNet N, int T,
                                                                   float* __restrict__ slabs) {
     constexpr int TF = TP * NB;
@@ -504,7 +509,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #pragma unroll
             for (int c = 0; c < C0; ++c) {
                 float x;
-                if (P.mode == 1) x = P.x_in ? P.x_in[((size_t)(b * C0 + c) * T + t) * 17 + v] : 0.f;
+                if constexpr (COND) x = load_coord(P.dv, b, c, M.src_frame[t], v, P.seg_len);
+                else if (P.mode == 1) x = P.x_in ? P.x_in[((size_t)(b * C0 + c) * T + t) * 17 + v] : 0.f;
                 else if ((fixed >> t) & 1u) x = load_coord(P.dv, b, c, src_of(t), v, P.seg_len);
                 else {
                     const int e = (c * Tx + tx_of(fixed, t)) * 17 + v;
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 XT[((i * TP + t) * 17 + v) * 4 + c] = x;
             }
         }
-        const int i_first = P.mode == 1 ? P.step_single : P.ns - 1, i_last = P.mode == 1 ? P.step_single : 1;
+        const int i_first = COND ? 0 : P.mode == 1 ? P.step_single : P.ns - 1, i_last = COND ? 0 : P.mode == 1 ? P.step_single : 1;
         for (int sidx = i_first; sidx >= i_last; --sidx) {
             const float* srow = P.step_table + sidx * (4 + EDIM);
             // opaque per step (see score_kernel): otherwise every per-lane address of every stage is hoisted out of the step
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             asm volatile("" : "+v"(tid));
             lane = tid & 63;
             wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            if constexpr (TF <= 16) {
+            if constexpr (TF <= 16 && !COND) {
                 // two workgroups per CU: they take turns at priority 1 by time slices of the 100 MHz clock XOR their slot on the
                 // CU, as in score_kernel (the arbiter otherwise serves the older one first and the younger one runs its last
                 // chains alone); the host sizes the slice to about a sixth of the launch
@@ -546,12 +552,12 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             float* const D1 = A1 + (R10 + 16) * 132;
             float* const D2 = D1 + (R17 + 16) * 36;
             __syncthreads();
-            if (tid < NB * EDIM) {
+            if (!COND && tid < NB * EDIM) {
                 float e = srow[4 + tid % EDIM];
                 if (P.cond_emb) e += P.cond_emb[(size_t)b_of(tid / EDIM) * EDIM + tid % EDIM];
                 SE[tid] = e / (1.f + expf(-e));
             }
-            if (sidx > 1 && P.mode == 0) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
+            if (!COND && sidx > 1 && P.mode == 0) {      // this step's noise, one thread per (frame, joint pair): the same Philox keys as score_kernel
                 const int k = P.ns - sidx;
                 for (int gi = tid; gi < NB * T * 9; gi += NTHREADS) {
                     const int i = gi / (T * 9), t = (gi / 9) % T, v0 = (gi % 9) * 2;
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 }
             }
             __syncthreads();
-            for (int u = tid; u < NB * EMB_TOTAL; u += NTHREADS) {
+            for (int u = tid; !COND && u < NB * EMB_TOTAL; u += NTHREADS) {
                 const int i = u / EMB_TOTAL, o = u % EMB_TOTAL;
                 const float* we = wb + Ns->we + o * EDIM;
                 float a = wb[Ns->be + o];
@@ -602,12 +608,12 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 constexpr bool HO17 = L == 0 || L == 1 || L == 9, HI17 = L == 1 || L == 2;
                 // ... and into a fused resampler (4 -> down2 -> 5, 6 -> up3 -> 7): output channels 0 .. 31 go where the next layer's
                 // resampler takes its input chunks from (that layer's z region), all frames at once
-                constexpr bool HOR = L == 4 || L == 6, HIR = L == 5 || L == 7;
+                constexpr bool HOR = L == 4 || (L == 6 && !COND), HIR = L == 5 || L == 7;
                 constexpr int TNEXT = (TF * (L == 4 ? 10 : L == 8 ? 17 : 12) + 16) * 36;     // offset of the next layer's z region
                 // ... or only the resampler's FIRST chunk where all of it does not fit (2 -> down1 -> 3, 8 -> up2 -> 9); layer 2 keeps
                 // group 0's accumulators until both groups are through (the chunk's place is still its own X rows before)
                 constexpr bool HOC = L == 2 || L == 8, HIC = L == 3 || L == 9;
-                constexpr LDesc D = layer_desc(L);
+                constexpr LDesc D = (COND && L == 6) ? LDesc{128, 16, 10, 1} : layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
                 constexpr bool RES = D.res != 0;
                 constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSZ = cs_of(CINV);
@@ -782,7 +788,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                             const int col = ng * 16 + (lane & 15) + i * TI::NG * 16;
                             if (ng + i * TI::NG < NT && col < ROWSG) {
                                 const int gcol = fg * ROWSG + col;
-                                const float4 e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
+                                float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if constexpr (!COND) e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
                                 const f32x2 t0 = f32x2{ac[i][0] + bcur.x, ac[i][1] + bcur.y}, t1 = f32x2{ac[i][2] + bcur.z, ac[i][3] + bcur.w};
                                 const f32x2 m0 = t0 * slope, m1 = t1 * slope;
                                 const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
@@ -864,11 +871,31 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             layer(TL_C(4), TL_NORS, A0, false, D2, nullptr);                // -> d2
             layer(TL_C(5), TL_C(1), D2, false, A0, nullptr);                // down2 on the way in; 64 -> 128
             layer(TL_C(6), TL_NORS, A0, false, A1, nullptr);                // 128 -> 64, mix-first here (four 32-channel quarters)
+            if constexpr (COND) {
+                // to_time_dim: emb[window][j] = b[j] + sum_k W[j][k] H[k], k = (c * T + t) * 10 + v, H = layer 6's 6 channels in the slab
+                __syncthreads();
+                int tid = tid0;
+                asm volatile("" : "+v"(tid));
+                const int F = CU_OUT_TL * T * 10;
+                const float* Wl = wb + Ns->we;
+                for (int u = tid >> 5; u < NB * EDIM; u += NTHREADS / 32) {        // 32 lanes per (chain, output)
+                    const int i = u / EDIM, jo = u % EDIM, part = tid & 31;
+                    float a = 0.f;
+                    for (int k = part; k < F; k += 32) {
+                        const int c = k / (T * 10), r = k % (T * 10);                // r = t * 10 + v
+                        a = fmaf(Wl[(size_t)jo * F + k], A1[(size_t)(i * TP * 10 + r) * cs_of(16) + c], a);
+                    }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 32);
+                    if (part == 0 && grp * NB + i < P.n_chains) P.eps_out[(size_t)b_of(i) * EDIM + jo] = a + wb[Ns->be + jo];
+                }
+            } else {
             layer(TL_C(7), TL_C(2), A1, false, A0, D2);                     // up3 + d2 on the way in
             layer(TL_C(8), TL_NORS, A0, false, A1, nullptr);
             layer(TL_C(9), TL_C(3), A1, false, A0, D1);                     // up2 + d1 on the way in
+            }
             TLMARK(61);
-            if (!LT || P.lt_stage == 10) {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
+            if (!COND && (!LT || P.lt_stage == 10)) {   // ---- layer 10 (32 -> 2) W-first on plain FMAs: P4[col][r] = sum_k W4[r][k] X[col][k]  (P_t 0,1 ; P_r 2,3)
                 int tid = tid0;
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -950,7 +977,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             }
         }
         __syncthreads();
-        if (P.mode == 1) continue;
+        if (COND || P.mode == 1) continue;
         // ---- loss over the corrupt frames (mocodad.py:484)
         for (int i = 0; i < NB; ++i) {
             if (grp * NB + i >= P.n_chains) break;

@@ -239,7 +239,11 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     ("concat", 20, [0, 1], "AE"), ("inbetween_imp", 30, 3, "AE"), ("no_condition", 17, None, "AE"), ("concat", 32, [28, 29, 30, 31], "AE"),
     # 25 .. 31 condition frames: the plain condition encoder with one of its three activation buffers in global scratch
     ("inject", 32, list(range(28)), "AE"), ("inject", 30, list(range(4, 30)), "AE"), ("inject", 32, list(range(31)), "E_unet"),
-    ("inject", 32, list(range(25)), "AE")])
+    ("inject", 32, list(range(25)), "AE"),
+    # 13 .. 20 condition frames of the shipped encoder: cond_fast_kernel (MFMA, one window per workgroup); 'E_unet' at 13 .. 32
+    # condition frames: the slab-tiled stages in their COND form (16: above; here the 24-frame padding)
+    ("inject", 20, list(range(17)), "AE"), ("inject", 24, list(range(20)), "AE"), ("inject", 26, list(range(5, 24)), "AE"),
+    ("inject", 28, list(range(20)), "E_unet")])
 def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 1, 2, 4, 5, 7 .. 11 frames on the
     specialised kernels (seg_len 10 split 5 + 5, seg_len 20 split 10 + 10, concat over 10 frames, a 1-frame window, ...); 13 .. 32
