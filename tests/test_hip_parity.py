@@ -242,7 +242,7 @@ def _random_model(strategy, seg_len, ci, arch="AE", seed=5):
     ("inject", 32, list(range(25)), "AE"),
     # 13 .. 20 condition frames of the shipped encoder: cond_fast_kernel (MFMA, one window per workgroup); 'E_unet' at 13 .. 32
     # condition frames: the slab-tiled stages in their COND form (16: above; here the 24-frame padding)
-    ("inject", 20, list(range(17)), "AE"), ("inject", 24, list(range(20)), "AE"), ("inject", 26, list(range(5, 24)), "AE"),
+    ("inject", 20, list(range(17)), "AE"), ("inject", 24, list(range(20)), "AE"), ("inject", 26, list(range(7, 26)), "AE"),
     ("inject", 28, list(range(20)), "E_unet")])
 def test_other_frame_counts_vs_oracle(strategy, seg_len, ci, arch):
     """U-Net frame counts that no reference-generated fixture covers, HIP vs. oracle: 1, 2, 4, 5, 7 .. 11 frames on the
