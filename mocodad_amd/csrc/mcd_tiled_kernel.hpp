@@ -85,9 +85,9 @@ struct ZeroInitL {
 // mix of CINV (16 or 32) channels over ALL TP frames: X (LDS, [frame * V + joint][channel], stride cs) -> store functor.
 // unit = (16-channel block, QC output frames); joint mix on the matrix cores exactly as in mix_stage, the time mix as
 // tm_step groups over one k-step's TP input frames at a time.
-template <int CINV, int V, int TP, int NB = 1>
+template <int CINV, int V, int TP, int NB = 1, int QCO = 0>
 struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's QC output frames (NB chains of TP frames each)
-    static constexpr int QC = tl_qc(TP), KS = (V + 3) / 4, MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
+    static constexpr int QC = QCO > 0 ? QCO : tl_qc(TP), KS = (V + 3) / 4, MT = (V + 15) / 16, CB = CINV / 16, NQ = TP / QC;
     static constexpr int UNITS = CB * NB * NQ, PER = (UNITS + NWAVES - 1) / NWAVES, NR = (KS * TP + 15) / 16;
     float tq[QC][NR], aop[QC][MT][KS];
     // u: unit index in the flat list of CB x (NB * NQ) units (clamped: waves without a unit fetch the last one's)
@@ -109,11 +109,11 @@ struct MixLongCoef {      // time-mix rows + joint-mix fragments of one unit's Q
 // `first`: the coefficients of the wave's first unit, fetched by the caller before it waited for X to land in LDS
 // NGRP > 1: only the output frames of frame group `grp` (the flat frame list cut in NGRP equal parts) -- the caller's z region
 // holds one group at a time
-template <int CINV, int V, int TP, int NB, int NGRP = 1, class Init, class Store>
-__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP, NB>& first,
+template <int CINV, int V, int TP, int NB, int NGRP = 1, int QCO = 0, class Init, class Store>
+__device__ __forceinline__ void mix_long(const float* __restrict__ X, int cs, const MixLongCoef<CINV, V, TP, NB, QCO>& first,
                                          const float* __restrict__ tqd, const float* __restrict__ af,
                                          int wave, int lane, Init&& init, Store&& store, int grp = 0) {
-    using MC = MixLongCoef<CINV, V, TP, NB>;
+    using MC = MixLongCoef<CINV, V, TP, NB, QCO>;
     constexpr int QC = MC::QC, KS = MC::KS, KP = 2 * (KS / 2), MT = MC::MT, CB = MC::CB, NQ = MC::NQ;
     static_assert((NB * NQ) % NGRP == 0, "frame groups hold whole mix units");
     constexpr int UNITS = MC::UNITS / NGRP, PER = (UNITS + NWAVES - 1) / NWAVES;
@@ -906,7 +906,12 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     }
                     __syncthreads();
                 }
-                MixLongCoef<16, 17, TP, NB> mc10;      // (the mix's first coefficients: in flight behind the product)
+#ifndef MCD_TL_QC10
+#define MCD_TL_QC10 2
+#endif
+                // (16 frames: two output frames per unit -- 8 units, every wave busy -- instead of four in 4 units)
+                constexpr int QC10 = TF <= 16 ? MCD_TL_QC10 : 0;
+                MixLongCoef<16, 17, TP, NB, QC10> mc10;      // (the mix's first coefficients: in flight behind the product)
                 mc10.load(wb + Ns->tq[10], wb + Ns->am[10], wave, lane);
                 const float* w4 = wb + Ns->wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
                 for (int col = tid; col < R17; col += NTHREADS) {
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 }
                 __syncthreads();
                 // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
-                mix_long<16, 17, TP, NB>(P4, 4, mc10, wb + Ns->tq[10], wb + Ns->am[10], wave, lane, ZeroInitL{},
+                mix_long<16, 17, TP, NB, 1, QC10>(P4, 4, mc10, wb + Ns->tq[10], wb + Ns->am[10], wave, lane, ZeroInitL{},
                                      [&](int q, int w0, int c, auto v) {
                                          if (c < C0) {
                                              float* zp = ZO + ((q * 17 + w0)) * C0 + c;
