@@ -520,11 +520,15 @@ def main():
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
         nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,2", 4: "4,1,4", 8: "8,1,2", 5: "5,1,4", 10: "10,1,2", 7: "7,1,2", 9: "9,1,2", 11: "11,1,2", 1: "1,4,4", 2: "2,3,4"}.get(sc.t_unet)
-        tiled = nb is None         # 13 .. 32 U-Net frames: the slab-tiled kernel, frame count padded to 16 (two chains per workgroup) / 24 / 32
-        kname = f"score_kernel<{nb}>" if nb else \
-            "score_tiled_kernel<%s> (T_u=%d)" % ("16,2" if sc.t_unet <= 16 else "24,1" if sc.t_unet <= 24 else "32,1", sc.t_unet)
-        enc = "" if strat != "inject" else (" + cond_unet_generic_kernel" if cfg.get("conditioning_architecture") == "E_unet" else " + cond_encode_kernel") if sc.t_cond > 12 \
-            else (f" + cond_unet_kernel<{sc.t_cond}>" if cfg.get("conditioning_architecture") == "E_unet" else f" + cond_fast_kernel<{sc.t_cond}>")
+        tiled = nb is None         # 13 .. 32 U-Net frames: the slab-tiled kernel, frame count padded to 16 (two workgroups per CU) / 24 / 32
+        tp_of = lambda t: 16 if t <= 16 else 24 if t <= 24 else 32
+        kname = f"score_kernel<{nb}>" if nb else "score_tiled_kernel<%d,1> (T_u=%d)" % (tp_of(sc.t_unet), sc.t_unet)
+        if strat != "inject":
+            enc = ""
+        elif cfg.get("conditioning_architecture") == "E_unet":     # 1 .. 12 frames: LDS-resident; 13 .. 32: the slab-tiled stages (COND form)
+            enc = f" + cond_unet_kernel<{sc.t_cond}>" if sc.t_cond <= 12 else " + score_tiled_kernel<%d,1,COND> (T_c=%d)" % (tp_of(sc.t_cond), sc.t_cond)
+        else:                                                      # shipped encoder: MFMA up to 20 frames, the plain kernel above
+            enc = f" + cond_fast_kernel<{sc.t_cond}>" if sc.t_cond <= 20 else " + cond_encode_kernel"
         split_used = sc.plan_split(B, S, ns) if B > 0 else 1         # what the library chose for this call (mcd_plan_split)
         # the shipped ('AE') encoder with as many condition frames as the U-Net has frames runs inside the one-launch kernel
         enc_inside = strat != "inject" or (cfg.get("conditioning_architecture") != "E_unet" and sc.t_cond == sc.t_unet)

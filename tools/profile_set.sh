@@ -14,7 +14,7 @@ for c in $CFGS; do
 done
 if [ -z "$2" ]; then
 # every other frame-count family: one line each (no CPU leg)
-{ for c in seg4 seg10 seg14 seg20 seg22 concat12 seg32 concat24 concat32 seg10_eunet seg32_eunet; do
+{ for c in seg4 seg10 seg14 seg16 seg18 seg20 seg22 concat12 seg32 concat24 concat32 seg10_eunet seg32_eunet; do
     timeout 300 python bench.py --config $c --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-12s %10.1f clips/s  frac %.4f  kernel ms/step %8.4f  %s' % ('$c', d['value'], r['frac'], r['kernel_ms_per_step'], r.get('kernel', '')))"
   done; } > $O/shapes.txt 2>&1
 # chain-major (3 launches) vs window-major (one launch, the default) on this box, interleaved
