@@ -148,8 +148,8 @@ int64_t mcd_score_workspace_bytes(const mcd_weights_t* w, const mcd_score_cfg_t*
  * 1 = a workgroup runs every sample of its windows -- condition encoder, trajectories and aggregation in ONE kernel launch,
  * the default for batches that fill the device (1024 windows x 5 samples on 256 CUs); n_samples = one trajectory per
  * workgroup with the encoder and the aggregation as their own launches (better fill for small batches); 0 = the call does
- * not run on score_kernel<T_u, ...> at all: 13 .. 32 U-Net frames (the slab-tiled kernel, one or two trajectories per
- * workgroup, aggregation as its own launch) or MCD_OPT_GENERIC_UNET.  Negative: MCD_E*. */
+ * not run on score_kernel<T_u, ...> at all: 13 .. 32 U-Net frames (the slab-tiled kernel, persistent workgroups of one chain at a
+ * time, aggregation as its own launch) or MCD_OPT_GENERIC_UNET.  Negative: MCD_E*. */
 int32_t mcd_plan_split(const mcd_weights_t* w, const mcd_score_cfg_t* cfg);
 
 /* Per-handle options (no environment variables; the only process-wide state is mcd_debug_set_prof's pointer).  Set them before the calls they affect, from the
