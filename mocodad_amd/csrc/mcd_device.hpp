@@ -492,7 +492,14 @@ struct MixCfg {
     static constexpr int Q5 = (T == 10) ? 5 : 1, Q4 = (T == 8) ? 4 : 1;      // (9 frames as 5 + 4: measured equal to 3 x 3, not taken)
     // (all three frames per unit for the 32-channel mixes of the 3-frame kernel -- 4 units, one round -- measured: 0 at 12 joints,
     // -1 % with the 17-joint layers included, profiles/r04n_q32_ab.txt)
-    static constexpr int QC = (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
+    // 10 / 11 frames, 32 channels: three frames per unit (3 + 3 + 3 + 1 / 3 + 3 + 3 + 2: 8 units, ONE round, instead of 10 / 12 units of
+    // two frames in two rounds with idle waves in the second): +0.6 / +2.3 % (MCD_MIXQX bit 0; profiles/r04ab_mixqx_ab.txt).  Bit 1,
+    // 11 frames at 64 channels as 6 + 5 (8 units instead of 12 of 4 + 4 + 3): 16 spilled registers, -0.2 %, off.
+#ifndef MCD_MIXQX
+#define MCD_MIXQX 1
+#endif
+    static constexpr int QX = NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3 : 0;
+    static constexpr int QC = QX > 0 ? QX : (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
                             : (Q4 > 1 && units_of(Q4) >= NWAVES) ? Q4 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
     static constexpr int NQ = (T + QC - 1) / QC;

@@ -20,7 +20,7 @@
 
 #define MCD_SCORE_INSTANCES(X) \
     X(1, 3, 2, 4, false)  /* HR-Avenue / HR-STC: 2 chains per workgroup, 2 workgroups per CU (<= 128 VGPRs) */ \
-    X(1, 1, 4, 4, false) X(1, 2, 3, 4, false) \
+    X(1, 1, 4, 4, false) X(1, 2, 2, 4, false) \
     X(2, 6, 1, 4, false)  /* concat over 6 frames */ \
     X(2, 4, 1, 4, false) \
     X(3, 12, 1, 2, false) /* seg_len 24 split in halves: 1 workgroup per CU, no register cap */ \
