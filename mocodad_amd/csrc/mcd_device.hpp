@@ -498,7 +498,8 @@ struct MixCfg {
 #ifndef MCD_MIXQX
 #define MCD_MIXQX 1
 #endif
-    static constexpr int QX = NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3 : 0;
+    static constexpr int QX = NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3
+                              : ((MCD_MIXQX & 4) && T == 9 && CIN == 32) ? 3 : ((MCD_MIXQX & 8) && T == 9 && CIN == 16) ? 2 : ((MCD_MIXQX & 16) && T == 9 && CIN == 16) ? 3 : 0;
     static constexpr int QC = QX > 0 ? QX : (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
                             : (Q4 > 1 && units_of(Q4) >= NWAVES) ? Q4 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
@@ -511,7 +512,10 @@ struct MixCfg {
     // 12 single-frame units on 8 waves (the 32-channel layers at T = 3, NB = 2): four waves take two units.  SAMEQ gives
     // those waves two units of the SAME output frame -- waves 0-3: frame w/2, groups 2(w&1) + round; waves 4-7: frame 2,
     // group w-4 -- so the coefficients (which depend on the frame only) serve both rounds and nothing is fetched mid-stage
-    static constexpr bool SAMEQ = QC == 1 && NQ == 3 && UNITS == 12 && NWAVES == 8;
+#ifndef MCD_SAMEQX
+#define MCD_SAMEQX 1
+#endif
+    static constexpr bool SAMEQ = (QC == 1 || MCD_SAMEQX) && NQ == 3 && UNITS == 12 && NWAVES == 8;
     // unit (frame chunk index, group = chain * CB + channel block) of (wave, round); u < 0: none
     __device__ static __forceinline__ int unit_of(int wave, int round) {
         if constexpr (SAMEQ) {
