@@ -495,8 +495,11 @@ struct MixCfg {
     // 10 / 11 frames, 32 channels: three frames per unit (3 + 3 + 3 + 1 / 3 + 3 + 3 + 2: 8 units, ONE round, instead of 10 / 12 units of
     // two frames in two rounds with idle waves in the second): +0.6 / +2.3 % (MCD_MIXQX bit 0; profiles/r04ab_mixqx_ab.txt).  Bit 1,
     // 11 frames at 64 channels as 6 + 5 (8 units instead of 12 of 4 + 4 + 3): 16 spilled registers, -0.2 %, off.
+    // 9 frames: the rule below picked ONE frame per unit at 32 and 16 channels (18 units = three rounds, 9 units = two rounds with a
+    // single unit in the second); three frames per unit at 32 channels (6 units, bit 2) and two at 16 channels (2 + 2 + 2 + 2 + 1: 5
+    // units, bit 3) are one round each: +0.9 % and +0.7 % (three frames at 16 channels, bit 4: +0); profiles/r04ad_t9_mixq_ab.txt
 #ifndef MCD_MIXQX
-#define MCD_MIXQX 1
+#define MCD_MIXQX 13
 #endif
     static constexpr int QX = NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3
                               : ((MCD_MIXQX & 4) && T == 9 && CIN == 32) ? 3 : ((MCD_MIXQX & 8) && T == 9 && CIN == 16) ? 2 : ((MCD_MIXQX & 16) && T == 9 && CIN == 16) ? 3 : 0;
@@ -667,9 +670,9 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             load_x(u < 0 ? 0 : u, xs);
             if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
             MixCoef<CIN, V, T, NB> nxt;
-            if constexpr (rnd + 1 < PER && !M::SAMEQ) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
+            if constexpr (rnd + 1 < PER && !M::SAMEQ && NQ > 1) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
             if (u >= 0) unit(cur, u, xs);
-            if constexpr (rnd + 1 < PER && !M::SAMEQ) cur = nxt;
+            if constexpr (rnd + 1 < PER && !M::SAMEQ && NQ > 1) cur = nxt;       // (one frame group: every unit has the same coefficients)
         });
     }
 }
