@@ -498,11 +498,26 @@ struct MixCfg {
     // 9 frames: the rule below picked ONE frame per unit at 32 and 16 channels (18 units = three rounds, 9 units = two rounds with a
     // single unit in the second); three frames per unit at 32 channels (6 units, bit 2) and two at 16 channels (2 + 2 + 2 + 2 + 1: 5
     // units, bit 3) are one round each: +0.9 % and +0.7 % (three frames at 16 channels, bit 4: +0); profiles/r04ad_t9_mixq_ab.txt
+    // 5 frames, 32 channels: 3 + 2 (4 units) instead of 2 + 2 + 1 (6 units): +1.3 % (bit 5).  The same sweep (-DMCD_QC16/32/64, profiles/
+    // r04ae_qc_sweep_ab.txt) found nothing at 6 frames / 32 channels as 3 + 3 (+0.1 %), and fewer, larger units at 16 channels slower:
+    // 7 / 8 frames in pairs -1.3 / -2.3 %, 12 frames in triples -0.5 %
 #ifndef MCD_MIXQX
-#define MCD_MIXQX 13
+#define MCD_MIXQX 45
 #endif
-    static constexpr int QX = NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3
-                              : ((MCD_MIXQX & 4) && T == 9 && CIN == 32) ? 3 : ((MCD_MIXQX & 8) && T == 9 && CIN == 16) ? 2 : ((MCD_MIXQX & 16) && T == 9 && CIN == 16) ? 3 : 0;
+    // (tuning builds: -DMCD_QC16= / -DMCD_QC32= / -DMCD_QC64= force the frames per unit of the 16- / 32- / 64-channel mixes)
+#ifndef MCD_QC16
+#define MCD_QC16 0
+#endif
+#ifndef MCD_QC32
+#define MCD_QC32 0
+#endif
+#ifndef MCD_QC64
+#define MCD_QC64 0
+#endif
+    static constexpr int QF = CIN == 16 ? MCD_QC16 : CIN == 32 ? MCD_QC32 : CIN == 64 ? MCD_QC64 : 0;
+    static constexpr int QX = QF > 0 ? QF : NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3
+                              : ((MCD_MIXQX & 4) && T == 9 && CIN == 32) ? 3 : ((MCD_MIXQX & 8) && T == 9 && CIN == 16) ? 2 : ((MCD_MIXQX & 16) && T == 9 && CIN == 16) ? 3
+                              : ((MCD_MIXQX & 32) && T == 5 && CIN == 32) ? 3 : 0;
     static constexpr int QC = QX > 0 ? QX : (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
                             : (Q4 > 1 && units_of(Q4) >= NWAVES) ? Q4 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;

@@ -189,7 +189,7 @@ int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const Frame
 #define MCD_FAST_NB (MCD_FAST_T == 3 ? 2 : 1)
 #endif
 #ifndef MCD_FAST_MINW
-#define MCD_FAST_MINW (MCD_FAST_T >= 8 ? 2 : 4)
+#define MCD_FAST_MINW (MCD_FAST_T >= 7 ? 2 : 4)
 #endif
 #endif
 
