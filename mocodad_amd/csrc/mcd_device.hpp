@@ -534,6 +534,9 @@ struct MixCfg {
 #define MCD_SAMEQX 1
 #endif
     static constexpr bool SAMEQ = (QC == 1 || MCD_SAMEQX) && NQ == 3 && UNITS == 12 && NWAVES == 8;
+    // a stage lasts as long as its busiest wave's units: a partial extra round (9 units on 8 waves) costs a whole one.  Every
+    // instantiated shape is either one round, full rounds, or the SAMEQ pair map -- a new shape that is not has to pick its QC here
+    static_assert(T > 12 || PER == 1 || UNITS % NWAVES == 0 || SAMEQ, "mix units: a partial round of units (see MixCfg::QX)");     // (T > 12: the condition encoders of 13 .. 20 frames, < 1 % of a step)
     // unit (frame chunk index, group = chain * CB + channel block) of (wave, round); u < 0: none
     __device__ static __forceinline__ int unit_of(int wave, int round) {
         if constexpr (SAMEQ) {

@@ -36,7 +36,7 @@
     X(20, 13, 1) X(20, 14, 1) X(20, 15, 1) X(20, 16, 1) X(21, 17, 1) X(21, 18, 1) X(21, 19, 1) X(21, 20, 1)   /* 13 .. 20 frames: one window per workgroup, up to 158 KB of LDS */
 
 #define MCD_COND_UNET_INSTANCES(X) \
-    X(8, 1, 4) X(8, 2, 3) X(8, 3, 2) X(8, 4, 2) X(8, 5, 2) X(8, 6, 1) X(8, 7, 1) X(10, 8, 1) X(10, 9, 1) X(10, 10, 1) X(10, 11, 1) X(10, 12, 1)
+    X(8, 1, 4) X(8, 2, 2) X(8, 3, 2) X(8, 4, 2) X(8, 5, 2) X(8, 6, 1) X(8, 7, 1) X(10, 8, 1) X(10, 9, 1) X(10, 10, 1) X(10, 11, 1) X(10, 12, 1)
 
 #define MCD_TILED_INSTANCES(X) X(6, 16, 1, false) X(11, 24, 1, false) X(12, 32, 1, false) X(14, 16, 1, true) X(15, 24, 1, true) X(16, 32, 1, true)
 
