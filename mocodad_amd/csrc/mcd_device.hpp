@@ -492,18 +492,22 @@ struct MixCfg {
     static constexpr int Q5 = (T == 10) ? 5 : 1, Q4 = (T == 8) ? 4 : 1;      // (9 frames as 5 + 4: measured equal to 3 x 3, not taken)
     // (all three frames per unit for the 32-channel mixes of the 3-frame kernel -- 4 units, one round -- measured: 0 at 12 joints,
     // -1 % with the 17-joint layers included, profiles/r04n_q32_ab.txt)
-    // 10 / 11 frames, 32 channels: three frames per unit (3 + 3 + 3 + 1 / 3 + 3 + 3 + 2: 8 units, ONE round, instead of 10 / 12 units of
-    // two frames in two rounds with idle waves in the second): +0.6 / +2.3 % (MCD_MIXQX bit 0; profiles/r04ab_mixqx_ab.txt).  Bit 1,
-    // 11 frames at 64 channels as 6 + 5 (8 units instead of 12 of 4 + 4 + 3): 16 spilled registers, -0.2 %, off.
-    // 9 frames: the rule below picked ONE frame per unit at 32 and 16 channels (18 units = three rounds, 9 units = two rounds with a
-    // single unit in the second); three frames per unit at 32 channels (6 units, bit 2) and two at 16 channels (2 + 2 + 2 + 2 + 1: 5
-    // units, bit 3) are one round each: +0.9 % and +0.7 % (three frames at 16 channels, bit 4: +0); profiles/r04ad_t9_mixq_ab.txt
-    // 5 frames, 32 channels: 3 + 2 (4 units) instead of 2 + 2 + 1 (6 units): +1.3 % (bit 5).  The same sweep (-DMCD_QC16/32/64, profiles/
-    // r04ae_qc_sweep_ab.txt) found nothing at 6 frames / 32 channels as 3 + 3 (+0.1 %), and fewer, larger units at 16 channels slower:
-    // 7 / 8 frames in pairs -1.3 / -2.3 %, 12 frames in triples -0.5 %
-#ifndef MCD_MIXQX
-#define MCD_MIXQX 45
-#endif
+    // Measured exceptions to the rule below (one chain per workgroup, 8 waves), all of one kind: a stage lasts as long as its busiest
+    // wave's units, so unit counts just above the wave count waste a round ("rounds of units"):
+    //   10 / 11 frames, 32 channels: 3 + 3 + 3 + 1 / 3 + 3 + 3 + 2 (8 units, ONE round) instead of 10 / 12 two-frame units: +0.6 / +2.3 %
+    //     (profiles/r04ab_mixqx_ab.txt; 11 frames at 64 channels as 6 + 5 instead of 4 + 4 + 3: 16 spilled registers, -0.2 %, not taken)
+    //   9 frames: the rule picked ONE frame per unit at 32 and 16 channels (18 units = three rounds, 9 units = a second round for one
+    //     unit); 3 per unit at 32 channels (6 units) and 2 at 16 channels (2 + 2 + 2 + 2 + 1) are one round each: +0.9 % and +0.7 %
+    //     (3 per unit at 16 channels: +0; profiles/r04ad_t9_mixq_ab.txt)
+    //   5 frames, 32 channels: 3 + 2 (4 units) instead of 2 + 2 + 1 (6 units): +1.3 %
+    // and where the lever ends (-DMCD_QC16/32/64 sweep, profiles/r04ae_qc_sweep_ab.txt): 6 frames / 32 channels as 3 + 3: +0.1 %; fewer,
+    // larger units at 16 channels are slower (7 / 8 frames in pairs -1.3 / -2.3 %, 12 frames in triples -0.5 %)
+    static constexpr int measured_qc() {
+        if (NB != 1 || NWAVES != 8) return 0;
+        if (CIN == 32 && (T == 5 || T == 9 || T == 10 || T == 11)) return 3;
+        if (CIN == 16 && T == 9) return 2;
+        return 0;
+    }
     // (tuning builds: -DMCD_QC16= / -DMCD_QC32= / -DMCD_QC64= force the frames per unit of the 16- / 32- / 64-channel mixes)
 #ifndef MCD_QC16
 #define MCD_QC16 0
@@ -515,9 +519,7 @@ struct MixCfg {
 #define MCD_QC64 0
 #endif
     static constexpr int QF = CIN == 16 ? MCD_QC16 : CIN == 32 ? MCD_QC32 : CIN == 64 ? MCD_QC64 : 0;
-    static constexpr int QX = QF > 0 ? QF : NB != 1 || NWAVES != 8 ? 0 : ((MCD_MIXQX & 2) && T == 11 && CIN == 64) ? 6 : ((MCD_MIXQX & 1) && (T == 11 || T == 10) && CIN == 32) ? 3
-                              : ((MCD_MIXQX & 4) && T == 9 && CIN == 32) ? 3 : ((MCD_MIXQX & 8) && T == 9 && CIN == 16) ? 2 : ((MCD_MIXQX & 16) && T == 9 && CIN == 16) ? 3
-                              : ((MCD_MIXQX & 32) && T == 5 && CIN == 32) ? 3 : 0;
+    static constexpr int QX = QF > 0 ? QF : measured_qc();
     static constexpr int QC = QX > 0 ? QX : (Q6 > 1 && units_of(Q6) >= NWAVES) ? Q6 : (Q5 > 1 && units_of(Q5) >= NWAVES) ? Q5
                             : (Q4 > 1 && units_of(Q4) >= NWAVES) ? Q4 : units_of(QALL) >= NWAVES ? QALL : units_of(Q2) >= NWAVES ? Q2
                             : 2 * units_of(QALL) > NWAVES ? QALL : 2 * units_of(Q2) > NWAVES ? Q2 : 1;
@@ -530,10 +532,9 @@ struct MixCfg {
     // 12 single-frame units on 8 waves (the 32-channel layers at T = 3, NB = 2): four waves take two units.  SAMEQ gives
     // those waves two units of the SAME output frame -- waves 0-3: frame w/2, groups 2(w&1) + round; waves 4-7: frame 2,
     // group w-4 -- so the coefficients (which depend on the frame only) serve both rounds and nothing is fetched mid-stage
-#ifndef MCD_SAMEQX
-#define MCD_SAMEQX 1
-#endif
-    static constexpr bool SAMEQ = (QC == 1 || MCD_SAMEQX) && NQ == 3 && UNITS == 12 && NWAVES == 8;
+    // (round 4: the same map at 9 / 11 frames and 64 channels -- 3 chunks x 4 blocks -- +0.8 / +1.1 % and 18 / 24 registers less,
+    // profiles/r04ac_sameqx_ab.txt)
+    static constexpr bool SAMEQ = NQ == 3 && UNITS == 12 && NWAVES == 8;
     // a stage lasts as long as its busiest wave's units: a partial extra round (9 units on 8 waves) costs a whole one.  Every
     // instantiated shape is either one round, full rounds, or the SAMEQ pair map -- a new shape that is not has to pick its QC here
     static_assert(T > 12 || PER == 1 || UNITS % NWAVES == 0 || SAMEQ, "mix units: a partial round of units (see MixCfg::QX)");     // (T > 12: the condition encoders of 13 .. 20 frames, < 1 % of a step)
