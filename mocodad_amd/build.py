@@ -31,6 +31,21 @@ def n_units() -> int:
     return int(re.search(r"#define\s+MCD_INST_UNITS\s+(\d+)", txt).group(1))
 
 
+def unit_flags() -> dict:
+    """Per-unit extra compile flags: `#define MCD_UNIT_FLAGS_<n> "..."` lines of csrc/mcd_instances.hpp."""
+    txt = open(os.path.join(CSRC, "mcd_instances.hpp")).read()
+    return {int(u): f.split() for u, f in re.findall(r'#define\s+MCD_UNIT_FLAGS_(\d+)\s+"([^"]*)"', txt)}
+
+
+def shipped_shape(t: int):
+    """(unit, NB, MINW) of the shipped score_kernel<T, ...> (the non-layer-test row of MCD_SCORE_INSTANCES), or None."""
+    txt = open(os.path.join(CSRC, "mcd_instances.hpp")).read()
+    for u, tt, nb, minw in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*false\)", txt.split("MCD_SCORE_INSTANCES(X)")[1].split("MCD_COND_FAST_INSTANCES")[0]):
+        if int(tt) == t:
+            return int(u), int(nb), int(minw)
+    return None
+
+
 def sources() -> List[str]:
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [HEADER]
 
@@ -59,7 +74,8 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
     fast = any(d.split("=")[0] == "MCD_FAST_T" for d in defines)
     units = [1] if fast else list(range(1, n_units() + 1))
     jobs_l = [("mcd_api.o", os.path.join(CSRC, "mcd_api.hip"), [])]
-    jobs_l += [(f"mcd_inst_{u}.o", os.path.join(CSRC, "mcd_inst.hip"), [f"-DMCD_INST_UNIT={u}"]) for u in units]
+    uf = {} if fast else unit_flags()      # (developer builds take their flags from the command line / main())
+    jobs_l += [(f"mcd_inst_{u}.o", os.path.join(CSRC, "mcd_inst.hip"), [f"-DMCD_INST_UNIT={u}"] + uf.get(u, [])) for u in units]
     todo = [(o, s, f) for o, s, f in jobs_l
             if force or not os.path.exists(os.path.join(obj_dir, o)) or os.path.getmtime(os.path.join(obj_dir, o)) < newest(s)]
     t0 = time.perf_counter()
@@ -98,6 +114,18 @@ def main() -> None:
         defs.append("MCD_PROFILE")
     if a.fast_t is not None:
         defs.append(f"MCD_FAST_T={a.fast_t}")
+        # the shipped shape of that frame count (chains per workgroup, waves per SIMD, its unit's flags) unless given
+        sh = shipped_shape(a.fast_t)
+        given = {d.split("=")[0] for d in defs}
+        if sh:
+            unit, nb, minw = sh
+            for fl in unit_flags().get(unit, []):
+                if fl.startswith("-D") and fl[2:].split("=")[0] not in given:
+                    defs.append(fl[2:])
+            if "MCD_FAST_NB" not in given:
+                defs.append(f"MCD_FAST_NB={nb}")
+            if "MCD_FAST_MINW" not in given and not any(d.split("=")[0] == "MCD_NWAVES" for d in a.defines):
+                defs.append(f"MCD_FAST_MINW={minw}")
     out = a.out or (os.path.join(HERE, "libmocodad_hip_prof.so") if a.profile else DEFAULT_OUT)
     build_library(out, defs, force=a.force, jobs=a.jobs)
 

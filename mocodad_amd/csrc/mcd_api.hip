@@ -785,7 +785,7 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
     switch (T) {
         case 3: return launch_score_t<3, 2, 4>(P, st, fused);                 // 2 chains / WG, 2 WGs per CU (<= 128 VGPRs)
         case 6: return launch_score_t<6, 1, 4>(P, st, fused);                 // 1 chain / WG, 2 WGs per CU
-        case 12: return launch_score_t<12, 1, 2>(P, st, fused);               // 1 chain / WG, 1 WG per CU (no register cap)
+        case 12: return launch_score_t<12, 1, 3>(P, st, fused);               // 1 chain / WG of 12 waves, 1 WG per CU (168 registers; mcd_instances.hpp)
         case 4: return launch_score_t<4, 1, 4>(P, st, fused);                 // e.g. seg_len 8 split in halves
         case 5: return launch_score_t<5, 1, 4>(P, st, fused);                 // e.g. seg_len 10 split in halves (1 chain / WG, 2 WGs per CU: +4.7 % over <5,2,2>, profiles/r04r_t5_shape_ab.txt)
         case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames

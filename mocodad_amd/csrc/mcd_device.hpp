@@ -503,6 +503,9 @@ struct MixCfg {
     // and where the lever ends (-DMCD_QC16/32/64 sweep, profiles/r04ae_qc_sweep_ab.txt): 6 frames / 32 channels as 3 + 3: +0.1 %; fewer,
     // larger units at 16 channels are slower (7 / 8 frames in pairs -1.3 / -2.3 %, 12 frames in triples -0.5 %)
     static constexpr int measured_qc() {
+        // 12 waves per workgroup (the 12-frame kernel, mcd_instances.hpp): 12 units per stage where the frame count allows --
+        // 4 (3 below 10 frames) / 2 / 1 frames per unit at 64 / 32 / 16 channels
+        if (NB == 1 && NWAVES == 12 && T >= 7) return CIN >= 64 ? (T >= 10 ? 4 : 3) : CIN == 32 ? 2 : 1;
         if (NB != 1 || NWAVES != 8) return 0;
         if (CIN == 32 && (T == 5 || T == 9 || T == 10 || T == 11)) return 3;
         if (CIN == 16 && T == 9) return 2;
@@ -905,6 +908,7 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
     constexpr int NG = Tiling<MT, NT>::NG;
     constexpr int MAXN = Tiling<MT, NT>::MAXN;
     const int mt = (wave + mi * NWAVES) % MT, ng = MT > NWAVES ? 0 : wave / MT;
+    if (NWAVES % MT != 0 && MT <= NWAVES && ng >= NG) return;     // (wave counts no m-tile count divides: the waves past NG x MT have no tile)
     const int j = lane & 15, g = lane >> 4;
     const int c0 = mt * 16 + 4 * g;
     // per-lane bases of this wave's FIRST tile, once per call; tile i sits at the compile-time offset i * NG * 16 * stride
@@ -917,7 +921,7 @@ __device__ __forceinline__ void gemm_tiles(const float4 (&a)[KQ1 + KQ2], const f
 #define MCD_PIPE_DEPTH 1
 #endif
 #ifndef MCD_PIPE_SEED
-#define MCD_PIPE_SEED 0
+#define MCD_PIPE_SEED (MCD_NWAVES == 12)      // (12 waves, 168 registers: the seeds with the read-ahead, 16 spilled registers less: +2 % there; 8 waves: -0.4 %)
 #endif
     constexpr int DEPTH0 = KQ < 3 ? KQ : 3;
     // one 16x16 output tile: B fragments (one ds_read_b128 = 4 k-steps) fetched DEPTH0 reads ahead of the MFMAs that consume

@@ -111,7 +111,12 @@
 #else
 #define MCD_U21(...)
 #endif
-#if MCD_INST_UNITS != 21
+#if MCD_UNIT_IS(22)
+#define MCD_U22(...) __VA_ARGS__
+#else
+#define MCD_U22(...)
+#endif
+#if MCD_INST_UNITS != 22
 #error "add the MCD_U<n> selectors of the new units"
 #endif
 

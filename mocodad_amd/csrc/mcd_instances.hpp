@@ -10,7 +10,13 @@
 //   X(unit, TP, NB)              score_tiled_kernel<TP, NB, false, true>: the 'E_unet' condition encoder at 13 .. 32 condition frames
 #pragma once
 
-#define MCD_INST_UNITS 21
+#define MCD_INST_UNITS 22
+
+// Per-unit compile flags (mocodad_amd/build.py reads these lines).  The wave count of a workgroup is a translation-unit constant
+// (MCD_NWAVES): unit 3 holds ONLY the 12-frame trajectory kernel and builds it with twelve waves per workgroup -- three per SIMD,
+// 168 registers, 12 mix units per stage, n-thirds in the 64-channel GEMMs: +2.6 % over eight waves (profiles/r04ak_t12_w12_ab.txt).
+// Its launcher (the same translation unit) launches 768 threads; nothing outside the unit depends on the wave count.
+#define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12"
 
 #ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only
 #define MCD_SCORE_VARIANT_INSTANCES(X) X(1, 3, 4, 2, false) X(1, 3, 1, 4, false) X(1, 3, 2, 2, false) X(2, 6, 2, 2, false)
@@ -23,8 +29,8 @@
     X(1, 1, 4, 4, false) X(1, 2, 2, 4, false) \
     X(2, 6, 1, 4, false)  /* concat over 6 frames */ \
     X(2, 4, 1, 4, false) \
-    X(3, 12, 1, 2, false) /* seg_len 24 split in halves: 1 workgroup per CU, no register cap */ \
-    X(3, 8, 1, 2, false) \
+    X(3, 12, 1, 3, false) /* seg_len 24 split in halves: 1 workgroup of TWELVE waves per CU (unit 3 is compiled with MCD_UNIT_FLAGS_3), 168 registers */ \
+    X(22, 8, 1, 2, false) \
     X(4, 5, 1, 4, false) X(4, 10, 1, 2, false) X(4, 7, 1, 2, false) \
     X(5, 9, 1, 2, false) X(5, 11, 1, 2, false) \
     X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \

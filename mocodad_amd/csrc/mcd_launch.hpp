@@ -68,13 +68,13 @@ inline int ensure_lds_limit(const void* fn, size_t bytes, std::atomic<unsigned l
     int rc_ = ensure_lds_limit(reinterpret_cast<const void*>(kernel_expr), (bytes), done_); if (rc_ != MCD_OK) return rc_; } while (0)
 
 // Workgroup slots of the device for a kernel (resident workgroups per CU x CUs), asked once per (kernel, device).
-inline int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64]) {
+inline int wg_slots(const void* fn, size_t lds, std::atomic<int> (&cache)[64], int threads) {      // (threads: the caller's NTHREADS -- a translation-unit constant)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
     int v = cache[dev].load(std::memory_order_relaxed);
     if (v > 0) return v;
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NTHREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     v = per_cu * cus;
     cache[dev].store(v, std::memory_order_relaxed);
@@ -101,7 +101,7 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
     LDS_LIMIT((&score_kernel<T, NB, MINW, LT>), PL::BYTES);
     static std::atomic<int> slots_cache[64];
     const int groups = (P.B + NB - 1) / NB;
-    const int slots = wg_slots(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW, LT>), PL::BYTES, slots_cache);
+    const int slots = wg_slots(reinterpret_cast<const void*>(&score_kernel<T, NB, MINW, LT>), PL::BYTES, slots_cache, NTHREADS);
     if (P.plan_only || P.mode != 0) {
         P.split = P.mode == 0 ? choose_split(groups, P.S, slots) : 1;
         if (P.mode == 0 && P.force_split > 0) P.split = P.force_split < P.S ? P.force_split : P.S;
@@ -189,7 +189,7 @@ int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const Frame
 #define MCD_FAST_NB (MCD_FAST_T == 3 ? 2 : 1)
 #endif
 #ifndef MCD_FAST_MINW
-#define MCD_FAST_MINW (MCD_FAST_T >= 7 ? 2 : 4)
+#define MCD_FAST_MINW (MCD_NWAVES == 12 ? 3 : MCD_FAST_T >= 7 ? 2 : 4)
 #endif
 #endif
 
