@@ -791,8 +791,8 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
         case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
         case 10: return launch_score_t<10, 1, 2>(P, st, fused);               // e.g. seg_len 20 split in halves / seg_len 10 concat
         case 7: return launch_score_t<7, 1, 2>(P, st, fused);                 // odd frame counts: one output frame per mix unit
-        case 9: return launch_score_t<9, 1, 2>(P, st, fused);
-        case 11: return launch_score_t<11, 1, 2>(P, st, fused);
+        case 9: return launch_score_t<9, 1, 3>(P, st, fused);                 // (12 waves, like 12 frames)
+        case 11: return launch_score_t<11, 1, 3>(P, st, fused);
         case 1: return launch_score_t<1, 4, 4>(P, st, fused);                 // (4 chains / WG, 2 WGs per CU)
         case 2: return launch_score_t<2, 2, 4>(P, st, fused);                 // e.g. seg_len 4 split in halves (2 chains / WG, 2 WGs per CU: every mix is one round of units; +31 % over <2,3,4>, profiles/r04aa_t2_nb_ab.txt)
         default: return fail(MCD_EUNSUPPORTED, "U-Net frame count " + std::to_string(T) + " not instantiated (supported: 1 .. 12)");
