@@ -519,7 +519,7 @@ def main():
         flop_per_window = P * f_unet(sc.t_unet) + (f_cond(sc.t_cond) if strat == "inject" else 0)
         achieved = B * flop_per_window / (kern_ms * 1e-3) / 1e12
         pmc = pmc_profile(args.config, B, ns, S, flop_per_window, kern_ms, sc.t_unet)
-        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,3", 4: "4,1,4", 8: "8,1,2", 5: "5,1,4", 10: "10,1,2", 7: "7,1,2", 9: "9,1,3", 11: "11,1,3", 1: "1,4,4", 2: "2,2,4"}.get(sc.t_unet)
+        nb = {3: "3,2,4", 6: "6,1,4", 12: "12,1,3", 4: "4,1,4", 8: "8,1,2", 5: "5,1,4", 10: "10,1,3", 7: "7,1,2", 9: "9,1,3", 11: "11,1,3", 1: "1,4,4", 2: "2,2,4"}.get(sc.t_unet)
         tiled = nb is None         # 13 .. 32 U-Net frames: the slab-tiled kernel, frame count padded to 16 (two workgroups per CU) / 24 / 32
         tp_of = lambda t: 16 if t <= 16 else 24 if t <= 24 else 32
         kname = f"score_kernel<{nb}>" if nb else "score_tiled_kernel<%d,1> (T_u=%d)" % (tp_of(sc.t_unet), sc.t_unet)

@@ -789,7 +789,7 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
         case 4: return launch_score_t<4, 1, 4>(P, st, fused);                 // e.g. seg_len 8 split in halves
         case 5: return launch_score_t<5, 1, 4>(P, st, fused);                 // e.g. seg_len 10 split in halves (1 chain / WG, 2 WGs per CU: +4.7 % over <5,2,2>, profiles/r04r_t5_shape_ab.txt)
         case 8: return launch_score_t<8, 1, 2>(P, st, fused);                 // e.g. seg_len 8 concat / seg_len 12 with 4 condition frames
-        case 10: return launch_score_t<10, 1, 2>(P, st, fused);               // e.g. seg_len 20 split in halves / seg_len 10 concat
+        case 10: return launch_score_t<10, 1, 3>(P, st, fused);               // e.g. seg_len 20 split in halves / seg_len 10 concat
         case 7: return launch_score_t<7, 1, 2>(P, st, fused);                 // odd frame counts: one output frame per mix unit
         case 9: return launch_score_t<9, 1, 3>(P, st, fused);                 // (12 waves, like 12 frames)
         case 11: return launch_score_t<11, 1, 3>(P, st, fused);

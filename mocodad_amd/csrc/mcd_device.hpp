@@ -504,8 +504,8 @@ struct MixCfg {
     // larger units at 16 channels are slower (7 / 8 frames in pairs -1.3 / -2.3 %, 12 frames in triples -0.5 %)
     static constexpr int measured_qc() {
         // 12 waves per workgroup (the 12-frame kernel, mcd_instances.hpp): 12 units per stage where the frame count allows --
-        // 4 (3 below 10 frames) / 2 / 1 frames per unit at 64 / 32 / 16 channels
-        if (NB == 1 && NWAVES == 12 && T >= 7) return CIN >= 64 ? (T >= 10 ? 4 : 3) : CIN == 32 ? 2 : 1;
+        // 4 (3 below 10 frames) / 2 / 1 frames per unit at 64 / 32 / 16 channels; 10 frames at 64 channels in halves (8 units: +2.7 % over 4 + 4 + 2)
+        if (NB == 1 && NWAVES == 12 && T >= 7) return CIN >= 64 ? (T == 10 && CIN == 64 ? 5 : T >= 10 ? 4 : 3) : CIN == 32 ? 2 : 1;
         if (NB != 1 || NWAVES != 8) return 0;
         if (CIN == 32 && (T == 5 || T == 9 || T == 10 || T == 11)) return 3;
         if (CIN == 16 && T == 9) return 2;

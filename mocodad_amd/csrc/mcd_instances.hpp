@@ -13,11 +13,11 @@
 #define MCD_INST_UNITS 22
 
 // Per-unit compile flags (mocodad_amd/build.py reads these lines).  The wave count of a workgroup is a translation-unit constant
-// (MCD_NWAVES): units 3 and 5 hold ONLY the 12-frame and the 9- / 11-frame trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
+// (MCD_NWAVES): units 3 and 5 hold ONLY the 12-frame and the 9- / 10- / 11-frame trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
 // 168 registers, 12 mix units per stage, n-thirds in the 64-channel GEMMs: +2.6 % over eight waves (profiles/r04ak_t12_w12_ab.txt).
 // Its launcher (the same translation unit) launches 768 threads; nothing outside the unit depends on the wave count.
 #define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12"
-#define MCD_UNIT_FLAGS_5 "-DMCD_NWAVES=12"      // 9 and 11 frames (profiles/r04al_w12_shapes_ab.txt)
+#define MCD_UNIT_FLAGS_5 "-DMCD_NWAVES=12"      // 9, 10 and 11 frames (profiles/r04al_w12_shapes_ab.txt, r04an_t10_w12_ab.txt)
 
 #ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only
 #define MCD_SCORE_VARIANT_INSTANCES(X) X(1, 3, 4, 2, false) X(1, 3, 1, 4, false) X(1, 3, 2, 2, false) X(2, 6, 2, 2, false)
@@ -32,8 +32,8 @@
     X(2, 4, 1, 4, false) \
     X(3, 12, 1, 3, false) /* seg_len 24 split in halves: 1 workgroup of TWELVE waves per CU (unit 3 is compiled with MCD_UNIT_FLAGS_3), 168 registers */ \
     X(22, 8, 1, 2, false) \
-    X(4, 5, 1, 4, false) X(4, 10, 1, 2, false) X(4, 7, 1, 2, false) \
-    X(5, 9, 1, 3, false) X(5, 11, 1, 3, false) /* twelve waves as well (unit 5): +3.7 % / +0.9 %; 8 and 10 frames measured +0.2 % / -1.8 %: eight waves */ \
+    X(4, 5, 1, 4, false) X(4, 7, 1, 2, false) \
+    X(5, 9, 1, 3, false) X(5, 10, 1, 3, false) X(5, 11, 1, 3, false) /* twelve waves as well (unit 5): +3.7 / +0.9 / +0.9 %; 7 and 8 frames measured -1 % / +0.2 %: eight waves */ \
     X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \
     X(13, 5, 1, 4, true) X(13, 7, 1, 2, true) X(13, 10, 1, 2, true) \
     MCD_SCORE_VARIANT_INSTANCES(X)
