@@ -56,9 +56,9 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/profile_set.sh): per-launch counter averages
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
-PMC_PROFILES = {"avenue": ("profiles/r04z_avenue_pmc.txt", 1024, 10, 5), "stc": ("profiles/r04z_avenue_pmc.txt", 1024, 10, 5),      # (stc: the same kernel, 2048 windows -- scaled)
-                "ubnormal_concat": ("profiles/r04z_ubnormal_concat_pmc.txt", 1024, 10, 5),
-                "seq24": ("profiles/r04z_seq24_pmc.txt", 1024, 50, 8), "concat32": ("profiles/r04z_concat32_pmc.txt", 1024, 10, 5)}
+PMC_PROFILES = {"avenue": ("profiles/r04zy_avenue_pmc.txt", 1024, 10, 5), "stc": ("profiles/r04zy_avenue_pmc.txt", 1024, 10, 5),      # (stc: the same kernel, 2048 windows -- scaled)
+                "ubnormal_concat": ("profiles/r04zy_ubnormal_concat_pmc.txt", 1024, 10, 5),
+                "seq24": ("profiles/r04zy_seq24_pmc.txt", 1024, 50, 8), "concat32": ("profiles/r04zy_concat32_pmc.txt", 1024, 10, 5)}
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
 
 

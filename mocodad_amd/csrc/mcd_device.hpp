@@ -1173,7 +1173,10 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
         // latency hides behind the mix as well)
         bcur = load_global4(bias + (wave % MT) * 16 + 4 * (lane >> 4));
     }
-    mix_stage<CIN, V, T, NB, FORCE>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
+#ifndef MCD_MIX_FORCE
+#define MCD_MIX_FORCE 1
+#endif
+    mix_stage<CIN, V, T, NB, (FORCE && MCD_MIX_FORCE)>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
                              [&](int n, int q, int w0, int c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the

@@ -11,6 +11,9 @@
 #ifndef MCD_NO_EARLY2
 #define MCD_NO_EARLY2 0
 #endif
+#ifndef MCD_RS_ILP
+#define MCD_RS_ILP 1
+#endif
 
 namespace mcd {
 
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(2, RG + PL::L2_out, 36, 32, 17);
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
         if constexpr (!EARLY2) mix_early(mc3, 3);
-        resample_stage<32, 17, 12, T, NB, true, false, (MINW <= MCD_LOWOCC)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
+        resample_stage<32, 17, 12, T, NB, true, false, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         if constexpr (STASH1) {
             priv_float* sp = (priv_float*)stash1_mem;
             asm volatile("" : "+v"(sp));
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(4, RG + PL::L4_out, 68, 64, 12);
         lt_inject(12, RG + PL::L4_out, 68, 64, 12);
         if constexpr (!EARLY2) mix_early(mc5, 5);
-        resample_stage<64, 12, 10, T, NB, true, false, (MINW <= MCD_LOWOCC)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
+        resample_stage<64, 12, 10, T, NB, true, false, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         if constexpr (STASH2) {
             priv_float* sp = (priv_float*)stash2_mem;
             asm volatile("" : "+v"(sp));            // opaque: the array stays in memory, plain (cached) scratch accesses
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         // ---- up path
         if constexpr (!EARLY2) mix_early(mc7, 7);
-        resample_stage<64, 10, 12, T, NB, false, true, (MINW <= MCD_LOWOCC)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
+        resample_stage<64, 10, 12, T, NB, false, true, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         wearly(A7, MCD_LC(7));
         bsync();
         STAGE(12);
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
         if constexpr (!EARLY2) mix_early(mc9, 9);
-        resample_stage<32, 12, 17, T, NB, false, true, (MINW <= MCD_LOWOCC)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+        resample_stage<32, 12, 17, T, NB, false, true, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         wearly(A9, MCD_LC(9));
         bsync();
         STAGE(15);
