@@ -13,10 +13,12 @@
 #define MCD_INST_UNITS 22
 
 // Per-unit compile flags (mocodad_amd/build.py reads these lines).  The wave count of a workgroup is a translation-unit constant
-// (MCD_NWAVES): units 3 and 5 hold ONLY the 12-frame and the 9- / 10- / 11-frame trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
+// (MCD_NWAVES): units 3, 5, 11 and 12 hold ONLY the 12-frame, the 9- / 10- / 11-frame and the 24- / 32-frame (slab-tiled) trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
 // 168 registers, 12 mix units per stage, n-thirds in the 64-channel GEMMs: +2.6 % over eight waves (profiles/r04ak_t12_w12_ab.txt).
 // Its launcher (the same translation unit) launches 768 threads; nothing outside the unit depends on the wave count.
 #define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12"
+#define MCD_UNIT_FLAGS_11 "-DMCD_NWAVES=12"     // the slab-tiled kernel at 24 frames: +4.5 % (profiles/r04aq_tiled_w12_ab.txt)
+#define MCD_UNIT_FLAGS_12 "-DMCD_NWAVES=12"     // ... and at 32 frames: +2.0 %
 #define MCD_UNIT_FLAGS_5 "-DMCD_NWAVES=12"      // 9, 10 and 11 frames (profiles/r04al_w12_shapes_ab.txt, r04an_t10_w12_ab.txt)
 
 #ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only

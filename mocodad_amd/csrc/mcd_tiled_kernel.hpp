@@ -375,7 +375,7 @@ template <int MT, int NT, int KQ1, int KQ2, int O1, int O2, int NA>
 __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __restrict__ b1, int cs1, const float* __restrict__ b2,
                                           int cs2, int wave, int lane, f32x4 (&acc)[Tiling<MT, NT>::MAXN]) {
     constexpr int NG = Tiling<MT, NT>::NG, MAXN = Tiling<MT, NT>::MAXN, KQ = KQ1 + KQ2;
-    const int ng = MT > NWAVES ? 0 : wave / MT;
+    const int ng = MT > NWAVES ? 0 : (wave / MT < NG ? wave / MT : NT);      // (wave counts that MT does not divide: the waves past NG x MT get no tile)
     const int j = lane & 15, g = lane >> 4;
     const float* const p1b = b1 + __mul24(ng * 16 + j, cs1) + 4 * g;
     const float* const p2b = b2 + __mul24(ng * 16 + j, cs2) + 4 * g;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
                 constexpr bool AQ = NH > 2;
                 constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
-                const int mt = wave % MT, ng = MT > NWAVES ? 0 : wave / MT, c0 = mt * 16 + 4 * (lane >> 4);
+                const int mt = wave % MT, ng = MT > NWAVES ? 0 : (wave / MT < TI::NG ? wave / MT : NT), c0 = mt * 16 + 4 * (lane >> 4);
                 LayerAfr<AQ ? 1 : KQA> A;
                 float4 aq[AQ ? 2 * KH : 1];
                 const float* wfr = wb + Nl->wp[L] + ((size_t)mt * KQA * 64 + lane) * 4;
@@ -1001,7 +1001,9 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             }
             RED[tid] = part;
             __syncthreads();
-            for (int o = NTHREADS / 2; o > 0; o >>= 1) { if (tid < o) RED[tid] += RED[tid + o]; __syncthreads(); }
+            // (tree over the next power of two: a workgroup of 12 waves has 768 threads; at 512 the order is the plain halving)
+            constexpr int RP2 = NTHREADS <= 512 ? 512 : 1024;
+            for (int o = RP2 / 2; o > 0; o >>= 1) { if (tid < o && tid + o < NTHREADS) RED[tid] += RED[tid + o]; __syncthreads(); }
             if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
             __syncthreads();
         }
