@@ -106,6 +106,7 @@ def main() -> None:
     ap.add_argument("-D", dest="defines", action="append", default=[], help="extra macro (NAME or NAME=VALUE)")
     ap.add_argument("--profile", action="store_true", help="-DMCD_PROFILE build (default output: libmocodad_hip_prof.so)")
     ap.add_argument("--fast-t", type=int, default=None, help="developer build holding only score_kernel<T, ...> (+ its encoders)")
+    ap.add_argument("-X", dest="xflags", action="append", default=[], help="extra raw compiler flag (repeatable), e.g. -X=-mllvm -X=-amdgpu-sched-strategy=max-ilp")
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-j", "--jobs", type=int, default=None)
     a = ap.parse_args()
@@ -127,7 +128,7 @@ def main() -> None:
             if "MCD_FAST_MINW" not in given and not any(d.split("=")[0] == "MCD_NWAVES" for d in a.defines):
                 defs.append(f"MCD_FAST_MINW={minw}")
     out = a.out or (os.path.join(HERE, "libmocodad_hip_prof.so") if a.profile else DEFAULT_OUT)
-    build_library(out, defs, force=a.force, jobs=a.jobs)
+    build_library(out, defs, extra_flags=a.xflags, force=a.force, jobs=a.jobs)
 
 
 if __name__ == "__main__":

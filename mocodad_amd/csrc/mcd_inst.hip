@@ -116,7 +116,12 @@
 #else
 #define MCD_U22(...)
 #endif
-#if MCD_INST_UNITS != 22
+#if MCD_UNIT_IS(23)
+#define MCD_U23(...) __VA_ARGS__
+#else
+#define MCD_U23(...)
+#endif
+#if MCD_INST_UNITS != 23
 #error "add the MCD_U<n> selectors of the new units"
 #endif
 

@@ -10,13 +10,14 @@
 //   X(unit, TP, NB)              score_tiled_kernel<TP, NB, false, true>: the 'E_unet' condition encoder at 13 .. 32 condition frames
 #pragma once
 
-#define MCD_INST_UNITS 22
+#define MCD_INST_UNITS 23
 
 // Per-unit compile flags (mocodad_amd/build.py reads these lines).  The wave count of a workgroup is a translation-unit constant
-// (MCD_NWAVES): units 3, 5, 11 and 12 hold ONLY the 12-frame, the 9- / 10- / 11-frame and the 24- / 32-frame (slab-tiled) trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
+// (MCD_NWAVES): units 3, 5, 23, 11 and 12 hold ONLY the 12-frame, the 9- / 10- / 11-frame and the 24- / 32-frame (slab-tiled) trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
 // 168 registers, 12 mix units per stage, n-thirds in the 64-channel GEMMs: +2.6 % over eight waves (profiles/r04ak_t12_w12_ab.txt).
 // Its launcher (the same translation unit) launches 768 threads; nothing outside the unit depends on the wave count.
-#define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12"
+#define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"      // (the scheduler strategy: 25 -> 19 spilled registers, +0.6 %, profiles/r04as_t12_sched_ab.txt)
+#define MCD_UNIT_FLAGS_23 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"     // 9 frames: +1.3 % with it (11 frames -2.4 %, 24 / 32 frames -0.7 / -3.2 %: default strategy, profiles/r04at_minreg_ab.txt)
 #define MCD_UNIT_FLAGS_11 "-DMCD_NWAVES=12"     // the slab-tiled kernel at 24 frames: +4.5 % (profiles/r04aq_tiled_w12_ab.txt)
 #define MCD_UNIT_FLAGS_12 "-DMCD_NWAVES=12"     // ... and at 32 frames: +2.0 %
 #define MCD_UNIT_FLAGS_5 "-DMCD_NWAVES=12"      // 9, 10 and 11 frames (profiles/r04al_w12_shapes_ab.txt, r04an_t10_w12_ab.txt)
@@ -35,7 +36,7 @@
     X(3, 12, 1, 3, false) /* seg_len 24 split in halves: 1 workgroup of TWELVE waves per CU (unit 3 is compiled with MCD_UNIT_FLAGS_3), 168 registers */ \
     X(22, 8, 1, 2, false) \
     X(4, 5, 1, 4, false) X(4, 7, 1, 2, false) \
-    X(5, 9, 1, 3, false) X(5, 10, 1, 3, false) X(5, 11, 1, 3, false) /* twelve waves as well (unit 5): +3.7 / +0.9 / +0.9 %; 7 and 8 frames measured -1 % / +0.2 %: eight waves */ \
+    X(23, 9, 1, 3, false) X(5, 10, 1, 3, false) X(5, 11, 1, 3, false) /* twelve waves as well (unit 5): +3.7 / +0.9 / +0.9 %; 7 and 8 frames measured -1 % / +0.2 %: eight waves */ \
     X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \
     X(13, 5, 1, 4, true) X(13, 7, 1, 2, true) X(13, 10, 1, 2, true) \
     MCD_SCORE_VARIANT_INSTANCES(X)
