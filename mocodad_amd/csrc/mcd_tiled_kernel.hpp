@@ -269,19 +269,29 @@ __device__ __forceinline__ void tl_time_mix(const float* __restrict__ X, int cs,
         for (int cb = 0; cb < CB; ++cb) acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(first[ks], b0[cb][ks], acc0[cb], 0, 0, 0);
     write_y(0, u0, acc0);
     if constexpr (PER > 1) {
-        f32x4 accr[NR][CB];
+        // the wave's later units, their MFMA chains interleaved.  Only the LAST round can lie past the end (a wave-uniform test):
+        // such a wave used to recompute the last unit unstored -- free on 8 waves' idle SIMD slots, but with 12 waves per workgroup
+        // those MFMAs (7 of 24 slots at 17 joints) take the matrix pipe from the SIMD's other two waves
+        auto later = [&](auto nn) {
+            constexpr int N = decltype(nn)::value;
+            if constexpr (N > 0) {
+                f32x4 accr[N][CB];
 #pragma unroll
-        for (int i = 0; i < PER - 1; ++i)
+                for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) accr[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int cb = 0; cb < CB; ++cb) accr[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks)
+                for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-            for (int i = 0; i < PER - 1; ++i)
+                    for (int i = 0; i < N; ++i)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) accr[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i][ks], br[i][cb][ks], accr[i][cb], 0, 0, 0);
+                        for (int cb = 0; cb < CB; ++cb) accr[i][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[i][ks], br[i][cb][ks], accr[i][cb], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < PER - 1; ++i) write_y(i + 1, ur[i], accr[i]);
+                for (int i = 0; i < N; ++i) write_y(i + 1, ur[i], accr[i]);
+            }
+        };
+        if (UNITS % NWAVES == 0 || wave + (PER - 1) * NWAVES < UNITS) later(std::integral_constant<int, PER - 1>{});
+        else later(std::integral_constant<int, PER - 2>{});
     }
 }
 template <int V, int TP, int NB, int NGRP>
@@ -363,8 +373,12 @@ __device__ __forceinline__ void tl_joint_mix(float* __restrict__ YZ, int cs, con
         }
     };
     const float (&f1)[1][MT][KS] = reinterpret_cast<const float (&)[1][MT][KS]>(first);
-    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f1);
-    if constexpr (PER > 1) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 1>{}, ar);
+    // (a wave whose round lies past the end of the units skips it -- see tl_time_mix)
+    if (UNITS >= NWAVES || wave < UNITS) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, f1);
+    if constexpr (PER > 1) {
+        if (UNITS % NWAVES == 0 || wave + (PER - 1) * NWAVES < UNITS) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 1>{}, ar);
+        else if constexpr (PER > 2) run(std::integral_constant<int, 1>{}, std::integral_constant<int, PER - 2>{}, ar);
+    }
 }
 
 // partial channel GEMM of a layer of the slab-tiled kernel: acc[i] += A[O1 ..] . B1 (+ A[O2 ..] . B2) over this wave's n-tiles
