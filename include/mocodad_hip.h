@@ -107,7 +107,8 @@ int mcd_cond_encode(const mcd_weights_t* w, const float* cond_data, int32_t n_wi
 int64_t mcd_pass_workspace_bytes(const mcd_weights_t* w, int32_t n_windows);
 
 /* Replaces: STSAE_Unet.forward (stsae_unet.py:406-438) for one timestep shared by the batch.
- * x (B,C,t_unet,V), step_table row `t` (see mcd_score), cond (B,emb_dim) or NULL -> eps_out (B,C,t_unet,V).
+ * x (B,C,t_unet,V), step_table row `t` (see mcd_score; t >= 0, the table must hold at least t + 1 rows -- a negative t is
+ * MCD_EINVAL), cond (B,emb_dim) or NULL -> eps_out (B,C,t_unet,V).
  * Runs the production kernel of the frame count in single-pass mode: score_kernel<T_u,...> (1 .. 12 frames) or
  * score_tiled_kernel (13 .. 32; workspace = mcd_pass_workspace_bytes, else may be NULL). */
 int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, const float* step_table,
@@ -118,7 +119,8 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
  * sd2.0, sd2.1, sd3.0, sd3.1, su4.0, su4.1, su3.0, su3.1), 11..14 = CNN_layer over the joint axis as called at
  * stsae_unet.py:205,213,381,391 (down1, down2, up3, up2; without the skip add).
  * x (B,Cin,t_unet,Vin), emb (B,emb_dim) = the layer's `t` argument (the layer adds Linear(SiLU(emb)); required),
- * out (B,Cout,t_unet,Vout).  Instantiated for 3, 5, 6, 7, 10, 12 U-Net frames (score_kernel's LDS plan) and for 13 .. 32
+ * out (B,Cout,t_unet,Vout).  Instantiated for 3, 5, 6, 7, 9, 10, 11, 12 U-Net frames (score_kernel's LDS plan; each with the
+ * template arguments and compile flags of the production kernel of that frame count -- twelve waves at 9 .. 12) and for 13 .. 32
  * (score_tiled_kernel: the stage's input is put where the previous layer's epilogue leaves it -- slab and LDS hand-over
  * regions -- and its output read from where its own epilogue puts it; workspace = mcd_pass_workspace_bytes).  In the slab-tiled
  * kernel the joint resamplers are not stages of their own: stages 3, 5, 7, 9 are (down1 | down2 | up3 | up2) + the layer, x is
@@ -208,14 +210,18 @@ int mcd_score_view(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const flo
  * MEDIAN / QUANTILE) in ONE call -- and, whenever the workgroups own whole windows, in ONE kernel launch: the condition
  * encoder runs in the workgroup that owns the window, the per-sample losses stay in its LDS, loss_agg (B,) is all that
  * is written.  loss_all (B,S) and pose_out are optional extra outputs (NULL = not wanted).  The *_pose strategies need the
- * generated poses of all samples: mcd_score + mcd_aggregate. */
+ * generated poses of all samples: mcd_score + mcd_aggregate.  Any n_samples >= 1 (the reference's shipped test configs use
+ * 50, config/<dataset>/mocodad_test.yaml): a workgroup keeps up to 64 per-sample losses of a window in LDS; with more samples the
+ * per-sample losses go through the workspace and the aggregation runs as its own launch (as for mcd_plan_split() != 1). */
 int mcd_score_fused(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const mcd_window_view_t* view,
                     const float* noise, uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
                     int32_t aggregation, float quantile, float* loss_agg, float* loss_all, float* pose_out, void* stream);
 
 /* Replaces: MoCoDAD._aggregation_strategy (mocodad.py:454-520) on the (B,S) losses / (B,S,C,Tx,V) poses.
  * data/cfg give the ground-truth corrupt frames for the *_pose strategies.  loss_agg (B,), pose_agg
- * NULL or (B,C,Tx,V).  MCD_AGGR_ALL is the identity and is not handled here. */
+ * NULL or (B,C,Tx,V).  MCD_AGGR_ALL is the identity and is not handled here.  Any n_samples >= 1, like the reference: one
+ * wave per window, order statistics (median = torch's lower middle value, quantile = torch's linear interpolation) by rank
+ * counting over the samples, best / worst with the reference's strict comparisons (the first of equal samples is kept). */
 int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_joints, int32_t strategy, float quantile,
                   const float* loss_all, const float* pose_all, const float* data, float* loss_agg,
                   float* pose_agg, void* stream);

@@ -95,6 +95,16 @@ def lib():
             L = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        # a stale library (the .so is git-ignored but travels with the tree) would silently misroute options and arguments:
+        # check the ABI before binding anything else
+        try:
+            L.mcd_abi_version.restype = C.c_int32
+            have = int(L.mcd_abi_version())
+        except AttributeError:
+            have = -1
+        if have != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {have}, this package needs {ABI_VERSION}: rebuild it with "
+                               "`python -m mocodad_amd.build` (or __graft_entry__.build())")
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype = res

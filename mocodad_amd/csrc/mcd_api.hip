@@ -151,79 +151,105 @@ __global__ __launch_bounds__(CE_THREADS) void cond_encode_kernel(const CondW W, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// aggregation over the S samples (mocodad.py:454-520); one thread per window, S <= 64
+// aggregation over the S samples (mocodad.py:454-520); one 64-lane wave per window, ANY S (the reference's shipped
+// n_generated_samples is 50, config/*/mocodad_test.yaml; its _aggregation_strategy has no cap)
 // ------------------------------------------------------------------------------------------------
 struct AggrParams {
     const float* loss_all; const float* pose_all; const float* data; float* loss_agg; float* pose_agg;
-    int B, S, C, Tx, V, seg_len, strategy, loss_fn;
+    int B, S, C, Tx, V, seg_len, strategy, loss_fn, in_lds;
     float q;
     int corrupt_idx[MCD_MAX_FRAMES];
 };
+constexpr int AGG_LDS_MAX = 8192;       // sample values staged in LDS (32 KB); a longer sample axis is read in place
 
-
-// One 64-lane wave per window, lane k = sample k (S <= 64): sums and best / worst run in sample order on wave-uniform values
-// (bit-identical to the sequential loops of aggregate_losses in the fused kernel), order statistics by rank counting -- no
-// per-thread array (the first version sorted a float[64] per thread in private memory: 272 B of scratch per lane).
-__device__ __forceinline__ float wave_get(float v, int k) { return __shfl(v, k, 64); }
-// rank of this lane's value among the first S lanes (ties broken by lane index): a permutation of 0 .. S-1
-__device__ __forceinline__ int wave_rank(float x, int lane, int S) {
-    int r = 0;
-    for (int k = 0; k < S; ++k) {
-        const float y = wave_get(x, k);
-        r += (y < x || (y == x && k < lane)) ? 1 : 0;
+// The S values of one window (its per-sample losses, or one pose element across the samples): staged in LDS, or -- beyond
+// AGG_LDS_MAX samples -- read where they lie (stride = floats between consecutive samples).
+struct SampleVals {
+    const float* p; long long stride;
+    __device__ __forceinline__ float operator()(int k) const { return p[(long long)k * stride]; }
+};
+__device__ __forceinline__ SampleVals stage_samples(const float* src, long long stride, int S, float* lds, bool in_lds, int lane) {
+    if (!in_lds) return SampleVals{src, stride};
+    __syncthreads();                                     // the previous round's readers are done with `lds`
+    for (int k = lane; k < S; k += 64) lds[k] = src[(long long)k * stride];
+    __syncthreads();
+    return SampleVals{lds, 1};
+}
+// Order statistics by rank counting: sample i's rank = #{k : x_k < x_i or (x_k == x_i and k < i)} is a permutation of
+// 0 .. S-1 whatever the ties; lane l ranks the samples l, l + 64, ...; the samples of rank r0 / r1 land in slot[0] / slot[1].
+// (No sort, no per-thread array: O(S^2 / 64) broadcast reads per lane.)  All lanes return the same pair.
+__device__ __forceinline__ void wave_rank_select(const SampleVals& X, int S, int lane, int r0, int r1, float* slot, float& v0, float& v1) {
+    for (int i = lane; i < S; i += 64) {
+        const float x = X(i);
+        int r = 0;
+        for (int k = 0; k < S; ++k) {
+            const float y = X(k);
+            r += (y < x || (y == x && k < i)) ? 1 : 0;
+        }
+        if (r == r0) slot[0] = x;
+        if (r == r1) slot[1] = x;
     }
-    return r;
+    __syncthreads();
+    v0 = slot[0]; v1 = slot[1];
+    __syncthreads();
 }
-// the value of the lane whose rank is r (lanes >= S never match)
-__device__ __forceinline__ float wave_select(float x, int rank, int lane, int S, int r) {
-    const unsigned long long m = __ballot(lane < S && rank == r);
-    return wave_get(x, m ? __ffsll((long long)m) - 1 : 0);
-}
-__device__ __forceinline__ float wave_order_stat(float x, int lane, int S, int strategy, float q) {
-    const int rank = wave_rank(x, lane, S);
-    if (strategy == MCD_AGGR_MEDIAN) return wave_select(x, rank, lane, S, (S - 1) / 2);      // torch.median: the lower middle value
-    const float pos = fminf(fmaxf(q, 0.f), 1.f) * (float)(S - 1);
+// torch.median: the lower middle value; torch.quantile: linear interpolation, torch.lerp's two-sided form
+__device__ __forceinline__ float wave_order_stat(const SampleVals& X, int S, int lane, int strategy, float q, float* slot) {
+    float a, c;
+    if (strategy == MCD_AGGR_MEDIAN) {
+        wave_rank_select(X, S, lane, (S - 1) / 2, (S - 1) / 2, slot, a, c);
+        return a;
+    }
+    const float pos = fminf(fmaxf(q, 0.f), 1.f) * (float)(S - 1);      // (q is validated on the host; the clamp is a backstop)
     const int lo = (int)floorf(pos);
     const int hi = lo + 1 < S ? lo + 1 : S - 1;
     const float wgt = pos - (float)lo;
-    const float a = wave_select(x, rank, lane, S, lo), c = wave_select(x, rank, lane, S, hi);
-    return wgt < 0.5f ? a + wgt * (c - a) : c - (c - a) * (1.f - wgt);                          // torch.lerp
+    wave_rank_select(X, S, lane, lo, hi, slot, a, c);
+    return wgt < 0.5f ? a + wgt * (c - a) : c - (c - a) * (1.f - wgt);
 }
 
+// Sums and best / worst run in sample order on wave-uniform values: bit-identical to the sequential loops of
+// aggregate_losses in the fused kernel.
 __global__ __launch_bounds__(64) void aggregate_kernel(const AggrParams P) {
+    extern __shared__ float agg_lds[];
+    float* slot = agg_lds;               // [2] selected order statistics
+    float* vals = agg_lds + 2;           // [S] staged sample values (in_lds)
     const int lane = threadIdx.x, S = P.S, per = P.C * P.Tx * P.V;
+    const bool in_lds = P.in_lds != 0;
     for (int b = blockIdx.x; b < P.B; b += gridDim.x) {
-        const float x = lane < S ? P.loss_all[(size_t)b * S + lane] : 0.f;
-        if (P.strategy == MCD_AGGR_BEST || P.strategy == MCD_AGGR_WORST) {
-            const bool best = P.strategy == MCD_AGGR_BEST;
-            float cur = best ? 1e10f : -1.f;       // mocodad.py:504-512: strict comparisons from 1e10 / -1
-            int sel = -1;
-            for (int k = 0; k < S; ++k) {
-                const float y = wave_get(x, k);
-                if (best ? (y < cur) : (y > cur)) { cur = y; sel = k; }
+        if (P.strategy <= MCD_AGGR_QUANTILE && P.strategy != MCD_AGGR_MEAN_POSE && P.strategy != MCD_AGGR_MEDIAN_POSE) {
+            const SampleVals X = stage_samples(P.loss_all + (size_t)b * S, 1, S, vals, in_lds, lane);
+            if (P.strategy == MCD_AGGR_BEST || P.strategy == MCD_AGGR_WORST) {
+                const bool best = P.strategy == MCD_AGGR_BEST;
+                float cur = best ? 1e10f : -1.f;       // mocodad.py:504-512: strict comparisons from 1e10 / -1 (the FIRST of equal samples stays)
+                int sel = -1;
+                for (int k = 0; k < S; ++k) {
+                    const float y = X(k);
+                    if (best ? (y < cur) : (y > cur)) { cur = y; sel = k; }
+                }
+                if (lane == 0) P.loss_agg[b] = cur;
+                if (P.pose_agg)
+                    for (int e = lane; e < per; e += 64)
+                        P.pose_agg[(size_t)b * per + e] = sel >= 0 ? P.pose_all[((size_t)b * S + sel) * per + e] : 0.f;
+            } else if (P.strategy == MCD_AGGR_MEAN) {
+                float sum = 0.f;
+                for (int k = 0; k < S; ++k) sum += X(k);
+                if (lane == 0) P.loss_agg[b] = sum / (float)S;
+            } else {
+                const float r = wave_order_stat(X, S, lane, P.strategy, P.q, slot);
+                if (lane == 0) P.loss_agg[b] = r;
             }
-            if (lane == 0) P.loss_agg[b] = cur;
-            if (P.pose_agg)
-                for (int e = lane; e < per; e += 64)
-                    P.pose_agg[(size_t)b * per + e] = sel >= 0 ? P.pose_all[((size_t)b * S + sel) * per + e] : 0.f;
-        } else if (P.strategy == MCD_AGGR_MEAN) {
-            float sum = 0.f;
-            for (int k = 0; k < S; ++k) sum += wave_get(x, k);
-            if (lane == 0) P.loss_agg[b] = sum / (float)S;
-        } else if (P.strategy == MCD_AGGR_MEDIAN || P.strategy == MCD_AGGR_QUANTILE) {
-            const float r = wave_order_stat(x, lane, S, P.strategy, P.q);
-            if (lane == 0) P.loss_agg[b] = r;
         } else {  // mean_pose / median_pose: per element over the S generated poses, then the loss of that pose (mocodad.py:493-503)
             float acc = 0.f;      // (every lane carries the same running sum: the per-element values are wave-uniform)
             for (int e = 0; e < per; ++e) {
-                const float pv = lane < S ? P.pose_all[((size_t)b * S + lane) * per + e] : 0.f;
+                const SampleVals X = stage_samples(P.pose_all + (size_t)b * S * per + e, per, S, vals, in_lds, lane);
                 float val;
                 if (P.strategy == MCD_AGGR_MEAN_POSE) {
                     float sum = 0.f;
-                    for (int k = 0; k < S; ++k) sum += wave_get(pv, k);
+                    for (int k = 0; k < S; ++k) sum += X(k);
                     val = sum / (float)S;
                 } else {
-                    val = wave_order_stat(pv, lane, S, MCD_AGGR_MEDIAN, 0.f);
+                    val = wave_order_stat(X, S, lane, MCD_AGGR_MEDIAN, 0.f, slot);
                 }
                 if (P.pose_agg && lane == 0) P.pose_agg[(size_t)b * per + e] = val;
                 const int c = e / (P.Tx * P.V), tx = (e / P.V) % P.Tx, v = e % P.V;
@@ -1350,6 +1376,7 @@ int mcd_unet_forward(const mcd_weights_t* w, const float* x, const float* cond, 
     if (!w) return fail(MCD_EINVAL, "null argument");
     if (n_windows <= 0) return MCD_OK;
     if (!x || !step_table || !eps_out) return fail(MCD_EINVAL, "null argument");
+    if (t < 0) return fail(MCD_EINVAL, "t must be >= 0 (step_table needs at least t + 1 rows)");
     ScoreParams P;
     memset(&P, 0, sizeof(P));
     P.wbuf = w->dbuf; P.x_in = x; P.cond_emb = cond; P.step_table = step_table; P.eps_out = eps_out;
@@ -1394,11 +1421,13 @@ int mcd_layer_forward(const mcd_weights_t* w, int32_t stage, const float* x, con
     switch (w->cfg.t_unet) {
         case 3: return launch_score_t<3, 2, 4, true>(P, st, nullptr);
         case 6: return launch_score_t<6, 1, 4, true>(P, st, nullptr);
-        case 12: return launch_score_t<12, 1, 2, true>(P, st, nullptr);
+        case 12: return launch_score_t<12, 1, 3, true>(P, st, nullptr);      // (the template arguments and unit flags of the production kernels)
         case 5: return launch_score_t<5, 1, 4, true>(P, st, nullptr);
         case 7: return launch_score_t<7, 1, 2, true>(P, st, nullptr);
-        case 10: return launch_score_t<10, 1, 2, true>(P, st, nullptr);
-        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3, 5, 6, 7, 10, 12 and 13 .. 32 U-Net frames (the fixtures' shapes)");
+        case 9: return launch_score_t<9, 1, 3, true>(P, st, nullptr);
+        case 10: return launch_score_t<10, 1, 3, true>(P, st, nullptr);
+        case 11: return launch_score_t<11, 1, 3, true>(P, st, nullptr);
+        default: return fail(MCD_EUNSUPPORTED, "mcd_layer_forward is instantiated for 3, 5, 6, 7, 9, 10, 11, 12 and 13 .. 32 U-Net frames");
     }
 #endif
 }
@@ -1481,8 +1510,10 @@ __global__ void gather_frames_kernel(const DataView dv, float* __restrict__ out,
     out[u] = load_coord(dv, b, c, fi.idx[k], v, T);
 }
 
-static int launch_aggregate(const AggrParams& A, hipStream_t st) {
-    hipLaunchKernelGGL(aggregate_kernel, dim3(A.B < 65536 ? A.B : 65536), dim3(64), 0, st, A);      // one wave per window
+static int launch_aggregate(AggrParams& A, hipStream_t st) {
+    A.in_lds = A.S <= AGG_LDS_MAX;
+    const size_t lds = (size_t)(2 + (A.in_lds ? A.S : 0)) * sizeof(float);
+    hipLaunchKernelGGL(aggregate_kernel, dim3(A.B < 65536 ? A.B : 65536), dim3(64), lds, st, A);      // one wave per window
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }
@@ -1502,11 +1533,11 @@ static int score_impl(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const 
         if (!loss_agg) return fail(MCD_EINVAL, "null argument");
         if (aggr != MCD_AGGR_BEST && aggr != MCD_AGGR_WORST && aggr != MCD_AGGR_MEAN && aggr != MCD_AGGR_MEDIAN && aggr != MCD_AGGR_QUANTILE)
             return fail(MCD_EINVAL, "mcd_score_fused aggregates losses (best, worst, mean, median, quantile); the *_pose strategies go through mcd_score + mcd_aggregate");
-        if (S > 64) return fail(MCD_EUNSUPPORTED, "aggregation supports n_generated_samples <= 64");
         if (aggr == MCD_AGGR_QUANTILE && !(quantile >= 0.f && quantile <= 1.f))       // (also rejects NaN; torch.quantile raises)
             return fail(MCD_EINVAL, "quantile must be in [0, 1]");
     }
     if (S < 1 || cfg->noise_steps < 2) return fail(MCD_EINVAL, "need n_samples >= 1 and noise_steps >= 2");
+    if ((long long)B * S > 0x7fffffffll) return fail(MCD_EINVAL, "n_windows x n_samples exceeds 2^31 - 1: score in smaller batches");
     if (cfg->n_corrupt < 1 || cfg->n_cond + cfg->n_corrupt != cfg->seg_len || cfg->seg_len > MCD_MAX_FRAMES)
         return fail(MCD_EINVAL, "cond/corrupt index lists do not partition seg_len");
     const int strat = w->cfg.strategy;
@@ -1656,7 +1687,7 @@ int mcd_aggregate(const mcd_score_cfg_t* cfg, int32_t num_coords, int32_t n_join
     if (!cfg) return fail(MCD_EINVAL, "null argument");
     if (cfg->n_windows <= 0) return MCD_OK;
     if (!loss_all || !loss_agg) return fail(MCD_EINVAL, "null argument");
-    if (cfg->n_samples > 64) return fail(MCD_EUNSUPPORTED, "aggregation supports n_generated_samples <= 64");
+    if (cfg->n_samples < 1) return fail(MCD_EINVAL, "need n_samples >= 1");
     if (strategy < MCD_AGGR_BEST || strategy > MCD_AGGR_QUANTILE) return fail(MCD_EINVAL, "unknown aggregation strategy");
     if (strategy == MCD_AGGR_QUANTILE && !(quantile >= 0.f && quantile <= 1.f)) return fail(MCD_EINVAL, "quantile must be in [0, 1]");
     const bool need_pose = strategy == MCD_AGGR_MEAN_POSE || strategy == MCD_AGGR_MEDIAN_POSE;

@@ -121,7 +121,17 @@
 #else
 #define MCD_U23(...)
 #endif
-#if MCD_INST_UNITS != 23
+#if MCD_UNIT_IS(24)
+#define MCD_U24(...) __VA_ARGS__
+#else
+#define MCD_U24(...)
+#endif
+#if MCD_UNIT_IS(25)
+#define MCD_U25(...) __VA_ARGS__
+#else
+#define MCD_U25(...)
+#endif
+#if MCD_INST_UNITS != 25
 #error "add the MCD_U<n> selectors of the new units"
 #endif
 

@@ -10,7 +10,7 @@
 //   X(unit, TP, NB)              score_tiled_kernel<TP, NB, false, true>: the 'E_unet' condition encoder at 13 .. 32 condition frames
 #pragma once
 
-#define MCD_INST_UNITS 23
+#define MCD_INST_UNITS 25
 
 // Per-unit compile flags (mocodad_amd/build.py reads these lines).  The wave count of a workgroup is a translation-unit constant
 // (MCD_NWAVES): units 3, 5, 23, 11 and 12 hold ONLY the 12-frame, the 9- / 10- / 11-frame and the 24- / 32-frame (slab-tiled) trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
@@ -21,6 +21,12 @@
 #define MCD_UNIT_FLAGS_11 "-DMCD_NWAVES=12"     // the slab-tiled kernel at 24 frames: +4.5 % (profiles/r04aq_tiled_w12_ab.txt)
 #define MCD_UNIT_FLAGS_12 "-DMCD_NWAVES=12"     // ... and at 32 frames: +2.0 %
 #define MCD_UNIT_FLAGS_5 "-DMCD_NWAVES=12"      // 9, 10 and 11 frames (profiles/r04al_w12_shapes_ab.txt, r04an_t10_w12_ab.txt)
+// The layer-test (LT) forms behind mcd_layer_forward are built with the flags AND the template arguments of their production
+// twins, so that the stage tests run the shipped stage code (the twelve-wave mix tables, n-thirds tiling, skip-round branches):
+#define MCD_UNIT_FLAGS_24 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"     // LT of 12 and 9 frames (= units 3, 23)
+#define MCD_UNIT_FLAGS_25 "-DMCD_NWAVES=12"     // LT of 10 and 11 frames (= unit 5)
+#define MCD_UNIT_FLAGS_15 "-DMCD_NWAVES=12"     // LT of the slab-tiled kernel at 24 frames (= unit 11)
+#define MCD_UNIT_FLAGS_16 "-DMCD_NWAVES=12"     // ... and at 32 frames (= unit 12)
 
 #ifdef MCD_TUNING_VARIANTS      // alternative workgroup shapes (MCD_OPT_VARIANT): developer builds only
 #define MCD_SCORE_VARIANT_INSTANCES(X) X(1, 3, 4, 2, false) X(1, 3, 1, 4, false) X(1, 3, 2, 2, false) X(2, 6, 2, 2, false)
@@ -37,8 +43,8 @@
     X(22, 8, 1, 2, false) \
     X(4, 5, 1, 4, false) X(4, 7, 1, 2, false) \
     X(23, 9, 1, 3, false) X(5, 10, 1, 3, false) X(5, 11, 1, 3, false) /* twelve waves as well (unit 5): +3.7 / +0.9 / +0.9 %; 7 and 8 frames measured -1 % / +0.2 %: eight waves */ \
-    X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(9, 12, 1, 2, true) \
-    X(13, 5, 1, 4, true) X(13, 7, 1, 2, true) X(13, 10, 1, 2, true) \
+    X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(24, 12, 1, 3, true) X(24, 9, 1, 3, true) \
+    X(13, 5, 1, 4, true) X(13, 7, 1, 2, true) X(25, 10, 1, 3, true) X(25, 11, 1, 3, true) \
     MCD_SCORE_VARIANT_INSTANCES(X)
 
 #define MCD_COND_FAST_INSTANCES(X) \

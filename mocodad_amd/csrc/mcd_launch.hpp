@@ -107,7 +107,8 @@ int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
         if (P.mode == 0 && P.force_split > 0) P.split = P.force_split < P.S ? P.force_split : P.S;
         if (P.plan_only) return MCD_OK;
     }
-    // the in-kernel condition encoder / aggregation need the workgroup to see all samples of its windows (and S <= 64)
+    // the in-kernel condition encoder / aggregation need the workgroup to see all samples of its windows; its LDS holds 64
+    // per-sample losses per window: more samples are aggregated by aggregate_kernel from the (B,S) losses
     const bool whole = P.split == 1 && P.mode == 0;
     if (!(whole && P.S <= 64)) P.loss_agg = nullptr;
     if (fused) *fused = P.loss_agg != nullptr;

@@ -326,7 +326,7 @@ class MoCoDAD(_Base):
         kw = dict(n_samples=S, noise_steps=ns, noise=noise, seed=self.seed, first_window_id=window_offset, loss_fn=self.loss_name,
                   cond_mask=cond_mask)
         fusable = aggr in ("best", "worst", "mean", "median") or "quantile" in aggr
-        if fusable and not want_pose and S <= 64:
+        if fusable and not want_pose:
             # loss-only output: trajectories, condition encoder and the aggregation over the samples in ONE launch
             loss, _, _ = sc.score_fused(tensor_data, aggregation=aggr, **kw)
             selected_x = None

@@ -546,6 +546,39 @@ def extra6(MoCoDAD):
                 save(f"traj_{name}_ns{nsl}_S{Sl}.npz", **trl)
 
 
+# `--extra7` (round 5): the reference's SHIPPED evaluation setting n_generated_samples = 50 (config/Avenue/mocodad_test.yaml:68,
+# config/STC/mocodad_test.yaml:69, config/UBnormal/mocodad_test.yaml:68) and sample counts around / above the 64-lane wave the
+# device aggregation is built on (64, 65, 100), ns 10, every aggregation (mocodad.py:454-520) -- from the ALREADY COMMITTED
+# weights (inject, concat, hostile_inject).  Five noise slots are duplicated (sample S//2 + k == sample k, k < 5) so that the
+# per-window losses / per-element poses hold exact ties: torch.median's lower-middle rule, torch.quantile's interpolation and
+# the strict `<` / `>` of best / worst (mocodad.py:504-512: the FIRST of two equal samples is kept) all see them.
+EXTRA7 = [("inject", 50, 4), ("inject", 64, 3), ("inject", 65, 3), ("inject", 100, 3), ("concat", 50, 3), ("concat", 100, 3),
+          ("hostile_inject", 50, 3)]      # (committed weights, S, B)
+
+
+def extra7(MoCoDAD):
+    ns = 10
+    for vname, S, B in EXTRA7:
+        d = np.load(os.path.join(HERE, f"weights_{vname}.npz"))
+        cfg = json.loads(bytes(d["__cfg__"]).decode())
+        args, _ = make_args(strategy=cfg["conditioning_strategy"], seg_len=cfg["seg_len"], cond_idx=cfg["conditioning_indices"],
+                            noise_steps=ns, n_gen=S, aggr="all", ret="all")
+        m = MoCoDAD(args).eval()
+        m.load_state_dict({k: torch.from_numpy(d[k]) for k in d.files if k != "__cfg__"})
+        gen = torch.Generator().manual_seed(7000 + 31 * len(vname) + S)
+        seg_len = cfg["seg_len"]
+        hostile = vname.startswith("hostile")
+        data = (synth_windows(B, seg_len, gen) * 3).clamp_(-5, 5) if hostile else synth_windows(B, seg_len, gen)
+        noise = fp16_round(torch.randn(S, ns - 1, B, 2, m.n_frames_corrupt, 17, generator=gen))
+        for k in range(5):
+            noise[S // 2 + k] = noise[k]
+        tr = _traj(m, data, noise, seg_len)
+        la = tr["loss_all"]
+        assert torch.equal(la[:, S // 2:S // 2 + 5], la[:, :5])
+        print(vname, "S", S, "loss range", float(la.min()), float(la.max()), "best", tr["loss_best"].tolist())
+        save(f"traj_{vname}_ns{ns}_S{S}.npz", **tr)
+
+
 def extra2():
     """Test-time affine transforms of the reference's dataset (utils/dataset_utils.py:255-310; applied in
     utils/dataset.py:67-76): `python tests/golden/gen_golden.py --extra2`."""
@@ -585,6 +618,9 @@ def main():
         return
     if "--extra6" in sys.argv:
         extra6(MoCoDAD)
+        return
+    if "--extra7" in sys.argv:
+        extra7(MoCoDAD)
         return
 
     # ---------------------------------------------------------------- 5. schedules

@@ -61,3 +61,40 @@ def test_layer_forward_ragged_batch_and_errors():
         sc.layer_forward(5, x[:, :10], e)
     with pytest.raises(KeyError):
         sc.layer_forward(15, x, e)
+
+
+@pytest.mark.parametrize("seg_len", [18, 22, 24, 20])
+def test_every_stage_at_twelve_wave_frame_counts_vs_oracle(seg_len):
+    """9 and 11 U-Net frames (seg_len 18 / 22 split in halves) have no reference-generated stage fixture: every stage of their
+    TWELVE-wave kernels alone (mcd_layer_forward runs score_kernel<9|10|11|12, 1, 3, LT> built with the flags of the shipped
+    kernel) against the ORACLE's stage functions, which are pinned to the reference's layer I/O at 3 .. 32 frames
+    (test_oracle_golden.py::test_layers).  10 and 12 frames ride along (they have reference fixtures too: test_extra6_gpu.py and above)."""
+    from oracle import mocodad_oracle as O
+    from test_hip_parity import _random_model
+    m, sd, gen = _random_model("inject", seg_len, 2)
+    sc = m.to("cuda:0").scorer()
+    T = seg_len // 2
+    assert sc.t_unet == T
+    sdo = O.to_torch_state({k: v.numpy() for k, v in sd.items()})
+    B = 3
+    e = torch.randn(B, 16, generator=gen)
+    blocks = O.UNET_DOWN + O.UNET_MID1 + O.UNET_MID2 + O.UNET_UP4 + O.UNET_UP3
+    worst = 0.0
+    with torch.no_grad():
+        for i, (b, li) in enumerate(blocks):
+            cin, vin, _, _ = sc._STAGES[i]
+            x = torch.randn(B, cin, T, vin, generator=gen)
+            ref = O.st_gcnn_layer(sdo, f"model.{b}.{li}", x, e).numpy()
+            out = sc.layer_forward(i, x, e).cpu().numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            worst = max(worst, np.abs(out - ref).max() / scale)
+            np.testing.assert_allclose(out, ref, atol=2e-5 * scale, rtol=1e-5, err_msg=f"T_u {T} layer {i}")
+        for sid, rn in ((11, "down1"), (12, "down2"), (13, "up3"), (14, "up2")):
+            cin, vin, _, _ = sc._STAGES[sid]
+            x = torch.randn(B, cin, T, vin, generator=gen)
+            ref = O.joint_resample(sdo, f"model.{rn}", x).numpy()
+            out = sc.layer_forward(sid, x, e).cpu().numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            worst = max(worst, np.abs(out - ref).max() / scale)
+            np.testing.assert_allclose(out, ref, atol=2e-5 * scale, rtol=1e-5, err_msg=f"T_u {T} {rn}")
+    print(f"T_u = {T}: max scaled |stage output - oracle| over the 15 stages = {worst:.3e}")
