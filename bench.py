@@ -56,10 +56,22 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/profile_set.sh): per-launch counter averages
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
-PMC_PROFILES = {"avenue": ("profiles/r04zy_avenue_pmc.txt", 1024, 10, 5), "stc": ("profiles/r04zy_avenue_pmc.txt", 1024, 10, 5),      # (stc: the same kernel, 2048 windows -- scaled)
-                "ubnormal_concat": ("profiles/r04zy_ubnormal_concat_pmc.txt", 1024, 10, 5),
-                "seq24": ("profiles/r04zy_seq24_pmc.txt", 1024, 50, 8), "concat32": ("profiles/r04zy_concat32_pmc.txt", 1024, 10, 5)}
+PMC_SET = "r05zz"           # tools/profile_set.sh's run directory of the committed set: profiles/<PMC_SET>_<config>_pmc.txt
+PMC_PROFILES = {"avenue": (1024, 10, 5), "stc": (2048, 10, 5), "ubnormal_concat": (1024, 10, 5), "seq24": (1024, 50, 8),
+                "concat24": (1024, 10, 5), "concat32": (1024, 10, 5)}      # config -> (windows, noise_steps, samples) of the profiled command
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
+
+
+_SO_SHA = None
+
+
+def loaded_library_sha256():
+    global _SO_SHA
+    if _SO_SHA is None:
+        import hashlib
+        from mocodad_amd import _lib
+        _SO_SHA = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    return _SO_SHA
 
 
 def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
@@ -67,10 +79,13 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
     matrix-pipe statistics of the trajectory kernel from the committed PMC profile of this configuration."""
     if config not in PMC_PROFILES:
         return None
-    path, pB, pns, pS = PMC_PROFILES[config]
+    pB, pns, pS = PMC_PROFILES[config]
+    path = f"profiles/{PMC_SET}_{config}_pmc.txt"
     try:
-        kernels, cur = {}, None
+        kernels, cur, man = {}, None, None
         for line in open(os.path.join(ROOT, path)):
+            if line.startswith("# manifest:"):
+                man = dict(kv.split("=", 1) for kv in line.split()[2:] if "=" in kv)
             if line.startswith("#") or not line.strip():
                 continue
             if not line.startswith(" "):
@@ -80,12 +95,17 @@ def pmc_profile(config, B, ns, S, flop_per_window, kern_ms, t_unet):
                 cur[f[0]] = float(f[1])
     except Exception:
         return None
+    # the counters describe ONE library build: a profile whose manifest names another libmocodad_hip.so (or none) is refused
+    # (`traffic` null), not silently attached to this run's kernels
+    if not man or man.get("so_sha256") != loaded_library_sha256():
+        return {"source": path, "refused": "the profile's manifest does not name the loaded libmocodad_hip.so "
+                f"(profile: {(man or {}).get('so_sha256', 'no manifest')[:12]}, loaded: {loaded_library_sha256()[:12]}): regenerate with tools/profile_set.sh"}
     sk = next((v for k, v in kernels.items() if k.startswith("score_kernel") or k.startswith("score_tiled_kernel")), None)
     tiled = any(k.startswith("score_tiled_kernel") for k in kernels)
     if not sk:
         return None
     scale = (B * S * (ns - 1)) / float(pB * pS * (pns - 1))       # counters scale with the chain-passes of a launch
-    out = {"source": path, "profiled_workload": {"windows": pB, "noise_steps": pns, "samples": pS}}
+    out = {"source": path, "manifest": man, "profiled_workload": {"windows": pB, "noise_steps": pns, "samples": pS}}
     mfma = sk.get("SQ_INSTS_MFMA")
     if mfma:
         mfma *= scale
@@ -319,6 +339,183 @@ def auc_vs_ref(sc, sd, cfg, ns, S, seeds=200, oracle_seeds=2, with_oracle=True):
     return out
 
 
+class GpuSampler:
+    """Shader clock (MHz) and socket power (W) of one GPU, sampled from a background thread while the kernels run: amdsmi
+    (the library behind amd-smi) when it loads, else torch.cuda.clock_rate / power_draw (amdsmi through torch)."""
+
+    def __init__(self, index, period_s=0.1):
+        import threading
+        self.index, self.period, self.samples, self._stop = index, period_s, [], threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._read = self._reader()
+
+    def _reader(self):
+        idx = self.index
+        try:
+            import amdsmi
+            try:
+                amdsmi.amdsmi_init()
+            except Exception:
+                pass
+            h = amdsmi.amdsmi_get_processor_handles()[idx]
+
+            def read():
+                clk = pw = None
+                try:
+                    m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                    cl = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 65535]
+                    clk = float(np.mean(cl)) if cl else (float(m["current_gfxclk"]) if isinstance(m.get("current_gfxclk"), (int, float)) and 0 < m["current_gfxclk"] < 65535 else None)
+                    for k in ("current_socket_power", "average_socket_power"):
+                        if isinstance(m.get(k), (int, float)) and 0 < m[k] < 65535:
+                            pw = float(m[k])
+                            break
+                except Exception:
+                    pass
+                if clk is None:
+                    try:
+                        clk = float(amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)["clk"])
+                    except Exception:
+                        pass
+                if pw is None:
+                    try:
+                        pi = amdsmi.amdsmi_get_power_info(h)
+                        for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                            if isinstance(pi.get(k), (int, float)) and pi[k] > 0:
+                                pw = float(pi[k])
+                                break
+                    except Exception:
+                        pass
+                return clk, pw
+            read()
+            self.source = "amdsmi"
+            return read
+        except Exception:
+            pass
+
+        def read_torch():
+            clk = pw = None
+            try:
+                clk = float(torch.cuda.clock_rate(idx))
+            except Exception:
+                pass
+            try:
+                pw = float(torch.cuda.power_draw(idx)) / 1e3
+            except Exception:
+                pass
+            return clk, pw
+        self.source = "torch.cuda"
+        return read_torch
+
+    def _loop(self):
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            clk, pw = self._read()
+            self.samples.append((time.perf_counter() - t0, clk, pw))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join(timeout=2)
+
+    def summary(self):
+        clk = [c for _, c, _ in self.samples if c]
+        pw = [p for _, _, p in self.samples if p]
+        st = lambda v: {"min": round(min(v), 1), "mean": round(float(np.mean(v)), 1), "max": round(max(v), 1)} if v else None
+        return {"source": self.source, "samples": len(self.samples), "sclk_mhz": st(clk), "socket_power_w": st(pw),
+                "sclk_mhz_first_last": [round(clk[0], 1), round(clk[-1], 1)] if clk else None}
+
+
+def sustained_run(launch, seconds, est_step_ms, windows_per_step, flop_per_window, dev_index):
+    """Back-to-back steps for at least `seconds` (never `value`): per-step HIP-event times, throughput of the first and of the
+    last second, and the shader clock / socket power sampled while the kernels run -- what the burst of the headline run
+    (tens of ms at the driver's --steps 20) cannot show: does the clock hold under seconds of fp32 MFMA?"""
+    n_steps = max(8, int(np.ceil(seconds * 1e3 / max(est_step_ms, 1e-3) * 1.02)))
+    chunk = max(1, int(np.ceil(250.0 / max(est_step_ms, 1e-3))))           # ~0.25 s of launches per chunk, two chunks in flight
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+    for e in ev:
+        e.record()
+    torch.cuda.synchronize()
+    with GpuSampler(dev_index) as smp:
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(n_steps):
+            launch(i)
+            ev[i + 1].record()
+            if i % chunk == chunk - 1 and i >= 2 * chunk:
+                ev[i + 1 - 2 * chunk].synchronize()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    ends = np.array([ev[0].elapsed_time(e) for e in ev[1:]])               # ms since the start of the region
+    step = np.diff(np.concatenate([[0.0], ends]))
+    total_ms = float(ends[-1])
+    first = int(np.searchsorted(ends, 1000.0)) + 1
+    last = n_steps - int(np.searchsorted(ends, total_ms - 1000.0))
+    rate = lambda n, ms: windows_per_step * n / (ms * 1e-3)
+    r_first = rate(first, float(ends[first - 1]))
+    r_last = rate(last, total_ms - float(ends[n_steps - last - 1]) if last < n_steps else total_ms)
+    frac = lambda r: round(r * flop_per_window / 1e12 / PEAK_FP32_TFLOPS, 4)
+    return {"seconds": round(total_ms / 1e3, 3), "wall_seconds": round(wall, 3), "steps": n_steps,
+            "value": round(rate(n_steps, total_ms), 1), "unit": "clips/s", "frac": frac(rate(n_steps, total_ms)),
+            "first_second": {"value": round(r_first, 1), "frac": frac(r_first)}, "last_second": {"value": round(r_last, 1), "frac": frac(r_last)},
+            "droop_last_vs_first": round(r_last / r_first - 1.0, 5),
+            "step_ms": {"p5": round(float(np.percentile(step, 5)), 4), "p50": round(float(np.percentile(step, 50)), 4),
+                        "p95": round(float(np.percentile(step, 95)), 4), "max": round(float(step.max()), 4)},
+            "gpu": smp.summary(),
+            "note": "same launches as the timed region, back to back for the stated time; HIP events per step; informational, never `value`"}
+
+
+def e2e_run(sd, cfg, ns, S, batch, n_clips, frames_per_clip, dev, kernel_rate):
+    """End to end, as eval_MoCoDAD.py runs it (the reference's caller: mocodad.py:230-274, eval_MoCoDAD.py:33-38): synthetic
+    per-person trajectories uploaded once, windows + test-time transforms cut on the device, the test_step loop over batches of
+    `batch` windows, then on_test_epoch_end = collation + mcd_frame_scores + roc_auc_score.  Never `value`."""
+    import argparse
+    import tempfile
+    from mocodad_amd.data import synthetic
+    from mocodad_amd.data.windows import TrajectoryWindows
+    from mocodad_amd.models.mocodad import MoCoDAD
+    import sklearn.metrics  # noqa: F401
+    c = dict(cfg, noise_steps=ns, n_generated_samples=S, batch_size=batch, aggregation_strategy="best", model_return_value="loss",
+             save_tensors=False, dataset_choice="synthetic", pad_size=-1, filter_kernel_size=3, frames_shift=2)
+    trajs, gts = synthetic.make_trajectories(n_clips=n_clips, frames_per_clip=frames_per_clip, seed=999)
+    gt_dir = tempfile.mkdtemp(prefix="mocodad_gt_")
+    synthetic.write_gt(gt_dir, gts)
+    c["gt_path"] = c["test_path"] = gt_dir
+    c.setdefault("ckpt_dir", "/tmp/mocodad_amd_ckpt")
+    t_build = time.perf_counter()
+    tw = TrajectoryWindows(trajs, c["seg_len"], c["num_transform"]).to(dev)
+    t_build = time.perf_counter() - t_build
+    m = MoCoDAD(argparse.Namespace(**c)).to(dev)
+    m.load_state_dict(sd)
+    m.dataset_name = "synthetic"
+    n = len(tw)
+    warm = tw.batch(0, min(batch, n))
+    m.on_test_epoch_start()
+    with torch.no_grad():
+        m.test_step(warm, 0)            # packs the weights, sizes the workspace (outside the timed region, like a checkpoint load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.on_test_epoch_start()
+    with torch.no_grad():
+        for i, b in enumerate(tw.batches(batch)):
+            m._calls = i * batch
+            m.test_step(b, i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    auc = m.on_test_epoch_end()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return {"windows": n, "batch": batch, "clips": n_clips, "frames_per_clip": frames_per_clip, "seconds": round(t2 - t0, 4),
+            "value": round(n / (t2 - t0), 1), "unit": "clips/s", "scoring_seconds": round(t1 - t0, 4), "epoch_end_seconds": round(t2 - t1, 4),
+            "vs_kernel_rate": round(n / (t2 - t0) / kernel_rate, 4) if kernel_rate else None, "auc": round(float(auc), 6),
+            "host_window_index_seconds": round(t_build, 3),
+            "note": "MoCoDAD.test_step loop over device-cut windows + on_test_epoch_end (gather, mcd_frame_scores, roc_auc_score); "
+                    "trajectories resident in HBM; informational, never `value`"}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -362,6 +559,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auc", action="store_true", help="skip the (untimed) AUC-vs-reference leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational H2D-inclusive and opt-in legs")
+    ap.add_argument("--min-seconds", type=float, default=0.0, help="make the TIMED region at least this long (steps = max(--steps, what fills it)): "
+                    "sustained throughput as `value`")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the informational `sustained` leg (0 = skip; skipped under --no-extras)")
+    ap.add_argument("--e2e-windows", type=int, default=None, help="windows of the informational end-to-end leg (default: about 0.5 s of scoring; 0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline sample (all threads + one thread)")
     ap.add_argument("--dist-backend", default="nccl", help="'nccl' (= RCCL over xGMI, the default) or 'gloo' (tests that "
                     "place several ranks on one GPU)")
@@ -463,6 +664,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    preroll_steps = 0
+    est_step_ms = None
+    if args.preroll_ms > 0 and B > 0:
+        t_pre = time.perf_counter()
+        pre_out = torch.zeros(per, device=dev, dtype=torch.float32)
+        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:      # local launches only: no collective, ranks may differ
+            t_one = time.perf_counter()
+            sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation="best", seed=preroll_steps, first_window_id=lo, out=pre_out[:B])
+            torch.cuda.synchronize()
+            est_step_ms = (time.perf_counter() - t_one) * 1e3            # (the last one: clocks are up by then)
+            preroll_steps += 1
+    if args.min_seconds > 0:
+        # a timed region of at least --min-seconds: the step count follows from the pre-roll's step time (every rank takes the
+        # largest count, so the single all-gather keeps one size)
+        if est_step_ms is None:
+            raise SystemExit("--min-seconds needs the pre-roll (--preroll-ms > 0) to size the step count")
+        want = int(np.ceil(args.min_seconds * 1e3 / est_step_ms * 1.03))
+        if use_dist:
+            w_t = torch.tensor([want], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(w_t, op=dist.ReduceOp.MAX)
+            want = int(w_t.item())
+        args.steps = max(args.steps, want)
     # the timed steps' events exist (hipEventCreate, signal pool growth) before anything is timed: torch creates them lazily
     # at their first record(), which would otherwise happen inside the timed loop
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -470,21 +693,18 @@ def main():
         a_.record()
         b_.record()
     torch.cuda.synchronize()
-    preroll_steps = 0
-    if args.preroll_ms > 0 and B > 0:
-        t_pre = time.perf_counter()
-        pre_out = torch.zeros(per, device=dev, dtype=torch.float32)
-        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:      # local launches only: no collective, ranks may differ
-            sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation="best", seed=preroll_steps, first_window_id=lo, out=pre_out[:B])
-            torch.cuda.synchronize()
-            preroll_steps += 1
     if args.warmup > 0:
         run(sc, args.warmup, 0)
     barrier()
+    sampler = GpuSampler(dev_index, 0.05) if (rank == 0 and not args.no_extras) else None      # (a host thread; does not touch the stream)
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     best = run(sc, args.steps, 100, ev)
     barrier()
     dt_local = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
     dt = dt_local
     step_ms = [a.elapsed_time(b) for a, b in ev]
     kern_ms = float(np.mean(step_ms)) if B > 0 else 0.0
@@ -548,6 +768,9 @@ def main():
                        "noise": "in-kernel Philox4x32-10", "parallelism": f"windows sharded over {world} GPU(s), one all-gather of scores",
                        "streams": max(args.streams, 1)},
             "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
+            "step_ms_pct": ({"p5": round(float(np.percentile(step_ms, 5)), 4), "p50": round(float(np.percentile(step_ms, 50)), 4),
+                             "p95": round(float(np.percentile(step_ms, 95)), 4)} if B > 0 else None),
+            "gpu_during_timed_region": sampler.summary() if sampler else None,
             "step_ms_first": [round(float(v), 4) for v in step_ms[:4]] if B > 0 else None,
             "step_ms_max": [round(float(np.max(step_ms)), 4), int(np.argmax(step_ms))] if B > 0 else None,    # [ms, step index]
             "roofline": {"bound": "mfma", "kernel": kname + (" (condition encoder and aggregation inside: one launch per step)" if one_launch and enc_inside
@@ -581,6 +804,18 @@ def main():
         if world == 1 and not args.no_extras and not args.no_auc:
             # `AUC vs ref` (BASELINE.json metric), untimed: see auc_vs_ref
             out["auc"] = auc_vs_ref(sc, sd, cfg, ns, S, with_oracle=not args.no_cpu_baseline and S * (ns - 1) <= 64)
+        if world == 1 and not args.no_extras and args.sustained_seconds > 0 and B > 0:
+            # informational only (never `value`): the same launches back to back for >= --sustained-seconds
+            sus_out = torch.zeros(per, device=dev, dtype=torch.float32)
+            out["sustained"] = sustained_run(lambda i: sc.score_fused(data, n_samples=S, noise_steps=ns, aggregation="best", seed=5000 + i,
+                                                                      first_window_id=lo, out=sus_out[:B]),
+                                             args.sustained_seconds, kern_ms, B, flop_per_window, dev_index)
+        if world == 1 and not args.no_extras and args.e2e_windows != 0 and not variant.startswith("rand:"):
+            # informational only: the caller's loop around the path (test_step + on_test_epoch_end), about 0.5 s of scoring by default
+            n_e2e = args.e2e_windows or int(max(4 * B, min(400_000, 0.5 * out["value"])))
+            fpc = 200 if seg_len <= 12 else 300
+            per_clip = 3 * (fpc - 5 - seg_len + 1) * int(cfg.get("num_transform", 5))
+            out["e2e"] = e2e_run(sd, cfg, ns, S, B, max(1, round(n_e2e / per_clip)), fpc, dev, out["value"])
         if world == 1 and not use_dist and not args.no_extras:
             # informational only (never `value`): the same steps fed from pinned HOST windows, the H2D copy inside the timed loop
             n_x = min(args.steps, 10)

@@ -1413,7 +1413,7 @@ struct Plan {
     static constexpr int LOSS = NB * 64;        // per-sample losses of the workgroup's windows [NB][S <= 64] (in-kernel aggregation)
     static constexpr int EXW = EMB_EXTRA * 20;  // embedding rows beyond the first NTHREADS: [row][16 weights, bias, pad]
 #ifdef MCD_PROFILE
-    static constexpr int PROFTR = (NB * T >= 10 && NWAVES <= 8) ? PROF_TRACE * PROF_NW : 0;     // time stamps: the one-workgroup-per-CU shapes have the room
+    static constexpr int PROFTR = (NB * T >= 10 && NWAVES <= 12) ? PROF_TRACE * PROF_NW : 0;    // time stamps: the one-workgroup-per-CU shapes have the room (12 waves: 6 KB of the 14.8 KB the 12-frame plan leaves)
     static constexpr int PROF = PROF_SLOTS + PROFTR;
 #else
     static constexpr int PROF = 0;

@@ -304,6 +304,10 @@ class HipScorer:
         """_aggregation_strategy of the reference on device -> (selected pose | None, loss (B,)).
         out: optional preallocated contiguous fp32 (B,) device tensor receiving the loss."""
         B, S = loss_all.shape
+        # the C ABI takes dense (B,S) / (B,S,C,Tx,V) tensors: views with other strides (e.g. a transposed (S,B) stack) are copied
+        loss_all = _f32c(loss_all, self.device)
+        if poses_all is not None:
+            poses_all = _f32c(poses_all, self.device)
         q = 0.0
         name = strategy
         if "quantile" in strategy:

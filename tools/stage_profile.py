@@ -59,7 +59,11 @@ for i, (n, v) in enumerate(zip(names, p)):
     print(f"  {n:14s} {v/NP:9.0f}  {100*v/tot:5.1f}%{extra}")
 
 # per-wave cycles spent waiting at each barrier of a pass (the wave with the smallest wait arrived last: the stage's critical path)
-NW = int(os.environ.get("MCD_NWAVES", "8"))           # PROF_NW of the build
+# PROF_NW of the build = the wave count of the unit that holds this frame count's kernel (MCD_UNIT_FLAGS_<n> of mcd_instances.hpp)
+from mocodad_amd import build as _b
+_sh = _b.shipped_shape(sc.t_unet)
+_nw = [f for f in (_b.unit_flags().get(_sh[0], []) if _sh else []) if f.startswith("-DMCD_NWAVES=")]
+NW = int(os.environ.get("MCD_NWAVES") or (_nw[0].split("=")[1] if _nw else 8))
 bar = p[72 + NW:72 + NW + 30 * NW].reshape(30, NW) / NP
 if bar.sum() > 0:
     print(f"\nbarrier waits per pass (cycles), {NW} waves: barrier | per wave | min  mean")
