@@ -90,7 +90,13 @@ typedef struct mcd_weights mcd_weights_t;
 
 /* Replaces: LightningModule.load_state_dict + model.eval() (eval_MoCoDAD.py:36-38).
  * Folds every eval-mode BatchNorm2d into the preceding 1x1 conv (stsgcn.py:57-80,181-182), repacks the
- * channel-mixing matrices into MFMA fragment order and uploads them to `device`. */
+ * channel-mixing matrices into MFMA fragment order and uploads them to `device`.
+ * The handle is read-only for the scoring calls (any number of streams / host threads may share it) with ONE exception: two
+ * device words in which workgroup 0 of a trajectory launch leaves (launch signature, its own lifetime in 100 MHz ticks) for
+ * the next launch of the same grid to size its wave-priority time slice from.  Launches that overlap on different streams
+ * race on these words (plain stores, no ordering); a torn or stale pair only selects the host's estimate of the slice (the
+ * signature does not match) or a slice measured by the other launch -- scheduling, never results: scores are bit-identical
+ * whatever the words hold (tests/test_hip_parity.py::test_overlapping_launches_on_two_streams). */
 int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_model_cfg_t* cfg,
                      int32_t device, mcd_weights_t** out);
 void mcd_free_weights(mcd_weights_t* w);

@@ -121,7 +121,7 @@ def test_scale_check_script_output_format():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     n = _n_gpus()
     per_mode = sum(1 for k in (1, 2, 4, 8) if k <= n)
-    assert lines[0] == f"# {n} GPU(s) visible" and len(lines) == 1 + 2 * per_mode, r.stdout
+    assert lines[0] == f"# {n} GPU(s) visible" and len(lines) == 1 + 3 * per_mode, r.stdout
     pat = re.compile(r"^(weak|strong) N=(\d+): (\d+) clips/s  eff ([0-9.]+)  rccl_ranks (\d+)  kernel ms/rank (None|\[[0-9., ]+\])  all_gather ms (None|\[[0-9., ]+\])$")
     seen = []
     for l in lines[1:]:
@@ -129,4 +129,5 @@ def test_scale_check_script_output_format():
         assert m, l
         seen.append((m.group(1), int(m.group(2))))
         assert int(m.group(3)) > 0 and (int(m.group(2)) > 1 or float(m.group(4)) == 1.0)
-    assert seen == [(mode, k) for mode in ("weak", "strong") for k in (1, 2, 4, 8) if k <= n]
+    # weak (avenue), strong (stc, 16 384 windows), strong (seq24 = BASELINE configs[4], the designated scaling shape)
+    assert seen == [(mode, k) for mode in ("weak", "strong", "strong") for k in (1, 2, 4, 8) if k <= n]

@@ -7,12 +7,14 @@ cd "$(dirname "$0")/.." || exit 1
 STEPS=${1:-100}
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "# $NGPU GPU(s) visible"
-for mode in "weak --config avenue" "strong --config stc --batch 16384"; do
+# ... and the shape BASELINE names as the scaling run (configs[4]: seq_len 24, ns 50, 8 samples), strong: 32 768 windows per step
+# split over the ranks (0.36 s per 1024 windows per GPU: 3 steps)
+for mode in "weak --config avenue" "strong --config stc --batch 16384" "strong --config seq24 --batch 32768 --steps 3 --warmup 1"; do
   set -- $mode; scaling=$1; shift
   ref=""
   for n in 1 2 4 8; do
     [ "$n" -gt "$NGPU" ] && continue
-    line=$(timeout 600 python bench.py --gpus $n --steps $STEPS --warmup 10 --scaling $scaling "$@" --no-cpu-baseline --no-extras ${ref:+--ref-value $ref} | tail -1)
+    line=$(timeout 900 python bench.py --gpus $n --steps $STEPS --warmup 10 --scaling $scaling "$@" --no-cpu-baseline --no-extras ${ref:+--ref-value $ref} | tail -1)
     [ -z "$ref" ] && ref=$(echo "$line" | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
     echo "$line" | python -c "
 import sys, json
