@@ -59,7 +59,9 @@ __device__ __forceinline__ gfloat* as_global(const float* p) { return (gfloat*)p
 // rather re-derive it per use), constant byte offsets folded into the instruction's offset field
 typedef float __attribute__((address_space(3))) lds_float;
 typedef f32x4 __attribute__((address_space(3))) lds_f32x4;
-__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)(lds_float*)p; }
+// (the low half of a generic pointer into LDS IS its LDS address; an addrspacecast would add a null check per use -- and with
+// -amdgpu-sched-strategy=iterative-minreg one of those trips "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(uintptr_t)p; }
 __device__ __forceinline__ float4 lds_load4(unsigned addr) {
     const f32x4 v = *(lds_f32x4*)(uintptr_t)addr;
     return make_float4(v[0], v[1], v[2], v[3]);
@@ -579,6 +581,11 @@ struct MixCoef {
     }
 };
 
+// channel of a lane inside a mix unit: 16 x channel block (wave-uniform: stays on the scalar unit in address sums) + lane's channel
+struct ChIdx {
+    int cb16, j;
+    __device__ __forceinline__ operator int() const { return cb16 + j; }
+};
 // init functor of a mix whose accumulators start at zero (x + 0.f is not folded away: -0.0)
 struct ZeroInit { __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; } };
 // FORCE (kernels without a register cap): the unit's X reads are pinned in front of its arithmetic (the scheduler otherwise
@@ -592,15 +599,24 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
     // the X values of one unit: x[ks][t] = X[(n, t, joint of (ks, lane group))][channel cb*16 + j]
+    // Addresses: the unit's part (chain, channel block: wave-uniform) is summed on the scalar unit, the lane's part is ONE
+    // v_mad_u32_u24 (lane group x row stride + channel), the reads sit at instruction offsets from their sum.  Written as one
+    // product (n T V + voff) x stride the compiler multiplied per unit and rebuilt the sum on the VALU: 6 instructions per unit
+    // against 3 -- and integer VALU instructions cost the matrix pipe as much as floating-point ones (tools/ubench/mix_ceiling.hip)
     auto load_x = [&](int u, float (&x)[KS][T]) {
         const int rest = u / NQ;
         const int cb = rest % CB, n = rest / CB;
-        const float* xin_p = in + __mul24(n * T * V + voff_pair, cs_in) + cb * 16 + j;       // (small indices: full-rate 24-bit multiply)
-        const float* xin_l = in + __mul24(n * T * V + g, cs_in) + cb * 16 + j;
+        unsigned ua = lds_addr(in) + 4u * (unsigned)(n * (T * V) * cs_in + cb * 16);          // scalar unit
+        asm volatile("" : "+s"(ua));      // (opaque: the region's offset stays in this sum -- split off into the reads' offset fields it costs the first pair a re-basing add too)
+        const lds_float* ub = (const lds_float*)(uintptr_t)ua;
+        const lds_float* a_p = ub + (__mul24(voff_pair, cs_in) + j);
+        // the trailing unpaired k-step reads joints 4 KP + g.  At 17 joints only g = 0 names a joint (16): the other lane groups'
+        // coefficients are zero (pack_mix_mfma), so every group reads joint 16 and the lane's part is its channel alone
+        const lds_float* a_l = (V == 17) ? ub + j : ub + (__mul24(g, cs_in) + j);
         static_for<KS>([&](auto si) {
             constexpr int ks = decltype(si)::value;
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
-            const float* xb = ks < KP ? xin_p : xin_l;
+            const lds_float* xb = ks < KP ? a_p : a_l;
 #pragma unroll
             for (int t = 0; t < T; ++t) x[ks][t] = xb[(t * V + vbase) * cs_in];
         });
@@ -621,8 +637,8 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             for (int mt = 0; mt < MTM; ++mt)
                 if (M::RAGGED && q0 + qi >= T) {
                     acc[qi][mt] = f32x4{0.f, 0.f, 0.f, 0.f};      // (the frame behind a ragged chain's last: computed on zero coefficients, never stored)
-                } else if constexpr (std::is_invocable_v<Init, int, int, int, int, std::true_type>) {
-                    acc[qi][mt] = init(n, q0 + qi, mt * 16 + 4 * g, cb * 16 + j, std::true_type{});   // whole fragment (masks joints >= V)
+                } else if constexpr (std::is_invocable_v<Init, int, int, int, ChIdx, std::true_type>) {
+                    acc[qi][mt] = init(n, q0 + qi, mt * 16 + 4 * g, ChIdx{cb * 16, j}, std::true_type{});   // whole fragment (masks joints >= V)
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -659,8 +675,8 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             for (int mt = 0; mt < MTM; ++mt) {
                 // a store functor that takes the whole 4-joint fragment can issue all its LDS reads before its first
                 // write (row-by-row calls serialise: every write may alias the next row's reads)
-                if constexpr (std::is_invocable_v<Store, int, int, int, int, f32x4>) {     // (the functor masks joints >= V)
-                    store(n, q0 + qi, mt * 16 + 4 * g, cb * 16 + j, acc[qi][mt]);
+                if constexpr (std::is_invocable_v<Store, int, int, int, ChIdx, f32x4>) {     // (the functor masks joints >= V)
+                    store(n, q0 + qi, mt * 16 + 4 * g, ChIdx{cb * 16, j}, acc[qi][mt]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -675,9 +691,9 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                 const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
                 const float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]);
                 if constexpr (std::is_same_v<std::decay_t<Init>, ZeroInit>) {
-                    if (g == 0) store(n, q0 + qi, 16, cb * 16 + j, z16);
+                    if (g == 0) store(n, q0 + qi, 16, ChIdx{cb * 16, j}, z16);
                 } else {
-                    if (g == 0) store(n, q0 + qi, 16, cb * 16 + j, z16 + init(n, q0 + qi, 16, cb * 16 + j));
+                    if (g == 0) store(n, q0 + qi, 16, ChIdx{cb * 16, j}, z16 + init(n, q0 + qi, 16, cb * 16 + j));
                 }
             }
         }
@@ -777,14 +793,20 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
         const int u = wave + i * NWAVES;
         if (u < UNITS) {
             const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
-            const float* xin = in + __mul24(nt * VIN, cs_in) + cb * 16 + j;
+            // addresses: the unit's part on the scalar unit, the lane's part one v_mad, the k-steps at instruction offsets
+            // (see mix_stage's load_x)
+            const float* ub = in + (nt * VIN * cs_in + cb * 16);
+            const float* a_main = ub + (__mul24(CAPTURE ? 4 * g : 4 * (g & 1) + (g >> 1), cs_in) + j);
+            // the k-step behind the main ones: joints 16 + g (capture; only joint 16 exists: every lane group reads it, the
+            // others' weights are zero and their captured value is never used) or 4 KP + g
+            const float* a_tail = CAPTURE ? ub + j : ub + (__mul24(g, cs_in) + j);
             static_for<KS>([&](auto si) {
                 constexpr int ks = decltype(si)::value;
-                int row;
-                if (CAPTURE) row = ks < 4 ? 4 * g + ks : 16 + g;
-                else row = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) + 4 * (g & 1) + (g >> 1) : 4 * KP + g;
-                if constexpr (CAPTURE) skip[i * SK + ks] = xin[row * cs_in];
-                else xr[i][ks] = xin[row * cs_in];
+                constexpr bool MAIN = CAPTURE ? ks < 4 : ks < KP;
+                constexpr int row0 = CAPTURE ? (ks < 4 ? ks : 16) : (ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP);
+                const float xv = (MAIN ? a_main : a_tail)[row0 * cs_in];
+                if constexpr (CAPTURE) skip[i * SK + ks] = xv;
+                else xr[i][ks] = xv;
             });
         }
     });
@@ -800,7 +822,8 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
             if constexpr (SK == 5 && !J16) acc[MT - 1][0] += skip[i * SK + 4];   // joint 16: lane group g = 0, row 0 of m-tile 1
         }
-        float* zo = out + __mul24(nt * VOUT + 4 * g, cs_out) + cb * 16 + j;
+        float* uo = out + (nt * VOUT * cs_out + cb * 16);
+        float* zo = uo + (__mul24(4 * g, cs_out) + j);
 #pragma unroll
         for (int mt = 0; mt < MTM; ++mt)
 #pragma unroll
@@ -813,7 +836,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
             float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]) + bias[1][0];
             if constexpr (ADD && SK == 5) z16 += skip[i * SK + 4];          // captured by lane group g = 0 (k-step 4: joint 16 + g)
-            if (g == 0) out[__mul24(nt * VOUT + 16, cs_out) + cb * 16 + j] = z16;
+            if (g == 0) uo[16 * cs_out + j] = z16;
         }
     };
     if constexpr (ILP) {
@@ -878,7 +901,6 @@ struct Tiling {
     static constexpr int NG = MT > NWAVES ? 1 : NWAVES / MT;      // waves sharing one m-tile
     static constexpr int MAXN = (NT + NG - 1) / NG;
 };
-
 // One 16x16 output tile at a time: accumulate over K (Z part from b1, X part from b2), then hand the accumulator
 // fragment to `epi(i, col, c0, acc)` (i = static tile slot of this wave, col = column of this lane, c0 = first of the
 // lane's 4 consecutive output channels).  The output buffer never aliases b1/b2 (3-region plan), so the epilogue
@@ -1178,10 +1200,11 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 #endif
     mix_stage<CIN, V, T, NB, (FORCE && MCD_MIX_FORCE)>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
-                             [&](int n, int q, int w0, int c, auto v) {
+                             [&](int n, int q, int w0, ChIdx c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
-                                 // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store)
-                                 float* zp = z + __mul24(n * (T * V) + w0, CSI) + c + q * (V * CSI);      // (q = the unit's first frame + a constant: one address per unit, the frames at constant offsets)
+                                 // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store); the
+                                 // unit's part of the address on the scalar unit, the lane's part one v_mad (see load_x)
+                                 float* zp = (z + (n * (T * V) * CSI + q * (V * CSI) + c.cb16)) + (__mul24(w0, CSI) + c.j);
                                  if constexpr (std::is_same_v<decltype(v), f32x4>) {
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)

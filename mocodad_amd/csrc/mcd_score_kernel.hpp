@@ -535,15 +535,16 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);
             mix_stage<64, 10, T, NB, (MINW <= MCD_LOWOCC)>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
-                                     [&](int n, int q, int w0, int c, std::true_type) {   // the fragment's 4 joints at once
-                                         const float* pp = Pb + __mul24(n * (T * 10) + w0, 132) + 64 + c + q * (10 * 132);
+                                     [&](int n, int q, int w0, ChIdx c, std::true_type) {   // the fragment's 4 joints at once
+                                         // (address: the unit's part on the scalar unit + one v_mad for the lane's, see mix_stage)
+                                         const float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w0, 132) + c.j);
                                          // joints >= 10 read the next frame's rows (inside the 64-column region): an MFMA's D rows
                                          // are independent and those rows are never stored
                                          return f32x4{pp[0], pp[132], pp[264], pp[396]};
                                      },
-                                     [&](int n, int q, int w0, int c, f32x4 v) {
+                                     [&](int n, int q, int w0, ChIdx c, f32x4 v) {
                                          const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
-                                         float* pp = Pb + __mul24(n * (T * 10) + w0, 132) + 64 + c + q * (10 * 132);
+                                         float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w0, 132) + c.j);
                                          const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{bias, bias}, t1 = f32x2{v[2], v[3]} + f32x2{bias, bias};
                                          const f32x2 m0 = t0 * slope6, m1 = t1 * slope6;
                                          const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf6), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf6)} + f32x2{e, e};
