@@ -113,6 +113,7 @@ def main() -> None:
     defs = list(a.defines)
     if a.profile:
         defs.append("MCD_PROFILE")
+    fast_x = []
     if a.fast_t is not None:
         defs.append(f"MCD_FAST_T={a.fast_t}")
         # the shipped shape of that frame count (chains per workgroup, waves per SIMD, its unit's flags) unless given
@@ -121,14 +122,17 @@ def main() -> None:
         if sh:
             unit, nb, minw = sh
             for fl in unit_flags().get(unit, []):
-                if fl.startswith("-D") and fl[2:].split("=")[0] not in given:
-                    defs.append(fl[2:])
+                if fl.startswith("-D"):
+                    if fl[2:].split("=")[0] not in given:
+                        defs.append(fl[2:])
+                elif not a.xflags:            # the unit's other flags (e.g. its scheduler strategy) unless -X gives a set
+                    fast_x.append(fl)
             if "MCD_FAST_NB" not in given:
                 defs.append(f"MCD_FAST_NB={nb}")
             if "MCD_FAST_MINW" not in given and not any(d.split("=")[0] == "MCD_NWAVES" for d in a.defines):
                 defs.append(f"MCD_FAST_MINW={minw}")
     out = a.out or (os.path.join(HERE, "libmocodad_hip_prof.so") if a.profile else DEFAULT_OUT)
-    build_library(out, defs, extra_flags=a.xflags, force=a.force, jobs=a.jobs)
+    build_library(out, defs, extra_flags=list(a.xflags) + (fast_x if a.fast_t is not None else []), force=a.force, jobs=a.jobs)
 
 
 if __name__ == "__main__":

@@ -77,6 +77,9 @@ __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byt
 #ifndef MCD_NWAVES
 #define MCD_NWAVES 8
 #endif
+#ifndef MCD_XB32
+#define MCD_XB32 1      // 1: the mixes' X reads of the kernels without a register cap as single ds_read_b32 (mix_stage); 2: + their Z stores
+#endif
 constexpr int NWAVES = MCD_NWAVES;          // waves per workgroup (8; 16 is a tuning experiment)
 constexpr int NTHREADS = NWAVES * 64;
 constexpr int C0 = 2;        // num_coords
@@ -596,6 +599,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                                           Init&& init, Store&& store) {
     using M = MixCfg<CIN, V, T, NB>;
     constexpr int KS = M::KS, KP = M::KP, MT = M::MT, CB = M::CB, QC = M::QC, NQ = M::NQ, PER = M::PER;
+    constexpr bool XB32 = FORCE && MCD_XB32;
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
     // the X values of one unit: x[ks][t] = X[(n, t, joint of (ks, lane group))][channel cb*16 + j]
@@ -618,7 +622,13 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             constexpr int vbase = ks < KP ? 8 * (ks >> 1) + 2 * (ks & 1) : 4 * KP;
             const lds_float* xb = ks < KP ? a_p : a_l;
 #pragma unroll
-            for (int t = 0; t < T; ++t) x[ks][t] = xb[(t * V + vbase) * cs_in];
+            for (int t = 0; t < T; ++t) {
+                // XB32 (kernels whose reads are pinned anyway): single ds_read_b32 with 16-bit offsets.  The compiler pairs the reads
+                // into ds_read2_b32 (8-bit offsets) and re-bases the address with a v_add for all but the first pair: the same
+                // number of instructions, but the adds take VALU issue time, which is what the mixes of these kernels are bound by
+                if constexpr (XB32) x[ks][t] = ((const volatile lds_float*)xb)[(t * V + vbase) * cs_in];
+                else x[ks][t] = xb[(t * V + vbase) * cs_in];
+            }
         });
     };
     auto unit = [&](const MixCoef<CIN, V, T, NB>& cur, int u, const float (&xs)[KS][T]) {
@@ -703,13 +713,16 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         MixCoef<CIN, V, T, NB> cur = pre;
         static_for<PER>([&](auto ri) {
             constexpr int rnd = decltype(ri)::value;
-            const int u = M::unit_of(wave, rnd);
+            // (full rounds: every wave has a unit -- said at compile time in the kernels without a register cap; in the condition
+            // encoders' instantiations the same shortcut trips an "Unsupported instruction" abort of this compiler's backend)
+            constexpr bool ALLW = FORCE && !M::SAMEQ && M::UNITS == PER * NWAVES;
+            const int u = ALLW ? wave + rnd * NWAVES : M::unit_of(wave, rnd);
             float xs[KS][T];
             load_x(u < 0 ? 0 : u, xs);
             if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
             MixCoef<CIN, V, T, NB> nxt;
             if constexpr (rnd + 1 < PER && !M::SAMEQ && NQ > 1) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
-            if (u >= 0) unit(cur, u, xs);
+            if (ALLW || u >= 0) unit(cur, u, xs);       // (full rounds: every wave has a unit, said at compile time)
             if constexpr (rnd + 1 < PER && !M::SAMEQ && NQ > 1) cur = nxt;       // (one frame group: every unit has the same coefficients)
         });
     }
@@ -788,10 +801,12 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     // all the X reads of this wave's units first (for the down-samplers they ARE the skip registers): a unit's stores
     // may alias the next unit's reads, so reading inside the unit loop would serialise the units on LDS latency
     float xr[CAPTURE ? 1 : PER][CAPTURE ? 1 : KS] = {};      // (the down-samplers read straight into `skip`)
+    // (FULL: every wave has all PER units -- said at compile time, or the conditional reads cost a copy of the whole `skip` array per unit)
+    constexpr bool FULL = (CAPTURE || ADD) && UNITS == PER * NWAVES;      // (score_kernel's resamplers; the slab-tiled kernel's fused ones keep the run-time test, see DESIGN)
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
-        if (u < UNITS) {
+        if (FULL || u < UNITS) {
             const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
             // addresses: the unit's part on the scalar unit, the lane's part one v_mad, the k-steps at instruction offsets
             // (see mix_stage's load_x)
@@ -860,13 +875,13 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             });
         });
         static_for<PER>([&](auto pi) {
-            if (wave + decltype(pi)::value * NWAVES < UNITS) finish(pi, acc[decltype(pi)::value], part[decltype(pi)::value]);
+            if (FULL || wave + decltype(pi)::value * NWAVES < UNITS) finish(pi, acc[decltype(pi)::value], part[decltype(pi)::value]);
         });
     } else {
         static_for<PER>([&](auto pi) {
             constexpr int i = decltype(pi)::value;
             const int u = wave + i * NWAVES;
-            if (u < UNITS) {
+            if (FULL || u < UNITS) {
                 f32x4 acc[MTM];
                 float part = 0.f;
 #pragma unroll
@@ -1208,7 +1223,10 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
                                  if constexpr (std::is_same_v<decltype(v), f32x4>) {
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)
-                                         if (w0 + r < V) zp[r * CSI] = v[r];
+                                         if (w0 + r < V) {
+                                             if constexpr (FORCE && MCD_XB32 >= 2) ((volatile lds_float*)(uintptr_t)lds_addr(zp))[r * CSI] = v[r];     // (single ds_write_b32, see load_x)
+                                             else zp[r * CSI] = v[r];
+                                         }
                                  } else {
                                      *zp = v;
                                  }
