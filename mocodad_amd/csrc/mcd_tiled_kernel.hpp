@@ -385,7 +385,11 @@ __device__ __forceinline__ void tl_joint_mix(float* __restrict__ YZ, int cs, con
 // (Tiling<MT, NT>), K = 16 KQ1 (+ 16 KQ2) channels of the LDS operands b1 / b2 ([col][ch]); two tiles' MFMA chains in flight
 // with their B fragments one read ahead, as in gemm_tiles.  The accumulators stay with the caller: a layer with 64 or 128
 // input channels sums its 32-channel halves into them and runs its epilogue once.
-template <int MT, int NT, int KQ1, int KQ2, int O1, int O2, int NA>
+// FIRST: the accumulators start here, from zero (the first MFMA of a tile takes the literal 0 as its C operand).  Zeroed by the
+// caller instead, the accumulator of a tile slot this wave does not own was a phi of "zero" and "unchanged" at every wave-dependent
+// branch below, and the register allocator materialised those zeros: 3 - 5 moves per slot and part, a quarter of the GEMM
+// stages' non-MFMA instructions.  Left undefined, a slot the wave does not own is simply never read.
+template <int MT, int NT, int KQ1, int KQ2, int O1, int O2, bool FIRST = false, int NA>
 __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __restrict__ b1, int cs1, const float* __restrict__ b2,
                                           int cs2, int wave, int lane, f32x4 (&acc)[Tiling<MT, NT>::MAXN]) {
     constexpr int NG = Tiling<MT, NT>::NG, MAXN = Tiling<MT, NT>::MAXN, KQ = KQ1 + KQ2;
@@ -401,8 +405,10 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
         constexpr int p = decltype(pp)::value;
         if constexpr (p < NP) {
             constexpr int i0 = 2 * p, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
-            if (ng + i0 * NG < NT) nxt[0] = rd0(i0);
-            if (i1 != i0 && ng + i1 * NG < NT) nxt[1] = rd0(i1);
+            // (unconditional: a slot past the wave's last tile reads rows nobody uses -- LDS reads past the allocation return 0 --;
+            // conditional reads made `nxt` a phi of every wave-dependent branch below and cost 2 - 8 register-pair moves per pair)
+            nxt[0] = rd0(i0);
+            if (i1 != i0) nxt[1] = rd0(i1);
         }
     };
     auto chain = [&](auto nn, auto pp, auto ia, auto ib) {
@@ -428,8 +434,13 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
             __builtin_amdgcn_sched_barrier(0);
             f32x4& c0 = acc[i0];
             f32x4& c1 = acc[i1];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[0].x, c0, 0, 0, 0);
-            if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[1].x, c1, 0, 0, 0);
+            if constexpr (FIRST && kq == 0) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[0].x, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[1].x, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            } else {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[0].x, c0, 0, 0, 0);
+                if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, u[1].x, c1, 0, 0, 0);
+            }
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, u[0].y, c0, 0, 0, 0);
             if constexpr (N == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, u[1].y, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, u[0].z, c0, 0, 0, 0);
@@ -774,13 +785,10 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     TLMARK(4 * L);
                     auto gemm_fg = [&](int fg, f32x4 (&ac)[TI::MAXN]) {
                         const float* xg = Xl + fg * ROWSG * CSV;
-                        if (h == 0) {
-#pragma unroll
-                            for (int i = 0; i < TI::MAXN; ++i) ac[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                        if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH>(aq, ZA, CSZ, xg, CSV, wave, lane, ac);
-                        else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
-                        else gemm_part<MT, NT, KH, 0, h * KH, 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        // (part 0 starts the accumulators: gemm_part's FIRST)
+                        if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH, h == 0>(aq, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH, h == 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
+                        else gemm_part<MT, NT, KH, 0, h * KH, 0, h == 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
                         if constexpr (!RES) {             // identity residual: the tile's own 4 channels of x, when they lie in this half
                             if ((mt * 16) / CINV == h) {
                                 const float* xr = xg + __mul24(ng * 16 + (lane & 15), CSV) + c0 - h * CINV;
