@@ -593,7 +593,13 @@ struct ChIdx {
 struct ZeroInit { __device__ __forceinline__ float operator()(int, int, int, int) const { return 0.f; } };
 // FORCE (kernels without a register cap): the unit's X reads are pinned in front of its arithmetic (the scheduler otherwise
 // sinks each k-step's reads to their first use and the wave pays an LDS round trip per k-step)
-template <int CIN, int V, int T, int NB, bool FORCE = false, class Init, class Store>
+#ifndef MCD_ALLW_CAPPED
+#define MCD_ALLW_CAPPED 1      // (+1.3 % at 3 frames, +0.9 % at 6: profiles/r05l_capped_ab.txt) tuning: the compile-time "every wave has a unit" of ALLW in the register-capped trajectory kernels too
+#endif
+#ifndef MCD_RS_FULL
+#define MCD_RS_FULL 1          // tuning: resample_stage's FULL
+#endif
+template <int CIN, int V, int T, int NB, bool FORCE = false, bool SCORE = false, class Init, class Store>
 __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_in, const MixCoef<CIN, V, T, NB>& pre,
                                           const float* __restrict__ tqd, const float* __restrict__ af, int wave, int lane,
                                           Init&& init, Store&& store) {
@@ -715,14 +721,15 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             constexpr int rnd = decltype(ri)::value;
             // (full rounds: every wave has a unit -- said at compile time in the kernels without a register cap; in the condition
             // encoders' instantiations the same shortcut trips an "Unsupported instruction" abort of this compiler's backend)
-            constexpr bool ALLW = FORCE && !M::SAMEQ && M::UNITS == PER * NWAVES;
+            constexpr bool ALLW = (FORCE || (SCORE && MCD_ALLW_CAPPED)) && !M::SAMEQ && M::UNITS == PER * NWAVES;
             const int u = ALLW ? wave + rnd * NWAVES : M::unit_of(wave, rnd);
+            constexpr bool SURE = ALLW;       // (the SAMEQ map's first round gives every wave a unit as well: said too, -0.3 %, profiles/r05n_sameq_ab.txt)
             float xs[KS][T];
-            load_x(u < 0 ? 0 : u, xs);
+            load_x(SURE ? u : (u < 0 ? 0 : u), xs);
             if constexpr (FORCE) __builtin_amdgcn_sched_barrier(0);
             MixCoef<CIN, V, T, NB> nxt;
             if constexpr (rnd + 1 < PER && !M::SAMEQ && NQ > 1) nxt.load_unit(tqd, af, M::unit_of(wave, rnd + 1), lane);
-            if (ALLW || u >= 0) unit(cur, u, xs);       // (full rounds: every wave has a unit, said at compile time)
+            if (SURE || u >= 0) unit(cur, u, xs);       // (full rounds: every wave has a unit, said at compile time)
             if constexpr (rnd + 1 < PER && !M::SAMEQ && NQ > 1) cur = nxt;       // (one frame group: every unit has the same coefficients)
         });
     }
@@ -802,7 +809,7 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     // may alias the next unit's reads, so reading inside the unit loop would serialise the units on LDS latency
     float xr[CAPTURE ? 1 : PER][CAPTURE ? 1 : KS] = {};      // (the down-samplers read straight into `skip`)
     // (FULL: every wave has all PER units -- said at compile time, or the conditional reads cost a copy of the whole `skip` array per unit)
-    constexpr bool FULL = (CAPTURE || ADD) && UNITS == PER * NWAVES;      // (score_kernel's resamplers; the slab-tiled kernel's fused ones keep the run-time test, see DESIGN)
+    constexpr bool FULL = MCD_RS_FULL && (CAPTURE || ADD) && UNITS == PER * NWAVES;      // (score_kernel's resamplers; the slab-tiled kernel's fused ones keep the run-time test, see DESIGN)
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
         const int u = wave + i * NWAVES;
@@ -1213,7 +1220,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 #ifndef MCD_MIX_FORCE
 #define MCD_MIX_FORCE 1
 #endif
-    mix_stage<CIN, V, T, NB, (FORCE && MCD_MIX_FORCE)>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
+    mix_stage<CIN, V, T, NB, (FORCE && MCD_MIX_FORCE), HASEMB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
                              [&](int n, int q, int w0, ChIdx c, auto v) {
                                  // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the

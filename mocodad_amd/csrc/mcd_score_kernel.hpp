@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(10);
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);
-            mix_stage<64, 10, T, NB, (MINW <= MCD_LOWOCC)>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
+            mix_stage<64, 10, T, NB, (MINW <= MCD_LOWOCC), true>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w0, ChIdx c, std::true_type) {   // the fragment's 4 joints at once
                                          // (address: the unit's part on the scalar unit + one v_mad for the lane's, see mix_stage)
                                          const float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w0, 132) + c.j);
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope10 = lw.slope;
             const bool single = P.mode == 1, zadd = sidx > 1;
             const int e10_off = (sidx & 1) * 16;
-            mix_stage<16, 17, T, NB, (MINW <= MCD_LOWOCC)>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
+            mix_stage<16, 17, T, NB, (MINW <= MCD_LOWOCC), true>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      ZeroInit{},
                                      [&](int n, int t, int w0, int c, auto val) {     // whole 4-joint fragments: one address, 4 stores
                                          if (c < C0) {
