@@ -46,6 +46,44 @@ def shipped_shape(t: int):
     return None
 
 
+_MLLVM_OK = {}
+
+
+def usable_flags(flags: List[str]) -> List[str]:
+    """`-mllvm <opt>` pairs name INTERNAL LLVM options (the scheduler strategy of units 3 / 23): probe each pair once on an empty
+    device file and drop it, with a warning, if this hipcc does not know it -- the library then builds with the default strategy
+    (same results, the tuned kernels a few per cent slower) instead of not building at all."""
+    out, i = [], 0
+    while i < len(flags):
+        if flags[i] == "-mllvm" and i + 1 < len(flags):
+            opt = flags[i + 1]
+            if opt not in _MLLVM_OK:
+                p = subprocess.run([HIPCC, "--offload-arch=gfx950", "--cuda-device-only", "-x", "hip", "-c", "/dev/null", "-o", os.devnull,
+                                    "-mllvm", opt], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                _MLLVM_OK[opt] = p.returncode == 0
+                if not _MLLVM_OK[opt]:
+                    print(f"warning: {HIPCC} rejects '-mllvm {opt}': building without it", file=sys.stderr)
+            if _MLLVM_OK[opt]:
+                out += ["-mllvm", opt]
+            i += 2
+        else:
+            out.append(flags[i]); i += 1
+    return out
+
+
+def _compile(cmd: List[str], obj: str) -> float:
+    """Compile into a private temporary and rename it into place: concurrent builds (several ranks calling build() at once)
+    never see, or link, a half-written object."""
+    tmp = obj + ".tmp%d" % os.getpid()
+    try:
+        dt = _run(cmd + ["-o", tmp])
+        os.replace(tmp, obj)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return dt
+
+
 def sources() -> List[str]:
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [HEADER]
 
@@ -66,7 +104,7 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
     defines = list(defines)
     flags = BASE_FLAGS + ["-D" + d for d in defines] + list(extra_flags)
     tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
-    obj_dir = obj_dir or os.path.join(CSRC, "_obj", tag)
+    obj_dir = os.path.join(obj_dir, tag) if obj_dir else os.path.join(CSRC, "_obj", tag)      # (the flag set is part of the path)
     os.makedirs(obj_dir, exist_ok=True)
     # an object depends on its own .hip, every header of csrc and the public header (not on the other .hip)
     hdr_m = max(os.path.getmtime(p) for p in sources() if not p.endswith(".hip"))
@@ -74,7 +112,7 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
     fast = any(d.split("=")[0] == "MCD_FAST_T" for d in defines)
     units = [1] if fast else list(range(1, n_units() + 1))
     jobs_l = [("mcd_api.o", os.path.join(CSRC, "mcd_api.hip"), [])]
-    uf = {} if fast else unit_flags()      # (developer builds take their flags from the command line / main())
+    uf = {} if fast else {u: usable_flags(f) for u, f in unit_flags().items()}      # (developer builds: command line / main())
     jobs_l += [(f"mcd_inst_{u}.o", os.path.join(CSRC, "mcd_inst.hip"), [f"-DMCD_INST_UNIT={u}"] + uf.get(u, [])) for u in units]
     todo = [(o, s, f) for o, s, f in jobs_l
             if force or not os.path.exists(os.path.join(obj_dir, o)) or os.path.getmtime(os.path.join(obj_dir, o)) < newest(s)]
@@ -84,7 +122,7 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
         if verbose:
             print(f"+ {HIPCC} {' '.join(flags)} -c  x {len(todo)} translation units, {workers} at a time", flush=True)
         with cf.ThreadPoolExecutor(max_workers=workers) as ex:
-            futs = {ex.submit(_run, [HIPCC] + flags + f + ["-c", s, "-o", os.path.join(obj_dir, o)]): o for o, s, f in todo}
+            futs = {ex.submit(_compile, [HIPCC] + flags + f + ["-c", s], os.path.join(obj_dir, o)): o for o, s, f in todo}
             for fu in cf.as_completed(futs):
                 dt = fu.result()
                 if verbose:
@@ -132,7 +170,7 @@ def main() -> None:
             if "MCD_FAST_MINW" not in given and not any(d.split("=")[0] == "MCD_NWAVES" for d in a.defines):
                 defs.append(f"MCD_FAST_MINW={minw}")
     out = a.out or (os.path.join(HERE, "libmocodad_hip_prof.so") if a.profile else DEFAULT_OUT)
-    build_library(out, defs, extra_flags=list(a.xflags) + (fast_x if a.fast_t is not None else []), force=a.force, jobs=a.jobs)
+    build_library(out, defs, extra_flags=usable_flags(list(a.xflags) + (fast_x if a.fast_t is not None else [])), force=a.force, jobs=a.jobs)
 
 
 if __name__ == "__main__":
