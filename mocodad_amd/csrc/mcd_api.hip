@@ -11,6 +11,12 @@
 
 #include "mcd_launch.hpp"
 
+#if MCD_NWAVES != 8
+#error "mcd_api.hip is built with the default wave count: per-unit wave counts belong to mcd_inst.hip (MCD_UNIT_FLAGS_<n>)"
+#endif
+namespace { constexpr int API_THREADS = 512; }      // block size of this file's own kernels
+#pragma GCC poison NWAVES NTHREADS                  // (translation-unit constants of the kernel units: see mcd_launch.hpp)
+
 using namespace mcd;
 
 namespace {
@@ -802,7 +808,7 @@ int launch_score(const mcd_weights* w, int T, ScoreParams& P, hipStream_t st, bo
 #ifdef MCD_TUNING_VARIANTS  // alternative workgroup shapes (MCD_OPT_VARIANT), developer builds only
     const int variant = w->opt[MCD_OPT_VARIANT];
     if (T == 3 && variant == 1) return launch_score_t<3, 4, 2>(P, st, fused);   // 4 chains / WG, 1 WG per CU
-    if (T == 3 && variant == 3) return launch_score_t<3, 1, 4>(P, st, fused);   // 1 chain / WG (with MCD_NWAVES=4)
+    if (T == 3 && variant == 3) return launch_score_t<3, 1, 4>(P, st, fused);   // 1 chain / WG (tuning variant)
     if (T == 3 && variant == 2) return launch_score_t<3, 2, 2>(P, st, fused);   // the default shape without the register cap
     if (T == 6 && variant == 1) return launch_score_t<6, 2, 2>(P, st, fused);   // 2 chains / WG, 1 WG per CU (no register cap)
 #else
@@ -960,9 +966,9 @@ static unsigned long long* g_prof = nullptr;  // MCD_PROFILE builds: device buff
 
 // test aid (mcd_debug_poison_lds): every CU's LDS filled with signalling garbage (NaN bit patterns), so that a kernel reading
 // shared memory it never wrote produces NaNs instead of depending on what the previous kernel happened to leave there
-__global__ __launch_bounds__(NTHREADS) void poison_lds_kernel(unsigned* sink, int words) {
+__global__ __launch_bounds__(API_THREADS) void poison_lds_kernel(unsigned* sink, int words) {
     extern __shared__ unsigned psm[];
-    for (int u = threadIdx.x; u < words; u += NTHREADS) psm[u] = 0x7fc00000u | (unsigned)u;
+    for (int u = threadIdx.x; u < words; u += API_THREADS) psm[u] = 0x7fc00000u | (unsigned)u;
     __syncthreads();
     if (threadIdx.x == 0 && sink) atomicOr(sink, psm[(blockIdx.x * 7919) % words] & 1u);      // (keeps the stores alive)
     __builtin_amdgcn_s_sleep(64);
@@ -978,7 +984,7 @@ int mcd_debug_poison_lds(void* stream) {
     constexpr size_t lds = 160 * 1024;
     LDS_LIMIT(poison_lds_kernel, lds);
     // one 160 KB workgroup per CU at a time; several waves of them so that every CU of every XCD takes at least one
-    hipLaunchKernelGGL(poison_lds_kernel, dim3(4096), dim3(NTHREADS), lds, static_cast<hipStream_t>(stream), (unsigned*)nullptr, (int)(lds / 4));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(4096), dim3(API_THREADS), lds, static_cast<hipStream_t>(stream), (unsigned*)nullptr, (int)(lds / 4));
     HIP_TRY(hipGetLastError());
     return MCD_OK;
 }

@@ -95,8 +95,21 @@ inline int choose_split(int n_groups, int S, int slots) {
     return S > 1 && chain_major < window_major ? S : 1;
 }
 
+// NWAVES / NTHREADS are constants of the TRANSLATION UNIT (-DMCD_NWAVES of a unit's flags, mcd_instances.hpp), and Plan, MixCfg,
+// Tiling, TlStage and the kernels depend on them: every kernel and launcher is instantiated in exactly one unit (the others see
+// `extern template`), the launchers below refuse to be instantiated with another wave count than the shipped one of their
+// frame count, and mcd_api.hip -- which is built with the default and only CALLS launchers -- poisons the two names.
+constexpr int shipped_waves_score(int t) { return t >= 9 && t <= 12 ? 12 : 8; }
+constexpr int shipped_waves_tiled(int tp) { return tp > 16 ? 12 : 8; }
+#if defined(MCD_FAST_T) || defined(MCD_ANY_NWAVES)      // developer builds measure other wave counts
+#define MCD_WAVES_CHECK(expected) static_assert(true, "")
+#else
+#define MCD_WAVES_CHECK(expected) static_assert(NWAVES == (expected), "this unit's MCD_NWAVES is not the wave count the kernel ships with (MCD_UNIT_FLAGS_<n> in mcd_instances.hpp)")
+#endif
+
 template <int T, int NB, int MINW, bool LT = false>
 int launch_score_t(ScoreParams& P, hipStream_t st, bool* fused) {
+    MCD_WAVES_CHECK(shipped_waves_score(T));
     using PL = Plan<T, NB>;
     LDS_LIMIT((&score_kernel<T, NB, MINW, LT>), PL::BYTES);
     static std::atomic<int> slots_cache[64];
@@ -162,6 +175,7 @@ constexpr int tl_nb(int TP) { return TP <= 16 ? MCD_TL16_NB : 1; }
 constexpr int tl_wgs_per_cu(int TP) { return TP * tl_nb(TP) <= 16 ? 2 : 1; }
 template <int TP, int NB, bool LT = false, bool COND = false>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
+    MCD_WAVES_CHECK(COND ? NWAVES : shipped_waves_tiled(TP));      // (the COND form -- the 'E_unet' encoder on the tiled stages -- runs on eight or twelve)
     constexpr int TF = TP * NB;
     constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS) * 4;
     LDS_LIMIT((&score_tiled_kernel<TP, NB, LT, COND>), lds);
