@@ -11,7 +11,7 @@
 
 #include "mcd_launch.hpp"
 
-#if MCD_NWAVES != 8
+#if MCD_NWAVES != 8 && !defined(MCD_FAST_T)      // (developer builds pass one flag set to every file)
 #error "mcd_api.hip is built with the default wave count: per-unit wave counts belong to mcd_inst.hip (MCD_UNIT_FLAGS_<n>)"
 #endif
 namespace { constexpr int API_THREADS = 512; }      // block size of this file's own kernels

@@ -69,6 +69,10 @@ __device__ __forceinline__ float4 lds_load4(unsigned addr) {
 __device__ __forceinline__ void lds_store4(unsigned addr, float a, float b, float c, float d) {
     *(lds_f32x4*)(uintptr_t)addr = f32x4{a, b, c, d};
 }
+typedef f32x4 __attribute__((address_space(1))) gf32x4_rw;
+__device__ __forceinline__ void store_global4(float* p, float4 v) {    // 16-byte aligned global store (global_store, not flat_store:
+    *(gf32x4_rw*)p = f32x4{v.x, v.y, v.z, v.w};                        // a flat access ticks lgkmcnt as well as vmcnt)
+}
 __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byte aligned global load
     const f32x4 v = *(gf32x4*)p;
     return make_float4(v[0], v[1], v[2], v[3]);
@@ -1423,6 +1427,12 @@ __device__ __forceinline__ void emb_compute(const EmbRow& f, const float* __rest
 
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
 // tables.  Sizes follow the padded column counts P17/P12/P10 and the row strides C+4.
+#ifndef MCD_LSTASH1
+#define MCD_LSTASH1 0       // registers of d1 ...
+#endif
+#ifndef MCD_LSTASH2
+#define MCD_LSTASH2 4       // ... and of d2 parked in LDS between the down- and the up-sampler (12 frames, twelve waves)
+#endif
 template <int T, int NB>
 struct Plan {
     static constexpr int NBT = NB * T;
@@ -1466,7 +1476,14 @@ struct Plan {
 #else
     static constexpr int PROF = 0;
 #endif
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + EXW + PROF;
+    // 12 frames on twelve waves: skip-tensor registers parked in the LDS the plan leaves free (score_kernel, "LDS stash")
+#if defined(MCD_PROFILE)
+    static constexpr int LSTASH = 0;            // (the profile build's time stamps take that room)
+#else
+    static constexpr int LSTASH = (T == 12 && NB == 1 && NWAVES == 12) ? (MCD_LSTASH1 + MCD_LSTASH2) * NTHREADS : 0;
+#endif
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + EXW + PROF + LSTASH;
+    static_assert((size_t)TOTAL * 4 <= 160 * 1024, "LDS plan: more than 160 KB");
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };
 

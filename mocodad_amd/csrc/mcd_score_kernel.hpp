@@ -275,6 +275,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     float stash1_mem[STASH1 ? RS1::PER * RS1::SK : 1];
     float stash2_mem[STASH2 ? RS2::PER * RS2::SK : 1];
     typedef float __attribute__((address_space(5))) priv_float;         // (explicit private address space: scratch_*, not flat_*)
+    // 12 frames on twelve waves (168 registers): the 26 skip registers do not all fit beside the 128-channel layers' fragments,
+    // and the allocator's own answer was 5 of them in scratch inside the step loop (write-through: 7 GB per launch).  The plan
+    // leaves 14.8 KB of LDS free there: 4 registers x 768 lanes, one ds_write_b32 / ds_read_b32 each at lane-linear addresses.
+    constexpr int LS1 = (!LT && PL::LSTASH > 0) ? MCD_LSTASH1 : 0, LS2 = (!LT && PL::LSTASH > 0) ? MCD_LSTASH2 : 0;
+    static_assert(LS1 <= RS1::PER * RS1::SK && LS2 <= RS2::PER * RS2::SK, "LDS stash: more registers than the skip tensor has");
+    float* const LST = EXW + PL::EXW + PL::PROF;
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
@@ -465,6 +471,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS1::PER * RS1::SK; ++i) sp[i] = skip1[i];
         }
+#pragma unroll
+        for (int i = 0; i < LS1; ++i) LST[i * NTHREADS + tid] = skip1[i];
         wearly(A3, MCD_LC(3));
         bsync();
         STAGE(5);
@@ -491,6 +499,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS2::PER * RS2::SK; ++i) sp[i] = skip2[i];
         }
+#pragma unroll
+        for (int i = 0; i < LS2; ++i) LST[(LS1 + i) * NTHREADS + tid] = skip2[i];
         // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
         wearly(A5, MCD_LC(5));
@@ -559,6 +569,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS2::PER * RS2::SK; ++i) skip2[i] = sp[i];
         }
+#pragma unroll
+        for (int i = 0; i < LS2; ++i) skip2[i] = LST[(LS1 + i) * NTHREADS + tid];
         if constexpr (!EARLY2) rs_early(rc3, 2);
         if constexpr (!FUSE64) bsync();     // aligned: up3 reads only this wave's own layer-6 output block
         STAGE(11);
@@ -594,6 +606,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
                                     for (int i = 0; i < RS1::PER * RS1::SK; ++i) skip1[i] = sp[i];
                                 }
+#pragma unroll
+                                for (int i = 0; i < LS1; ++i) skip1[i] = LST[i * NTHREADS + tid];
                             }, WEARLY ? &A8 : nullptr);                                            // su4.1
         STAGE(14);
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);

@@ -47,6 +47,9 @@ __host__ __device__ constexpr long long tl_slab_floats(int TP) {
     return (long long)2 * (TP * 10 + 16) * 132 + (long long)(TP * 17 + 16) * 36 + (long long)(TP * 12 + 16) * 68;
 }
 
+#ifndef MCD_TL_LATE
+#define MCD_TL_LATE 1      // the next part's slab loads go out right before the current part's channel GEMM (see `layer`)
+#endif
 // cooperative copies between the slab and LDS, `ch` channels (multiple of 4) from channel ch0 of `rows` rows
 __device__ __forceinline__ void tl_g2l(float* dst, int ds, const float* src, int ss, int ch0, int ch, int rows) {
     const int q = ch >> 2;
@@ -61,11 +64,14 @@ template <int ROWS, int CH>
 struct TlStage {
     static constexpr int Q = CH / 4, N = (ROWS * Q + NTHREADS - 1) / NTHREADS;
     float4 v[N];
+    // (unconditional: a slot past the end re-reads the last one.  Conditional loads make the NUMBER of loads in flight depend on
+    // the path, and every later wait for an older load -- a weight fragment fetched before them -- then has to assume none were
+    // issued: s_waitcnt vmcnt(0), i.e. it waits for these slab loads as well)
     __device__ __forceinline__ void issue(int tid, const float* src, int ss, int ch0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int u = tid + i * NTHREADS;
-            if (u < ROWS * Q) { const int r = u / Q, c = (u - r * Q) * 4; v[i] = load_global4(src + (size_t)r * ss + ch0 + c); }
+            const int u0 = tid + i * NTHREADS, u = (MCD_TL_LATE && u0 >= ROWS * Q) ? ROWS * Q - 1 : u0;
+            if (MCD_TL_LATE || u < ROWS * Q) { const int r = u / Q, c = (u - r * Q) * 4; v[i] = load_global4(src + (size_t)r * ss + ch0 + c); }
         }
     }
     __device__ __forceinline__ void commit(int tid, float* dst, int ds) const {
@@ -461,11 +467,19 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
 
 // profile builds (tools/tiled_stage_profile.py): lane 0 of waves 0 and 7 of workgroup 0 add the cycles since their previous
 // mark to slot 2048 (+ 64 for wave 7) + id of the profile buffer
+#ifndef MCD_TL_ONECHUNK
+#define MCD_TL_ONECHUNK 1
+#endif
 #ifdef MCD_PROFILE
+// ... and lane 0 of EVERY wave of workgroup 0 stamps the events of ONE pass (the third of its first chain): event e of wave w at
+// slot 4096 + 16 e + w, the event's id at 4096 + 8192 + e (TLTR: a trace-only event)
+#define TLTR(id) do { if (tl_tron) { P.prof[4096 + 16 * tl_ev + (tid0 >> 6)] = __builtin_readcyclecounter(); \
+    if (tid0 == 0) P.prof[4096 + 8192 + tl_ev] = (id); } ++tl_ev; } while (0)
 #define TLMARK(id) do { if (tl_prof) { const unsigned long long t_ = __builtin_readcyclecounter(); \
-    atomicAdd(P.prof + 2048 + (tid0 ? 64 : 0) + (id), t_ - tl_last); tl_last = t_; } } while (0)
+    atomicAdd(P.prof + 2048 + (tid0 ? 64 : 0) + (id), t_ - tl_last); tl_last = t_; } TLTR(id); } while (0)
 #else
 #define TLMARK(id) do { } while (0)
+#define TLTR(id) do { } while (0)
 #endif
 // the kernel's argument list as the kernarg segment lays it out (arguments in order at their natural alignment = C struct
 // layout): the per-layer table offsets of TiledNet are read through a pointer into the segment that is made opaque per step and
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
     float* const ZO = ZN + R17 * C0;                // [R17][2]  layer 10's mixed output
     float* const P4 = ZO + R17 * C0;                // [R17 + 16][4]  layer 10's W-first product (+ zero pad rows: its mix reads 16-channel blocks)
     float* const RED = P4 + (R17 + 16) * 4;         // [NTHREADS]
+    float* const W4L = RED + NTHREADS;              // [4][32]  layer 10's W-first weights [W_t; W_r] (constant over the launch)
     const int tid0 = threadIdx.x;
     int tid = tid0, lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,12 +525,15 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #ifdef MCD_PROFILE
     const bool tl_prof = P.prof && blockIdx.x == 0 && (tid0 == 0 || tid0 == NTHREADS - 64);
     unsigned long long tl_last = __builtin_readcyclecounter();
+    bool tl_tron = false;
+    int tl_ev = 0, tl_pass = 0;
 #endif
     float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TF);
     const int Tx = P.n_corrupt, K = P.ns > 2 ? P.ns - 1 : 1, per = C0 * Tx * 17;
     for (int u = tid; u < (int)tl_slab_floats(TF); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
     for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
     if (tid < 64) P4[R17 * 4 + tid] = 0.f;
+    if (!COND && tid < 128) W4L[tid] = P.wbuf[N.wp[10] + tid];
     for (int u = tid; u < RA_F; u += NTHREADS) RA[u] = 0.f;           // pad rows meet zero coefficients: they must be finite
 
     for (long long grp = blockIdx.x; grp * NB < P.n_chains; grp += gridDim.x) {
@@ -548,6 +566,11 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
         const int i_first = COND ? 0 : P.mode == 1 ? P.step_single : P.ns - 1, i_last = COND ? 0 : P.mode == 1 ? P.step_single : 1;
         for (int sidx = i_first; sidx >= i_last; --sidx) {
             const float* srow = P.step_table + sidx * (4 + EDIM);
+#ifdef MCD_PROFILE
+            tl_tron = P.prof && blockIdx.x == 0 && (tid0 & 63) == 0 && tl_pass == 2;
+            tl_ev = 0;
+            ++tl_pass;
+#endif
             // opaque per step (see score_kernel): otherwise every per-lane address of every stage is hoisted out of the step
             // loop as loop-invariant and the hundreds of resulting registers are spilled
             tid = tid0;
@@ -607,8 +630,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             __syncthreads();
             for (int u = tid; !COND && u < NB * EMB_TOTAL; u += NTHREADS) {
                 const int i = u / EMB_TOTAL, o = u % EMB_TOTAL;
-                const float* we = wb + Ns->we + o * EDIM;
-                float a = wb[Ns->be + o];
+                gfloat* we = as_global(wb + Ns->we + o * EDIM);
+                float a = as_global(wb)[Ns->be + o];
 #pragma unroll
                 for (int k = 0; k < EDIM; ++k) a = fmaf(we[k], SE[i * EDIM + k], a);
                 EMB[i * EMBS + o] = a;
@@ -690,25 +713,42 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                         __syncthreads();
                     }
                 }
+                // (profile builds: the X staging of layers 3 .. 9 split further -- slot 40 + 2 (L - 3): the wait for the other waves'
+                // previous stage; + 1: the wait for the loads issued a stage ahead + their LDS stores)
+#define TLXMARK(k) do { if constexpr (L >= 3) TLMARK(40 + 2 * (L - 3) + (k)); } while (0)
                 float* const XA = RA;                                          // [ROWS + 16][CSV]
                 float* const ZA = RA + (ROWS + 16) * (L <= 1 ? 36 : CSZ);      // [ROWSG + 16][CSZ]  (layer 0: behind the next layer's X)
                 TlStage<ROWS, CINV> sx;                // plain input: a 32-channel part of all frames; resampled input: the skip rows
                 constexpr int IR = TL_FC * VIN, OR = TL_FC * V;
-                TlStage<RSI >= 0 ? IR : 1, 32> si;     // resampled input: a chunk of the resampler's input rows
+                // resampled input: a chunk of the resampler's input rows -- or, behind a layer that hands its output over in LDS (HIR: the
+                // z region holds the resampler's input of ALL frames), every later 32-channel part whole as well: its loads are issued a
+                // whole part ahead, where a part's second chunk was fetched under the first chunk's 300-cycle resampling (its latency
+                // to the slab exposed, plus two barriers per chunk)
+                constexpr bool ONE = HIR && MCD_TL_ONECHUNK;
+                TlStage<RSI >= 0 ? (ONE ? NFC * IR : IR) : 1, 32> si;
                 RsCoef<32, VIN, V, TL_FC, 1, false> rc;
                 if constexpr (RSI >= 0) {
                     static_assert(!HIR || NH >= 2, "");
                     static_assert(!HIC || (NH == 1 && NFC == 2), "");
+                    // Vector-memory loads return IN ORDER: a wait for any load also waits for every older one.  The slab loads are the
+                    // slow ones (the slabs of an XCD's workgroups are 13 MB against 4 MB of L2), so nothing that is needed early may
+                    // be issued behind them: the coefficient fetches go first, and (MCD_TL_LATE) a later part's slab loads only go out
+                    // right before the current part's channel GEMM -- the mix stages fetch their later units' coefficients in place
+                    // and wait for them with vmcnt(0); issued in front of the mixes, as they were, the slab loads' whole latency sat
+                    // in every time mix.
+                    if constexpr (MCD_TL_LATE) rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     if constexpr (HIC) si.issue(tid, xin + (size_t)IR * CSI, CSI, 0);      // (chunk 0 is in the z region already)
-                    else si.issue(tid, xin, CSI, HIR ? CINV : 0);   // (HIR: part 0 is in the z region already, all chunks of it)
-                    rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
-                    if (skip) sx.issue(tid, skip, CSI, 0);
+                    else if constexpr (!(MCD_TL_LATE && HIR)) si.issue(tid, xin, CSI, HIR ? CINV : 0);   // (HIR: part 0 is in the z region already, all chunks of it)
+                    if constexpr (!MCD_TL_LATE) rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                    static_assert(RSI < 0 || HIC || HIR, "");
                 } else if (!xin_lds && !HI17) {
                     static_assert(!HI || (RSI < 0 && NH >= 2), "");
-                    sx.issue(tid, xin, CSI, HI ? CINV : 0);
+                    static_assert(!MCD_TL_LATE || HI || HI17 || L == 0, "a plain layer's first part comes through LDS (hand-over), the later ones are fetched behind the GEMMs");
+                    if constexpr (!MCD_TL_LATE) sx.issue(tid, xin, CSI, HI ? CINV : 0);
                 }
                 float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
                 tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, 0);
+                if constexpr (RSI >= 0) { if (skip) sx.issue(tid, skip, CSI, 0); }
                 // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
                 constexpr bool AQ = NH > 2;
                 constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
@@ -736,21 +776,34 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #pragma unroll
                             for (int fc = 0; fc < NFC; ++fc)
                                 resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA + fc * IR * CSZ, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                        } else if constexpr (ONE) {
+                            __syncthreads();              // (the previous part is done with XA and the z region)
+                            TLXMARK(0);
+                            si.commit(tid, ZA, CSZ);
+                            TLXMARK(1);
+                            __syncthreads();
+                            if constexpr (h + 1 < NH && !MCD_TL_LATE) si.issue(tid, xin, CSI, (h + 1) * CINV);
+#pragma unroll
+                            for (int fc = 0; fc < NFC; ++fc)
+                                resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA + fc * IR * CSZ, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
                         } else {
 #pragma unroll
                             for (int fc = 0; fc < NFC; ++fc) {
                                 if (!(HIC && fc == 0)) {
                                     __syncthreads();      // (the previous stage / part / chunk is done with XA and the chunk region)
+                                    TLXMARK(0);
                                     si.commit(tid, ZA, CSZ);
+                                    TLXMARK(1);
                                     __syncthreads();
                                     if (!HIC && fc + 1 < NFC) si.issue(tid, xin + (size_t)(fc + 1) * IR * CSI, CSI, h * CINV);
-                                    else if constexpr (h + 1 < NH) si.issue(tid, xin, CSI, (h + 1) * CINV);
+                                    else if constexpr (h + 1 < NH && !MCD_TL_LATE) si.issue(tid, xin, CSI, (h + 1) * CINV);
                                 }
                                 resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
                             }
                         }
                         if (skip) {                       // + the U-Net skip (d2 / d1), this part's channels
                             __syncthreads();
+                            TLMARK(4 * L);
 #pragma unroll
                             for (int i = 0; i < decltype(sx)::N; ++i) {
                                 const int u = tid + i * NTHREADS;
@@ -760,7 +813,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                                     *xp = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
                                 }
                             }
-                            if constexpr (h + 1 < NH) sx.issue(tid, skip, CSI, (h + 1) * CINV);
+                            TLXMARK(1);
+                            if constexpr (h + 1 < NH && !MCD_TL_LATE) sx.issue(tid, skip, CSI, (h + 1) * CINV);
                         }
                         Xl = XA;
                     } else if (HI17) {
@@ -768,8 +822,10 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     } else if (!xin_lds) {
                         if constexpr (!(HI && h == 0)) {  // (HI: part 0 is in XA already, part 1 on its way)
                             __syncthreads();              // (the previous stage / half is done with XA)
+                            TLXMARK(0);
                             sx.commit(tid, XA, CSV);
-                            if constexpr (h + 1 < NH) sx.issue(tid, xin, CSI, (h + 1) * CINV);
+                            TLXMARK(1);
+                            if constexpr (h + 1 < NH && !MCD_TL_LATE) sx.issue(tid, xin, CSI, (h + 1) * CINV);
                         }
                         Xl = XA;
                     }
@@ -781,6 +837,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                             aq[KH + k] = load_global4(wfr + (CIN / 16 + h * KH + k) * 256);
                         }
                     }
+                    TLTR(180 + L);
                     __syncthreads();
                     TLMARK(4 * L);
                     auto gemm_fg = [&](int fg, f32x4 (&ac)[TI::MAXN]) {
@@ -817,7 +874,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                                 const float4 o = make_float4(__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf) + e.x, __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf) + e.y,
                                                              __builtin_amdgcn_fmed3f(t1[0], m1[0], pinf) + e.z, __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf) + e.w);
                                 if (HO17 || (HO && mt < 2)) *reinterpret_cast<float4*>(XA + gcol * 36 + c0) = o;
-                                else *reinterpret_cast<float4*>(xout + (size_t)gcol * CSO + c0) = o;      // (layer 4's is the skip d2 as well)
+                                else store_global4(xout + (size_t)gcol * CSO + c0, o);      // (layer 4's is the skip d2 as well)
                                 if (HOR && mt < 2) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
                                 if (HOC && gcol < TL_FC * V) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
                             }
@@ -856,15 +913,29 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                             tl_joint_fetch<V, TP, NB, FS>(aja, wb + Nl->am[L], wave, lane, fg);
                             tl_time_mix<CINV, V, TP, NB, FS>(Xl, CSV, ZA, CSZ, wb + Nl->tqm[L], wave, lane, fg, tqa);
                             if (fg + 1 < FS || h + 1 < NH) tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, fg + 1 < FS ? fg + 1 : 0);
+                            TLTR(100 + L);
                             __syncthreads();
+                            TLTR(120 + L);
                             tl_joint_mix<CINV, V, TP, NB, FS>(ZA, CSZ, wb + Nl->am[L], wave, lane, fg, aja);
                             TLMARK(4 * L + 1);
                             __syncthreads();
                             TLMARK(4 * L + 2);
+                            if constexpr (MCD_TL_LATE && h + 1 < NH) {      // the next part's slab loads: in flight behind this part's GEMM
+                                if (fg == FS - 1) {
+                                    if constexpr (RSI >= 0) {
+                                        si.issue(tid, xin, CSI, (h + 1) * CINV);
+                                        if (skip) sx.issue(tid, skip, CSI, (h + 1) * CINV);
+                                    } else if (!xin_lds && !HI17) {
+                                        sx.issue(tid, xin, CSI, (h + 1) * CINV);
+                                    }
+                                }
+                            }
                             gemm_fg(fg, acc);
                             if constexpr (h == NH - 1) {
                                 static_assert(!(HO || HOR) || (FS == 1 && CSV == 36), "");
+                                TLTR(140 + L);
                                 if constexpr (HO || HOR || L == 8) __syncthreads();    // (every wave is done with XA / z: the m-tiles 0, 1 go there)
+                                TLTR(160 + L);
                                 epi_fg(fg, acc);
                             }
                             if (fg + 1 < FS) __syncthreads();  // (the next group's mix overwrites z)
@@ -935,7 +1006,9 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 constexpr int QC10 = TF <= 16 ? MCD_TL_QC10 : 0;
                 MixLongCoef<16, 17, TP, NB, QC10> mc10;      // (the mix's first coefficients: in flight behind the product)
                 mc10.load(wb + Ns->tq[10], wb + Ns->am[10], wave, lane);
-                const float* w4 = wb + Ns->wp[10];     // [4][32], read with wave-uniform addresses (scalar loads)
+                // the weights [4][32] from LDS at wave-uniform addresses (broadcast reads).  Read through the laundered weight pointer
+                // they were 32 flat_load_dwordx4 per column, each behind an s_waitcnt vmcnt(0) lgkmcnt(0) of its own (a flat load
+                // ticks both counters): 32 serial L2 round trips, 5 % of a pass for 0.1 % of its arithmetic
                 for (int col = tid; col < R17; col += NTHREADS) {
                     const float* xp = RA + col * 36;          // layer 9's output, handed over in LDS
                     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -944,8 +1017,9 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                         const float4 x = *reinterpret_cast<const float4*>(xp + 4 * q);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            a[r] = fmaf(w4[r * 32 + 4 * q + 0], x.x, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 1], x.y, a[r]);
-                            a[r] = fmaf(w4[r * 32 + 4 * q + 2], x.z, a[r]); a[r] = fmaf(w4[r * 32 + 4 * q + 3], x.w, a[r]);
+                            const float4 w = *reinterpret_cast<const float4*>(W4L + r * 32 + 4 * q);
+                            a[r] = fmaf(w.x, x.x, a[r]); a[r] = fmaf(w.y, x.y, a[r]);
+                            a[r] = fmaf(w.z, x.z, a[r]); a[r] = fmaf(w.w, x.w, a[r]);
                         }
                     }
                     *reinterpret_cast<float4*>(P4 + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
