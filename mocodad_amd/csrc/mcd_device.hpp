@@ -1427,12 +1427,6 @@ __device__ __forceinline__ void emb_compute(const EmbRow& f, const float* __rest
 
 // LDS plan: one work region R carved per layer into disjoint (in, z, out) pieces + the persistent x_t / embedding
 // tables.  Sizes follow the padded column counts P17/P12/P10 and the row strides C+4.
-#ifndef MCD_LSTASH1
-#define MCD_LSTASH1 0       // registers of d1 ...
-#endif
-#ifndef MCD_LSTASH2
-#define MCD_LSTASH2 4       // ... and of d2 parked in LDS between the down- and the up-sampler (12 frames, twelve waves)
-#endif
 template <int T, int NB>
 struct Plan {
     static constexpr int NBT = NB * T;
@@ -1476,13 +1470,7 @@ struct Plan {
 #else
     static constexpr int PROF = 0;
 #endif
-    // 12 frames on twelve waves: skip-tensor registers parked in the LDS the plan leaves free (score_kernel, "LDS stash")
-#if defined(MCD_PROFILE)
-    static constexpr int LSTASH = 0;            // (the profile build's time stamps take that room)
-#else
-    static constexpr int LSTASH = (T == 12 && NB == 1 && NWAVES == 12) ? (MCD_LSTASH1 + MCD_LSTASH2) * NTHREADS : 0;
-#endif
-    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + EXW + PROF + LSTASH;
+    static constexpr int TOTAL = R + XT + EMB + EAUX + ZN + WM + BIA + UPD + ZO + TT + CE + LOSS + EXW + PROF;
     static_assert((size_t)TOTAL * 4 <= 160 * 1024, "LDS plan: more than 160 KB");
     static constexpr size_t BYTES = (size_t)TOTAL * 4;
 };

@@ -270,17 +270,14 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #ifndef MCD_STASH
 #define MCD_STASH 1
 #endif
+#ifndef MCD_RELAUNDER_UP
+#define MCD_RELAUNDER_UP 1      // 0: off, 1: the register-capped kernels that spilled (see the step loop), 7: every kernel (A/B)
+#endif
     constexpr bool STASH2 = !LT && ((MINW >= 4 && ((T == 6 && (MCD_STASH & 1)) || (T == 3 && (MCD_STASH & 4)))) || (MINW == 3 && (MCD_STASH & 32)));
     constexpr bool STASH1 = !LT && ((MINW >= 4 && ((T == 6 && (MCD_STASH & 2)) || (T == 3 && (MCD_STASH & 8)))) || (MINW == 3 && (MCD_STASH & 16)));
     float stash1_mem[STASH1 ? RS1::PER * RS1::SK : 1];
     float stash2_mem[STASH2 ? RS2::PER * RS2::SK : 1];
     typedef float __attribute__((address_space(5))) priv_float;         // (explicit private address space: scratch_*, not flat_*)
-    // 12 frames on twelve waves (168 registers): the 26 skip registers do not all fit beside the 128-channel layers' fragments,
-    // and the allocator's own answer was 5 of them in scratch inside the step loop (write-through: 7 GB per launch).  The plan
-    // leaves 14.8 KB of LDS free there: 4 registers x 768 lanes, one ds_write_b32 / ds_read_b32 each at lane-linear addresses.
-    constexpr int LS1 = (!LT && PL::LSTASH > 0) ? MCD_LSTASH1 : 0, LS2 = (!LT && PL::LSTASH > 0) ? MCD_LSTASH2 : 0;
-    static_assert(LS1 <= RS1::PER * RS1::SK && LS2 <= RS2::PER * RS2::SK, "LDS stash: more registers than the skip tensor has");
-    float* const LST = EXW + PL::EXW + PL::PROF;
 
     const int i_first = P.mode == 1 ? P.step_single : P.ns - 1;
     const int i_last = P.mode == 1 ? P.step_single : 1;
@@ -471,8 +468,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS1::PER * RS1::SK; ++i) sp[i] = skip1[i];
         }
-#pragma unroll
-        for (int i = 0; i < LS1; ++i) LST[i * NTHREADS + tid] = skip1[i];
         wearly(A3, MCD_LC(3));
         bsync();
         STAGE(5);
@@ -499,8 +494,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS2::PER * RS2::SK; ++i) sp[i] = skip2[i];
         }
-#pragma unroll
-        for (int i = 0; i < LS2; ++i) LST[(LS1 + i) * NTHREADS + tid] = skip2[i];
         // wave-aligned units: the layer-5 mix reads only what this wave just wrote -> no barrier (see RsCfg::ALIGNED)
         constexpr bool FUSE64 = RS2::ALIGNED && MixCfg<64, 10, T, NB>::QC == T && MixCfg<64, 10, T, NB>::UNITS == NWAVES;
         wearly(A5, MCD_LC(5));
@@ -569,8 +562,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int i = 0; i < RS2::PER * RS2::SK; ++i) skip2[i] = sp[i];
         }
-#pragma unroll
-        for (int i = 0; i < LS2; ++i) skip2[i] = LST[(LS1 + i) * NTHREADS + tid];
+        if constexpr (MCD_RELAUNDER_UP == 7 || (MCD_RELAUNDER_UP && (MINW == 3 || (MINW >= 4 && T >= 5)))) {
+            // The register-capped kernels (twelve waves: 168 registers; two workgroups per CU: 128): per-lane LDS addresses of the
+            // down path that the up path's stages compute again -- the B-operand address of the 17-joint GEMMs (layers 2 and 9), a
+            // mix's store address (layers 1 and 8) -- were kept live across the 128-channel layers, i.e. SPILLED there (all 11
+            // spilled registers of the 12-frame kernel, 20 at 10 / 11 frames, 11 at 6), and every reload is a vector-memory load:
+            // returned in order, it drains the coefficient prefetches in flight (s_waitcnt vmcnt(0) in the middle of a stage).
+            // Opaque from here on: the up path derives its addresses again, ~40 integer instructions per pass, and nothing is
+            // spilled any more -- 12 / 10 / 6 / 5 frames +0.6 / +3.6 / +0.8 / +0.7 % (profiles/r05s_relaunder_up_ab.txt).  Not for the
+            // kernels that had no spills inside the step loop (3 frames: -0.4 %; 7 / 8 frames, uncapped: 0).
+            tid = tid0;
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63;
+            wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        }
         if constexpr (!EARLY2) rs_early(rc3, 2);
         if constexpr (!FUSE64) bsync();     // aligned: up3 reads only this wave's own layer-6 output block
         STAGE(11);
@@ -606,8 +611,6 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
                                     for (int i = 0; i < RS1::PER * RS1::SK; ++i) skip1[i] = sp[i];
                                 }
-#pragma unroll
-                                for (int i = 0; i < LS1; ++i) skip1[i] = LST[i * NTHREADS + tid];
                             }, WEARLY ? &A8 : nullptr);                                            // su4.1
         STAGE(14);
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
