@@ -268,11 +268,18 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     // Parked in private memory by hand instead -- stored after down2 has used it, fetched back in front of the barrier
     // that precedes up3, whose MFMAs run before the skip values are added: the round trip is off the critical path.
 #ifndef MCD_STASH
-#define MCD_STASH 1
+#define MCD_STASH 0      // (round 5: nothing is hand-parked any more; bit 0 / 1: d2 / d1 of the 6-frame kernel, +1.7 % without)
+#endif
+#ifndef MCD_T6_LOWO
+#define MCD_T6_LOWO 1
 #endif
 #ifndef MCD_RELAUNDER_UP
 #define MCD_RELAUNDER_UP 1      // 0: off, 1: the register-capped kernels that spilled (see the step loop), 7: every kernel (A/B)
 #endif
+    // LOWO: the stage forms of the kernels with registers to spare -- pinned X reads in the mixes (FORCE), the pipelined GEMM's
+    // read-ahead, interleaved resampler units.  The 6-frame kernel joined them in round 5 (114 of its 128 registers once the
+    // up path derives its addresses again, see the step loop): +1.1 %; 3 frames -5 %, 5 frames +0.3 % (profiles/r05u_lowocc4_ab.txt)
+    constexpr bool LOWO = MINW <= MCD_LOWOCC || (MCD_T6_LOWO && T == 6 && NB == 1 && MINW >= 4);
     constexpr bool STASH2 = !LT && ((MINW >= 4 && ((T == 6 && (MCD_STASH & 1)) || (T == 3 && (MCD_STASH & 4)))) || (MINW == 3 && (MCD_STASH & 32)));
     constexpr bool STASH1 = !LT && ((MINW >= 4 && ((T == 6 && (MCD_STASH & 2)) || (T == 3 && (MCD_STASH & 8)))) || (MINW == 3 && (MCD_STASH & 16)));
     float stash1_mem[STASH1 ? RS1::PER * RS1::SK : 1];
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // each SIMD only waits): the resampler is too short to cover 36 loads per wave, and issued at its top they delayed its
         // MFMAs by ~2 k cycles
         // (6 frames: +1 % on top of the pre-barrier placement; 3 frames: -0.3 %, the 128-register budget has no room for it)
-        constexpr bool EARLY2 = (MINW <= MCD_LOWOCC && !MCD_NO_EARLY2) || T == 6;
+        constexpr bool EARLY2 = (LOWO && !MCD_NO_EARLY2) || T == 6;
         LMix<1, T, NB> mc1;
         // layer 0 reads the chain state XT[col][4] in place (x in channels 0,1): its lanes' channels 2..15 are then other
         // columns' coordinates -- finite, and multiplied by the zero-padded K rows of the layer's weights -- so no 16-channel
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         LAfr<1> A1; LAfr<2> A2; LAfr<3> A3; LAfr<4> A4; LAfr<5> A5; LAfr<7> A7; LAfr<8> A8; LAfr<9> A9;
         auto wearly = [&](auto& A, auto lc) { if constexpr (WEARLY) load_lafr<decltype(lc)::value>(A, wb, wave, lane); };
 #define MCD_LC(l) std::integral_constant<int, l>{}
-        layer_std<0, T, NB, (MINW <= MCD_LOWOCC), 4>(wb, mc0, XT, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
+        layer_std<0, T, NB, LOWO, 4>(wb, mc0, XT, RG + PL::L0_z, RG + PL::L0_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc1, 1); }, [&] { wearly(A1, MCD_LC(1)); }, WEARLY ? &A0 : nullptr);     // sp1a (2 -> 16)
         STAGE(2);
         lt_dump(0, RG + PL::L0_out, 20, 16, 17);
@@ -448,20 +455,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // SiLU(pe + cond) for the NEXT pass's embeddings (consumed in this pass's last layer): two global loads and an
         // exp -- by the idle waves too, not on wave 0's path at the top of the pass
         silu_row(sidx > 0 ? sidx - 1 : 0, tid - NZ_T0);
-        layer_std<1, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
+        layer_std<1, T, NB, LOWO>(wb, mc1, RG + PL::L1_in, RG + PL::L1_z, RG + PL::L1_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc2, 2); }, [&] { wearly(A2, MCD_LC(2)); }, WEARLY ? &A1 : nullptr);     // sd1.0
         STAGE(3);
         lt_dump(1, RG + PL::L1_out, 36, 32, 17);
         lt_inject(2, RG + PL::L2_in, 36, 32, 17);
         RsCoef<32, 17, 12, T, NB, true> rc1;
         LMix<3, T, NB> mc3;
-        layer_std<2, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
+        layer_std<2, T, NB, LOWO>(wb, mc2, RG + PL::L2_in, RG + PL::L2_z, RG + PL::L2_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc1, 0); }, [&] { if constexpr (EARLY2) mix_early(mc3, 3); }, WEARLY ? &A2 : nullptr);      // sd1.1 -> d1
         STAGE(4);
         lt_dump(2, RG + PL::L2_out, 36, 32, 17);
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
         if constexpr (!EARLY2) mix_early(mc3, 3);
-        resample_stage<32, 17, 12, T, NB, true, false, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
+        resample_stage<32, 17, 12, T, NB, true, false, (LOWO && MCD_RS_ILP)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         if constexpr (STASH1) {
             priv_float* sp = (priv_float*)stash1_mem;
             asm volatile("" : "+v"(sp));
@@ -474,20 +481,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(11, RG + PL::DN1_out, 36, 32, 12);
         lt_inject(3, RG + PL::L3_in, 36, 32, 12);
         LMix<4, T, NB> mc4;
-        layer_std<3, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
+        layer_std<3, T, NB, LOWO>(wb, mc3, RG + PL::L3_in, RG + PL::L3_z, RG + PL::L3_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc4, 4); }, [&] { wearly(A4, MCD_LC(4)); }, WEARLY ? &A3 : nullptr);     // sd2.0
         STAGE(6);
         lt_dump(3, RG + PL::L3_out, 68, 64, 12);
         lt_inject(4, RG + PL::L4_in, 68, 64, 12);
         RsCoef<64, 12, 10, T, NB, true> rc2;
         LMix<5, T, NB> mc5;
-        layer_std<4, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
+        layer_std<4, T, NB, LOWO>(wb, mc4, RG + PL::L4_in, RG + PL::L4_z, RG + PL::L4_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc2, 1); }, [&] { if constexpr (EARLY2) mix_early(mc5, 5); }, WEARLY ? &A4 : nullptr);      // sd2.1 -> d2
         STAGE(7);
         lt_dump(4, RG + PL::L4_out, 68, 64, 12);
         lt_inject(12, RG + PL::L4_out, 68, 64, 12);
         if constexpr (!EARLY2) mix_early(mc5, 5);
-        resample_stage<64, 12, 10, T, NB, true, false, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
+        resample_stage<64, 12, 10, T, NB, true, false, (LOWO && MCD_RS_ILP)>(RG + PL::L4_out, 68, RG + PL::DN2_out, 68, rc2, skip2, wave, lane);  // down2 (captures d2)
         if constexpr (STASH2) {
             priv_float* sp = (priv_float*)stash2_mem;
             asm volatile("" : "+v"(sp));            // opaque: the array stays in memory, plain (cached) scratch accesses
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const LayerW lw = layer_w(wb, 6);
             float4 afr[8];
             MixCoef<64, 10, T, NB> mc6;
-            layer_std<5, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
+            layer_std<5, T, NB, LOWO>(wb, mc5, RG + PL::L5_in, RG + PL::L5_z, RG + PL::L5_out, EMB, wave, lane, prof, nohook,
                                 [&] {
                                     load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, 0);
                                     if constexpr (EARLY2) mc6.load(wb + lw.tq, wb + lw.am, wave, lane);
@@ -525,11 +532,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 constexpr int STEP = Tiling<8, NT>::NG * 16 * 132;
                 if (col < COLS) *reinterpret_cast<float4*>(Pb + __mul24(col0, 132) + c0 + decltype(ti)::value * STEP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             };
-            gemm_tiles<8, NT, 8, 0, false, (MINW <= MCD_LOWOCC)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
+            gemm_tiles<8, NT, 8, 0, false, LOWO>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, 0);
 #pragma unroll
             for (int mi = 1; mi < Tiling<8, NT>::MW; ++mi) {
                 load_afrags<8, 8>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr, mi);
-                gemm_tiles<8, NT, 8, 0, false, (MINW <= MCD_LOWOCC)>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
+                gemm_tiles<8, NT, 8, 0, false, LOWO>(afr, RG + PL::L6_in, 132, RG + PL::L6_in, 132, wave, lane, epi6, mi);
             }
             if constexpr (EARLY2) { rs_early(rc3, 2); mix_early(mc7, 7); }      // up3's fragments, layer 7's mix coefficients
             bsync();
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             STAGE(10);
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);
-            mix_stage<64, 10, T, NB, (MINW <= MCD_LOWOCC), true>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
+            mix_stage<64, 10, T, NB, LOWO, true>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
                                      [&](int n, int q, int w0, ChIdx c, std::true_type) {   // the fragment's 4 joints at once
                                          // (address: the unit's part on the scalar unit + one v_mad for the lane's, see mix_stage)
                                          const float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w0, 132) + c.j);
@@ -587,21 +594,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         }
         // ---- up path
         if constexpr (!EARLY2) mix_early(mc7, 7);
-        resample_stage<64, 10, 12, T, NB, false, true, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
+        resample_stage<64, 10, 12, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         wearly(A7, MCD_LC(7));
         bsync();
         STAGE(12);
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
         lt_inject(7, RG + PL::L7_in, 68, 64, 12);
         LMix<8, T, NB> mc8;
-        layer_std<7, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
+        layer_std<7, T, NB, LOWO>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, [&] { wearly(A8, MCD_LC(8)); }, WEARLY ? &A7 : nullptr);     // su4.0
         STAGE(13);
         lt_dump(7, RG + PL::L7_out, 68, 64, 12);
         lt_inject(8, RG + PL::L8_in, 68, 64, 12);
         RsCoef<32, 12, 17, T, NB, false> rc4;
         LMix<9, T, NB> mc9;
-        layer_std<8, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
+        layer_std<8, T, NB, LOWO>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); },
                             [&] {
                                 if constexpr (EARLY2) mix_early(mc9, 9);
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
         if constexpr (!EARLY2) mix_early(mc9, 9);
-        resample_stage<32, 12, 17, T, NB, false, true, (MINW <= MCD_LOWOCC && MCD_RS_ILP)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+        resample_stage<32, 12, 17, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         wearly(A9, MCD_LC(9));
         bsync();
         STAGE(15);
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             // conditionally loaded register struct costs ~35 VGPRs of phi copies here.
             EmbRow ef;
             auto ef_load = [&] { ef.load(wb, tid); };
-            layer_std<9, T, NB, (MINW <= MCD_LOWOCC)>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
+            layer_std<9, T, NB, LOWO>(wb, mc9, RG + PL::L9_in, RG + PL::L9_z, RG + PL::L9_out, EMB, wave, lane, prof,
                                 [&] {
                                     mc10.load(wb + lw.tq, wb + lw.am, wave, lane);
                                     ef_load();
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope10 = lw.slope;
             const bool single = P.mode == 1, zadd = sidx > 1;
             const int e10_off = (sidx & 1) * 16;
-            mix_stage<16, 17, T, NB, (MINW <= MCD_LOWOCC), true>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
+            mix_stage<16, 17, T, NB, LOWO, true>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      ZeroInit{},
                                      [&](int n, int t, int w0, int c, auto val) {     // whole 4-joint fragments: one address, 4 stores
                                          if (c < C0) {
