@@ -47,6 +47,13 @@ __host__ __device__ constexpr long long tl_slab_floats(int TP) {
     return (long long)2 * (TP * 10 + 16) * 132 + (long long)(TP * 17 + 16) * 36 + (long long)(TP * 12 + 16) * 68;
 }
 
+#ifndef MCD_TL_DENSE
+#define MCD_TL_DENSE 0     // 1: slab rows of exactly C floats (every 64-byte chunk of a row aligned); 0: C + 4 like the LDS rows
+#endif
+// row stride of a C-channel tensor in the SLAB.  The + 4 of the LDS row strides (cs_of) serves the LDS banks; in global memory it
+// puts a 32-channel part of a row (128 bytes) across two 128-byte lines.  Dense rows were measured: 24 frames +0.1 %, 32 frames
+// -2.2 % (power-of-two row strides; profiles/r05y_tiled_dense_rows_ab.txt) -- the padded stride stays
+__host__ __device__ constexpr int ss_of(int c) { return MCD_TL_DENSE ? c : c + 4; }
 #ifndef MCD_TL_LATE
 #define MCD_TL_LATE 1      // the next part's slab loads go out right before the current part's channel GEMM (see `layer`)
 #endif
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 // group 0's accumulators until both groups are through (the chunk's place is still its own X rows before)
                 constexpr bool HOC = L == 2 || L == 8, HIC = L == 3 || L == 9;
                 constexpr LDesc D = (COND && L == 6) ? LDesc{128, 16, 10, 1} : layer_desc(L);
-                constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = cs_of(CIN), CSO = cs_of(COUT);
+                constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = ss_of(CIN), CSO = ss_of(COUT);
                 constexpr bool RES = D.res != 0;
                 constexpr int CINV = CIN >= 32 ? 32 : 16, NH = CIN / CINV, CSZ = cs_of(CINV);
                 constexpr int CSV = L == 0 ? 4 : L == 1 ? 36 : CSZ;    // layer 0 reads the chain state in place (see score_kernel); layer 1's
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                         constexpr bool HO17p = LP == 0 || LP == 1 || LP == 9, HOp = LP == 3 || LP == 5 || LP == 7;
                         constexpr bool HORp = LP == 4 || LP == 6, HOCp = LP == 2 || LP == 8;
                         constexpr int TNEXTp = (TF * (LP == 4 ? 10 : LP == 8 ? 17 : 12) + 16) * 36;
-                        constexpr int CI = DP.cout, VI = DP.V, CSP = cs_of(CI);
+                        constexpr int CI = DP.cout, VI = DP.V, CSP = ss_of(CI);
                         float* xprev = const_cast<float*>(xin);
                         for (int u = tid; u < NB * CI * T * VI; u += NTHREADS) {
                             const int v = u % VI, t = (u / VI) % T, c = (u / (VI * T)) % CI, i = u / (VI * T * CI);
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     float a = 0.f;
                     for (int k = part; k < F; k += 32) {
                         const int c = k / (T * 10), r = k % (T * 10);                // r = t * 10 + v
-                        a = fmaf(Wl[(size_t)jo * F + k], A1[(size_t)(i * TP * 10 + r) * cs_of(16) + c], a);
+                        a = fmaf(Wl[(size_t)jo * F + k], A1[(size_t)(i * TP * 10 + r) * ss_of(16) + c], a);
                     }
 #pragma unroll
                     for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 32);
