@@ -41,6 +41,14 @@ __host__ __device__ constexpr int tl_ra_floats(int TP) {
     // (A fused resampler's input chunk passes through the z region.)
     return cmax((TP * 17 + 16 + TP * 17 / 2 + 16) * 36, 2 * (TP * 12 + 16) * 36);
 }
+// 24 frames: the LDS has room (29 KB of the 43 KB the plan leaves) for the SECOND chunk of a resampler's input as well, behind
+// the layers whose output all 32 channels of the next layer's fused resampler read (2 -> down1 -> 3, 8 -> up2 -> 9): both chunks are
+// handed over in LDS and layers 3 / 9 start without the store -> barrier -> load round trip through the slab (MCD_TL_EX)
+#ifndef MCD_TL_EX
+#define MCD_TL_EX 1
+#endif
+// (+ 4 pad rows: the 17-joint resampler's last k-step reads joints 16 .. 19 of the chunk's last frame -- zero coefficients on finite values)
+__host__ __device__ constexpr int tl_ex_floats(int TF) { return (MCD_TL_EX && TF == 24) ? (tl_fc(TF) * 17 + 4) * 36 : 0; }
 __host__ __device__ constexpr int tl_qc(int TP) { return TP % 3 == 0 ? 3 : 4; }     // output frames per mix unit (6 at 24 frames: 108 coefficient registers, spills)
 __host__ __device__ constexpr long long tl_slab_floats(int TP) {
     // A0, A1 (ping-pong, up to 128 ch x 10 joints), the skips D1, D2 -- each with 16 rows of padding behind it
@@ -54,6 +62,19 @@ __host__ __device__ constexpr long long tl_slab_floats(int TP) {
 // puts a 32-channel part of a row (128 bytes) across two 128-byte lines.  Dense rows were measured: 24 frames +0.1 %, 32 frames
 // -2.2 % (power-of-two row strides; profiles/r05y_tiled_dense_rows_ab.txt) -- the padded stride stays
 __host__ __device__ constexpr int ss_of(int c) { return MCD_TL_DENSE ? c : c + 4; }
+// cross-layer prefetches in front of a layer's last channel GEMM (see `layer`), per frame-count class: bit 0 the next layer's first
+// time-mix fragments, bit 1 the fragments of the resampler fused into the next layer, bit 2 the skip rows of layers 7 / 9.
+// Measured per shape (profiles/r05z_tiled24_*_ab.txt, r05zb_tiled_pre_shapes_ab.txt): they hold registers across the GEMM
+#ifndef MCD_TL_PRE16
+#define MCD_TL_PRE16 7
+#endif
+#ifndef MCD_TL_PRE24
+#define MCD_TL_PRE24 7
+#endif
+#ifndef MCD_TL_PRE32
+#define MCD_TL_PRE32 0      // (32 frames: 111 spilled registers already; -0.8 .. -2 % with them)
+#endif
+__host__ __device__ constexpr int tl_pre(int TF) { return TF <= 16 ? MCD_TL_PRE16 : TF == 24 ? MCD_TL_PRE24 : MCD_TL_PRE32; }
 #ifndef MCD_TL_LATE
 #define MCD_TL_LATE 1      // the next part's slab loads go out right before the current part's channel GEMM (see `layer`)
 #endif
@@ -525,6 +546,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
     float* const P4 = ZO + R17 * C0;                // [R17 + 16][4]  layer 10's W-first product (+ zero pad rows: its mix reads 16-channel blocks)
     float* const RED = P4 + (R17 + 16) * 4;         // [NTHREADS]
     float* const W4L = RED + NTHREADS;              // [4][32]  layer 10's W-first weights [W_t; W_r] (constant over the launch)
+    constexpr int EXF = tl_ex_floats(TF);
+    float* const EX = W4L + 128;                    // [TL_FC * 17][36]  second hand-over chunk of layers 2 -> 3, 8 -> 9 (24 frames only)
     const int tid0 = threadIdx.x;
     int tid = tid0, lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -541,6 +564,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
     for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
     if (tid < 64) P4[R17 * 4 + tid] = 0.f;
     if (!COND && tid < 128) W4L[tid] = P.wbuf[N.wp[10] + tid];
+    for (int u = tid; u < EXF; u += NTHREADS) EX[u] = 0.f;              // (its pad rows stay zero; the rest is rewritten every pass)
     for (int u = tid; u < RA_F; u += NTHREADS) RA[u] = 0.f;           // pad rows meet zero coefficients: they must be finite
 
     for (long long grp = blockIdx.x; grp * NB < P.n_chains; grp += gridDim.x) {
@@ -651,6 +675,21 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             // frames in two groups, z holding one group at a time.
             // RSI >= 0: the layer's input is joint resampler RSI applied to `xin` (+ `skip`): each 32-channel part of X is built in
             // LDS from the resampler's input rows, chunk of frames by chunk -- the resampled tensor never exists in the slab
+            // the U-Net skip rows (d2 / d1, first 32 channels) that layers 7 / 9 add behind their fused resampler: written long before
+            // (layers 4 / 2), so their loads go out in front of the PREVIOUS layer's last channel GEMM instead of at the layer's start
+            // ... and the next layer's first time-mix fragments likewise: fetched behind a layer's own epilogue they wait for the
+            // epilogue's slab stores to be acknowledged (stores count in vmcnt too, and everything returns in order)
+            constexpr bool TQPRE = (tl_pre(TF) & 1) && !LT;
+            float tqx[TP / 4];
+            constexpr bool RCPRE = (tl_pre(TF) & 2) && !LT;      // ... and the fragments of the resampler fused into the next layer
+            constexpr int FCX = tl_fc(TF);
+            RsCoef<32, 17, 12, FCX, 1, false> rcx3;
+            RsCoef<32, 12, 10, FCX, 1, false> rcx5;
+            RsCoef<32, 10, 12, FCX, 1, false> rcx7;
+            RsCoef<32, 12, 17, FCX, 1, false> rcx9;
+            constexpr bool SKPRE = (tl_pre(TF) & 4) && !LT && !COND;
+            TlStage<SKPRE ? TF * 12 : 1, 32> sk7;
+            TlStage<SKPRE ? TF * 17 : 1, 32> sk9;
             auto layer = [&](auto lc, auto rsc, const float* xin, bool xin_lds, float* xout, const float* skip) {
                 constexpr int L = decltype(lc)::value, RSI = decltype(rsc)::value;
                 constexpr int VIN = RSI == 0 ? 17 : RSI == 2 ? 10 : 12;      // joints of the resampler's input (down1, down2, up3, up2)
@@ -668,6 +707,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 // ... or only the resampler's FIRST chunk where all of it does not fit (2 -> down1 -> 3, 8 -> up2 -> 9); layer 2 keeps
                 // group 0's accumulators until both groups are through (the chunk's place is still its own X rows before)
                 constexpr bool HOC = L == 2 || L == 8, HIC = L == 3 || L == 9;
+                constexpr bool HOC2 = HOC && EXF > 0, HIC2 = HIC && EXF > 0;      // ... and the second chunk as well (EX)
                 constexpr LDesc D = (COND && L == 6) ? LDesc{128, 16, 10, 1} : layer_desc(L);
                 constexpr int CIN = D.cin, COUT = D.cout, V = D.V, CSI = ss_of(CIN), CSO = ss_of(COUT);
                 constexpr bool RES = D.res != 0;
@@ -708,6 +748,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                             else xprev[(size_t)gcol * CSP + c] = val;
                             if (HORp && c < 32) RA[TNEXTp + gcol * 36 + c] = val;
                             if (HOCp && gcol < TL_FC * VI) RA[TNEXTp + gcol * 36 + c] = val;
+                            if (HOCp && EXF > 0 && gcol >= TL_FC * VI && gcol < 2 * TL_FC * VI) EX[(gcol - TL_FC * VI) * 36 + c] = val;
                         }
                         if (skip) {      // the U-Net skip tensor behind the fused resampler (d2 / d1; zeros when the caller gave none)
                             float* sk = const_cast<float*>(skip);
@@ -725,7 +766,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #define TLXMARK(k) do { if constexpr (L >= 3) TLMARK(40 + 2 * (L - 3) + (k)); } while (0)
                 float* const XA = RA;                                          // [ROWS + 16][CSV]
                 float* const ZA = RA + (ROWS + 16) * (L <= 1 ? 36 : CSZ);      // [ROWSG + 16][CSZ]  (layer 0: behind the next layer's X)
-                TlStage<ROWS, CINV> sx;                // plain input: a 32-channel part of all frames; resampled input: the skip rows
+                TlStage<ROWS, CINV> sx_own;            // plain input: a 32-channel part of all frames; resampled input: the skip rows
+                auto& sx = [&]() -> auto& { if constexpr (SKPRE && L == 7) return sk7; else if constexpr (SKPRE && L == 9) return sk9; else return sx_own; }();
                 constexpr int IR = TL_FC * VIN, OR = TL_FC * V;
                 // resampled input: a chunk of the resampler's input rows -- or, behind a layer that hands its output over in LDS (HIR: the
                 // z region holds the resampler's input of ALL frames), every later 32-channel part whole as well: its loads are issued a
@@ -733,7 +775,11 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 // to the slab exposed, plus two barriers per chunk)
                 constexpr bool ONE = HIR && MCD_TL_ONECHUNK;
                 TlStage<RSI >= 0 ? (ONE ? NFC * IR : IR) : 1, 32> si;
-                RsCoef<32, VIN, V, TL_FC, 1, false> rc;
+                RsCoef<32, VIN, V, TL_FC, 1, false> rc_own;
+                auto& rc = [&]() -> auto& {
+                    if constexpr (RCPRE && L == 3) return rcx3; else if constexpr (RCPRE && L == 5) return rcx5;
+                    else if constexpr (RCPRE && L == 7) return rcx7; else if constexpr (RCPRE && L == 9) return rcx9; else return rc_own;
+                }();
                 if constexpr (RSI >= 0) {
                     static_assert(!HIR || NH >= 2, "");
                     static_assert(!HIC || (NH == 1 && NFC == 2), "");
@@ -743,10 +789,12 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     // right before the current part's channel GEMM -- the mix stages fetch their later units' coefficients in place
                     // and wait for them with vmcnt(0); issued in front of the mixes, as they were, the slab loads' whole latency sat
                     // in every time mix.
-                    if constexpr (MCD_TL_LATE) rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
-                    if constexpr (HIC) si.issue(tid, xin + (size_t)IR * CSI, CSI, 0);      // (chunk 0 is in the z region already)
+                    if constexpr (MCD_TL_LATE && !RCPRE) rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                    static_assert(!HIC2 || (IR + 4) * 36 <= EXF, "");
+                    if constexpr (HIC2) { }                                                   // (both chunks are in LDS already)
+                    else if constexpr (HIC) si.issue(tid, xin + (size_t)IR * CSI, CSI, 0);      // (chunk 0 is in the z region already)
                     else if constexpr (!(MCD_TL_LATE && HIR)) si.issue(tid, xin, CSI, HIR ? CINV : 0);   // (HIR: part 0 is in the z region already, all chunks of it)
-                    if constexpr (!MCD_TL_LATE) rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
+                    if constexpr (!MCD_TL_LATE && !RCPRE) rc.load(wb + Nl->rsw[RSI], wb + Nl->rsw[RSI] + ((V + 15) / 16) * ((VIN + 3) / 4) * 64, lane);
                     static_assert(RSI < 0 || HIC || HIR, "");
                 } else if (!xin_lds && !HI17) {
                     static_assert(!HI || (RSI < 0 && NH >= 2), "");
@@ -754,8 +802,25 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     if constexpr (!MCD_TL_LATE) sx.issue(tid, xin, CSI, HI ? CINV : 0);
                 }
                 float tqa[TP / 4], aja[(V + 15) / 16][(V + 3) / 4];     // the first units' mix coefficients, a stage ahead
-                tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, 0);
-                if constexpr (RSI >= 0) { if (skip) sx.issue(tid, skip, CSI, 0); }
+                if constexpr (TQPRE && L > 0) {
+#pragma unroll
+                    for (int i = 0; i < TP / 4; ++i) tqa[i] = tqx[i];
+                } else {
+                    tl_time_fetch<V, TP, NB, FS>(tqa, wb + Nl->tqm[L], wave, lane, 0);
+                }
+                auto next_tq = [&] {      // (called in front of the layer's last channel GEMM)
+                    if constexpr (RCPRE && (L == 2 || L == 4 || ((L == 6 || L == 8) && !COND))) {
+                        constexpr int RN = L / 2 - 1;                         // the next layer's resampler: down1, down2, up3, up2
+                        constexpr int VI = RN == 0 ? 17 : RN == 2 ? 10 : 12, VO = layer_desc(L + 1).V;
+                        auto& rn = [&]() -> auto& { if constexpr (L == 2) return rcx3; else if constexpr (L == 4) return rcx5; else if constexpr (L == 6) return rcx7; else return rcx9; }();
+                        rn.load(wb + Nl->rsw[RN], wb + Nl->rsw[RN] + ((VO + 15) / 16) * ((VI + 3) / 4) * 64, lane);
+                    }
+                    if constexpr (TQPRE && L + 1 <= (COND ? 6 : 9)) {
+                        constexpr LDesc DN = layer_desc(L + 1);
+                        tl_time_fetch<DN.V, TP, NB, tl_ngrp(DN.V)>(tqx, wb + Nl->tqm[L + 1], wave, lane, 0);
+                    }
+                };
+                if constexpr (RSI >= 0 && !(SKPRE && (L == 7 || L == 9))) { if (skip) sx.issue(tid, skip, CSI, 0); }
                 // weight fragments of the wave's m-tile: all of them up front, or (128 input channels) a quarter at a time
                 constexpr bool AQ = NH > 2;
                 constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
@@ -793,6 +858,9 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #pragma unroll
                             for (int fc = 0; fc < NFC; ++fc)
                                 resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA + fc * IR * CSZ, CSZ, XA + fc * OR * CSV, CSV, rc, nosk, wave, lane);
+                        } else if constexpr (HIC2) {
+                            resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(ZA, CSZ, XA, CSV, rc, nosk, wave, lane);
+                            resample_stage<32, VIN, V, TL_FC, 1, false, false, true>(EX, 36, XA + OR * CSV, CSV, rc, nosk, wave, lane);
                         } else {
 #pragma unroll
                             for (int fc = 0; fc < NFC; ++fc) {
@@ -812,7 +880,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                             __syncthreads();
                             TLMARK(4 * L);
 #pragma unroll
-                            for (int i = 0; i < decltype(sx)::N; ++i) {
+                            for (int i = 0; i < std::remove_reference_t<decltype(sx)>::N; ++i) {
                                 const int u = tid + i * NTHREADS;
                                 if (u < ROWS * 8) {
                                     float4* xp = reinterpret_cast<float4*>(XA + (u >> 3) * CSV + (u & 7) * 4);
@@ -884,6 +952,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                                 else store_global4(xout + (size_t)gcol * CSO + c0, o);      // (layer 4's is the skip d2 as well)
                                 if (HOR && mt < 2) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
                                 if (HOC && gcol < TL_FC * V) *reinterpret_cast<float4*>(RA + TNEXT + gcol * 36 + c0) = o;
+                                if (HOC2 && gcol >= TL_FC * V) *reinterpret_cast<float4*>(EX + (gcol - TL_FC * V) * 36 + c0) = o;
                             }
                         });
                     };
@@ -909,6 +978,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                         TLMARK(4 * L + 1);
                         __syncthreads();
                         TLMARK(4 * L + 2);
+                        next_tq();
                         gemm_fg(1, acc);
                         __syncthreads();                  // (... nor those of group 1)
                         if constexpr (!HO17) epi_fg(0, acc0);
@@ -935,6 +1005,13 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                                     } else if (!xin_lds && !HI17) {
                                         sx.issue(tid, xin, CSI, (h + 1) * CINV);
                                     }
+                                }
+                            }
+                            if constexpr (h == NH - 1) { if (fg == FS - 1) next_tq(); }
+                            if constexpr (SKPRE && h == NH - 1 && (L == 6 || L == 8)) {
+                                if (fg == FS - 1) {
+                                    if constexpr (L == 6) sk7.issue(tid, D2, ss_of(64), 0);
+                                    else sk9.issue(tid, D1, ss_of(32), 0);
                                 }
                             }
                             gemm_fg(fg, acc);
@@ -1010,7 +1087,11 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #define MCD_TL_QC10 2
 #endif
                 // (16 frames: two output frames per unit -- 8 units, every wave busy -- instead of four in 4 units)
-                constexpr int QC10 = TF <= 16 ? MCD_TL_QC10 : 0;
+                // (24 frames on twelve waves: two output frames per unit as well -- 12 units, every wave busy -- instead of three in 8)
+#ifndef MCD_TL_QC10_24
+#define MCD_TL_QC10_24 0      // (2: 12 units of two frames -- measured 0, profiles/r05z_tiled24_qc10_ab.txt)
+#endif
+                constexpr int QC10 = TF <= 16 ? MCD_TL_QC10 : (TF == 24 && NWAVES == 12) ? MCD_TL_QC10_24 : 0;
                 MixLongCoef<16, 17, TP, NB, QC10> mc10;      // (the mix's first coefficients: in flight behind the product)
                 mc10.load(wb + Ns->tq[10], wb + Ns->am[10], wave, lane);
                 // the weights [4][32] from LDS at wave-uniform addresses (broadcast reads).  Read through the laundered weight pointer

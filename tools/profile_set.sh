@@ -57,6 +57,12 @@ for c in avenue ubnormal_concat seq24; do
   timeout 900 python tools/stage_profile.py 0 $c > $O/${c}_stage_profile.txt 2> $O/${c}_stage_profile.err
   stamp $O/${c}_stage_profile.txt
 done
+for c in concat24 concat32; do      # (the slab-tiled kernel: stage cycles of waves 0 / last + the per-wave event trace of one pass)
+  timeout 600 python tools/tiled_stage_profile.py $c 2>&1 | grep -v amdgpu.ids > $O/${c}_stage_profile.txt
+  stamp $O/${c}_stage_profile.txt
+done
+# shard-sized end-to-end runs (eval_MoCoDAD.py: test_step loop + gather + frame scores + AUC)
+bash tools/e2e_shards.sh $TAG $HEAD > /dev/null 2>&1
 fi
 cd /tmp && export TMPDIR=/tmp
 for c in $PCFGS; do
