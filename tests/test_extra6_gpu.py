@@ -61,7 +61,12 @@ def test_every_stage_vs_reference_layer_io(variant):
     worst = 0.0
     blocks = O.UNET_DOWN + O.UNET_MID1 + O.UNET_MID2 + O.UNET_UP4 + O.UNET_UP3
     fused = {3: "down1", 5: "down2", 7: "up3", 9: "up2"}
+    from mocodad_amd import _lib
     for i in range(11):
+        # every stage starts from LDS full of NaN patterns: a stage entry that reads a pad row or a hand-over region nobody wrote
+        # (0 * NaN) fails here on every box, not only on the one whose LDS happens to hold non-finite values (round 5: the second
+        # hand-over chunk of the 24-frame kernel, four rows past its end, seen once on a fresh box)
+        assert _lib.lib().mcd_debug_poison_lds(None) == 0
         if tiled and i in fused:
             # the fused stage of the slab-tiled kernel: resampler input (+ skip) -> layer output; expected value = the oracle's
             # layer applied to the oracle's resampler output (each pinned to the reference's own I/O on these very tensors)

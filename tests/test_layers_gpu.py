@@ -7,6 +7,7 @@ import json
 import numpy as np
 import pytest
 import torch
+from mocodad_amd import _lib
 
 from conftest import load_golden
 
@@ -35,6 +36,7 @@ def test_every_layer_vs_reference_layer_io(variant):
     e = torch.from_numpy(g["emb_in"])
     worst = 0.0
     for i in range(11):
+        assert _lib.lib().mcd_debug_poison_lds(None) == 0      # (LDS full of NaN patterns: no stage entry may read what it did not write)
         out = sc.layer_forward(i, torch.from_numpy(g[f"L{i}_in"]), e).cpu().numpy()
         ref = g[f"L{i}_out"]
         scale = max(1.0, float(np.abs(ref).max()))
@@ -85,6 +87,7 @@ def test_every_stage_at_twelve_wave_frame_counts_vs_oracle(seg_len):
             cin, vin, _, _ = sc._STAGES[i]
             x = torch.randn(B, cin, T, vin, generator=gen)
             ref = O.st_gcnn_layer(sdo, f"model.{b}.{li}", x, e).numpy()
+            assert _lib.lib().mcd_debug_poison_lds(None) == 0
             out = sc.layer_forward(i, x, e).cpu().numpy()
             scale = max(1.0, float(np.abs(ref).max()))
             worst = max(worst, np.abs(out - ref).max() / scale)

@@ -1,10 +1,1 @@
-mkdir -p gpurun_out/r05zz2
-python bench.py > gpurun_out/r05zz2/bench_avenue.json 2>/dev/null
-for c in stc ubnormal_concat seq24 concat24 concat32; do python bench.py --config $c --no-cpu-baseline > gpurun_out/r05zz2/bench_$c.json 2>/dev/null; done
-for c in avenue stc ubnormal_concat seq24 concat24 concat32; do python - <<PY
-import json
-d=json.loads(open('gpurun_out/r05zz2/bench_$c.json').read().strip().splitlines()[-1])
-r=d['roofline']; print('$c', d['value'], r['frac'], 'traffic', r.get('traffic'), r.get('traffic_source'), json.dumps(r.get('pmc'))[:300])
-PY
-done
-timeout 1200 python tests/studies/random_sweep.py 200 120 > gpurun_out/r05zz2/random_sweep.txt 2>&1; tail -2 gpurun_out/r05zz2/random_sweep.txt
+timeout 1200 python -m pytest tests/test_layers_gpu.py tests/test_extra6_gpu.py -m gpu -q 2>&1 | tail -4
