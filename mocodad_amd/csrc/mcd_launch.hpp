@@ -177,7 +177,7 @@ template <int TP, int NB, bool LT = false, bool COND = false>
 int launch_score_tiled_t(const mcd_weights* w, const ScoreParams& P, const FrameMaps& M, float* scratch, int wgs, hipStream_t st) {
     MCD_WAVES_CHECK(COND ? NWAVES : shipped_waves_tiled(TP));      // (the COND form -- the 'E_unet' encoder on the tiled stages -- runs on eight or twelve)
     constexpr int TF = TP * NB;
-    constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS + 128 + tl_ex_floats(TF)) * 4;
+    constexpr size_t lds = ((size_t)tl_ra_floats(TF) + (TF * 17 + 16) * 4 + NB * (EMB_TOTAL + 4 + EDIM) + TF * 17 * 2 * 2 + (TF * 17 + 16) * 4 + NTHREADS + 128 + 32 + tl_ex_floats(TF)) * 4;
     LDS_LIMIT((&score_tiled_kernel<TP, NB, LT, COND>), lds);
     ScoreParams Q = P;
     Q.prio_shift = 0;

@@ -75,6 +75,9 @@ __host__ __device__ constexpr int ss_of(int c) { return MCD_TL_DENSE ? c : c + 4
 #define MCD_TL_PRE32 0      // (32 frames: 111 spilled registers already; -0.8 .. -2 % with them)
 #endif
 __host__ __device__ constexpr int tl_pre(int TF) { return TF <= 16 ? MCD_TL_PRE16 : TF == 24 ? MCD_TL_PRE24 : MCD_TL_PRE32; }
+#ifndef MCD_TL_L10_MFMA
+#define MCD_TL_L10_MFMA 1
+#endif
 #ifndef MCD_TL_LATE
 #define MCD_TL_LATE 1      // the next part's slab loads go out right before the current part's channel GEMM (see `layer`)
 #endif
@@ -547,7 +550,8 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
     float* const RED = P4 + (R17 + 16) * 4;         // [NTHREADS]
     float* const W4L = RED + NTHREADS;              // [4][32]  layer 10's W-first weights [W_t; W_r] (constant over the launch)
     constexpr int EXF = tl_ex_floats(TF);
-    float* const EX = W4L + 128;                    // [TL_FC * 17][36]  second hand-over chunk of layers 2 -> 3, 8 -> 9 (24 frames only)
+    int* const UPDT = reinterpret_cast<int*>(W4L + 128);   // [32]  frame t -> frame whose chain state its prediction updates (pos_of[upd_of[t]]), or -1
+    float* const EX = W4L + 128 + 32;                    // [TL_FC * 17][36]  second hand-over chunk of layers 2 -> 3, 8 -> 9 (24 frames only)
     const int tid0 = threadIdx.x;
     int tid = tid0, lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -564,15 +568,26 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
     for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
     if (tid < 64) P4[R17 * 4 + tid] = 0.f;
     if (!COND && tid < 128) W4L[tid] = P.wbuf[N.wp[10] + tid];
+    if (tid < 32) { const int k = tid < T ? M.upd_of[tid] : -1; UPDT[tid] = (k >= 0 && k < MCD_MAX_FRAMES) ? M.pos_of[k] : -1; }
     for (int u = tid; u < EXF; u += NTHREADS) EX[u] = 0.f;              // (its pad rows stay zero; the rest is rewritten every pass)
     for (int u = tid; u < RA_F; u += NTHREADS) RA[u] = 0.f;           // pad rows meet zero coefficients: they must be finite
 
     for (long long grp = blockIdx.x; grp * NB < P.n_chains; grp += gridDim.x) {
         // chain i of the group (the last group of an odd count runs its last chain twice and writes it once)
         auto chain_of = [&](int i) { const long long c = grp * NB + i; return c < P.n_chains ? c : P.n_chains - 1; };
-        auto b_of = [&](int i) { return (int)(chain_of(i) / P.S); };
-        auto s_of = [&](int i) { return (int)(chain_of(i) % P.S); };
-        auto fixed_of = [&](int i) { return (unsigned)(P.win_mask ? P.win_mask[b_of(i)] : P.fixed_mask); };
+        // (window, sample, condition-frame mask) of the group's chains: once per group -- they were 64-bit divisions and a global
+        // load inside every pass's noise loop and update tail
+        int bq[NB], sq[NB];
+        unsigned fq[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const long long c = chain_of(i);
+            bq[i] = (int)(c / P.S); sq[i] = (int)(c - (long long)bq[i] * P.S);
+            fq[i] = (unsigned)(P.win_mask ? P.win_mask[bq[i]] : P.fixed_mask);
+        }
+        auto b_of = [&](int i) { return NB == 1 ? bq[0] : bq[i]; };
+        auto s_of = [&](int i) { return NB == 1 ? sq[0] : sq[i]; };
+        auto fixed_of = [&](int i) { return NB == 1 ? fq[0] : fq[i]; };
         auto tx_of = [&](unsigned fixed, int t) { return P.win_mask ? __popc(~fixed & ((1u << t) - 1u)) : M.tx_of[t]; };
         auto src_of = [&](int t) { return P.win_mask ? t : M.src_frame[t]; };
         __syncthreads();
@@ -659,6 +674,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 }
             }
             __syncthreads();
+            TLMARK(58);                                // pass prologue: SiLU(pe + cond), noise
             for (int u = tid; !COND && u < NB * EMB_TOTAL; u += NTHREADS) {
                 const int i = u / EMB_TOTAL, o = u % EMB_TOTAL;
                 gfloat* we = as_global(wb + Ns->we + o * EDIM);
@@ -1094,9 +1110,34 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 constexpr int QC10 = TF <= 16 ? MCD_TL_QC10 : (TF == 24 && NWAVES == 12) ? MCD_TL_QC10_24 : 0;
                 MixLongCoef<16, 17, TP, NB, QC10> mc10;      // (the mix's first coefficients: in flight behind the product)
                 mc10.load(wb + Ns->tq[10], wb + Ns->am[10], wave, lane);
-                // the weights [4][32] from LDS at wave-uniform addresses (broadcast reads).  Read through the laundered weight pointer
-                // they were 32 flat_load_dwordx4 per column, each behind an s_waitcnt vmcnt(0) lgkmcnt(0) of its own (a flat load
-                // ticks both counters): 32 serial L2 round trips, 5 % of a pass for 0.1 % of its arithmetic
+                // P4[col][0 .. 3] = [W_t; W_r] (4 x 32) . X[col][0 .. 31].  Round 4 ran it as plain FMAs per column (a 16-row MFMA tile is 3/4
+                // padding): with the weights read through the laundered (generic) weight pointer that was 32 serial flat loads per column,
+                // 5 % of a pass; from LDS at wave-uniform addresses it is LDS-bound (40 ds_read_b128 per column on 7 of the 12 waves:
+                // 1.6 % of a pass).  On the matrix cores the padding is free -- 26 tiles x 8 MFMAs at 24 frames -- and a tile costs two
+                // B-operand reads: A = the weights' rows 0 .. 3 (zero rows below), K in the order (16 jj + 4 g + r) for both operands.
+#if MCD_TL_L10_MFMA
+                {
+                    const int j = lane & 15, g = lane >> 4;
+                    float4 af[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        af[jj] = j < 4 ? *reinterpret_cast<const float4*>(W4L + j * 32 + 16 * jj + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    constexpr int NT10 = (R17 + 15) / 16;
+                    for (int nt = wave; nt < NT10; nt += NWAVES) {
+                        const float* xp = RA + (nt * 16 + j) * 36 + 4 * g;      // layer 9's output, handed over in LDS (pad rows: finite)
+                        const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 16);
+                        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0].x, x0.x, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0].y, x0.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0].z, x0.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0].w, x0.w, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1].x, x1.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1].y, x1.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1].z, x1.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1].w, x1.w, acc, 0, 0, 0);
+                        if (g == 0 && nt * 16 + j < R17) *reinterpret_cast<float4*>(P4 + (nt * 16 + j) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    }
+                }
+#else
                 for (int col = tid; col < R17; col += NTHREADS) {
                     const float* xp = RA + col * 36;          // layer 9's output, handed over in LDS
                     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1112,7 +1153,9 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     }
                     *reinterpret_cast<float4*>(P4 + col * 4) = make_float4(a[0], a[1], a[2], a[3]);
                 }
+#endif
                 __syncthreads();
+                TLMARK(55);                            // layer 10: W-first product
                 // its 2-channel mix (16-channel block view of P4: channels 2..15 are the next columns' values, never stored)
                 mix_long<16, 17, TP, NB, 1, QC10>(P4, 4, mc10, wb + Ns->tq[10], wb + Ns->am[10], wave, lane, ZeroInitL{},
                                      [&](int q, int w0, int c, auto v) {
@@ -1128,8 +1171,10 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                                          }
                                      });
                 __syncthreads();
+                TLMARK(56);                            // layer 10: mix
                 // eps = layer 10 + x; DDPM update of the frame each prediction drives (mocodad.py:172-178,829-838)
                 const float slope10 = Ns->slope[10], ca = srow[0], cb = srow[1], csg = srow[2];
+                const float b10[C0] = {as_global(wb)[Ns->bias[10]], as_global(wb)[Ns->bias[10] + 1]};
                 const bool zadd = sidx > 1;
                 constexpr int NIT = (C0 * TF * 17 + NTHREADS - 1) / NTHREADS;
                 float xn[NIT];
@@ -1140,7 +1185,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     dst[it] = -1; xn[it] = 0.f;
                     if (u < TF * 17 * C0) {
                         const int c = u % C0, col = u / C0, f = col / 17, i = f / TP, t = f % TP, v = col % 17;
-                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + wb[Ns->bias[10] + c], slope10) + EMB[i * EMBS + emb_off(10) + c];
+                        const float l10 = prelu(ZO[u] + P4[col * 4 + C0 + c] + (c ? b10[1] : b10[0]), slope10) + EMB[i * EMBS + emb_off(10) + c];
                         const float eps = l10 + XT[col * 4 + c];
                         if constexpr (LT) {      // layer 10 alone: without the U-Net's residual (+ x)
                             if (t < T && grp * NB + i < P.n_chains) P.lt_out[(((size_t)b_of(i) * C0 + c) * T + t) * 17 + v] = l10;
@@ -1149,9 +1194,10 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                             if (t < T && P.eps_out && grp * NB + i < P.n_chains) P.eps_out[(((size_t)b_of(i) * C0 + c) * T + t) * 17 + v] = eps;
                             continue;
                         }
-                        const int k = t >= T ? -1 : P.win_mask ? (((fixed_of(i) >> t) & 1u) ? -1 : 0) : M.upd_of[t];
+                        const int tpm = UPDT[t];                             // (LDS: M.upd_of[t] -> M.pos_of[k] were two dependent global loads per element)
+                        const int k = t >= T ? -1 : P.win_mask ? (((fixed_of(i) >> t) & 1u) ? -1 : 0) : tpm;
                         if (k >= 0) {
-                            const int tp = P.win_mask ? t : M.pos_of[k];
+                            const int tp = P.win_mask ? t : tpm;
                             const int colp = (i * TP + tp) * 17 + v;
                             xn[it] = ca * (XT[colp * 4 + c] - cb * eps) + csg * (zadd ? ZN[colp * C0 + c] : 0.f);
                             dst[it] = colp * 4 + c;

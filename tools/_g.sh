@@ -1,1 +1,3 @@
-timeout 1200 python -m pytest tests/test_layers_gpu.py tests/test_extra6_gpu.py -m gpu -q 2>&1 | tail -4
+mkdir -p gpurun_out/r05ze
+bash tools/ab_bench.sh "--config concat32" mocodad_amd/lib_e0.so mocodad_amd/lib_e1.so > gpurun_out/r05ze/tiled32_l10mfma_ab.txt 2>&1
+cat gpurun_out/r05ze/tiled32_l10mfma_ab.txt

@@ -45,8 +45,8 @@ for wv, off in ((0, 2048), (7, 2048 + 64)):
     for l in range(3, 10):
         v = p[40 + 2 * (l - 3):42 + 2 * (l - 3)]
         print(f"  {lname[l]:4s} {v[0]:10.0f} {v[1]:9.0f}   {100 * v.sum() / tot:5.1f}%")
-    for i, n in [(54, "L10 + update"), (60, "pass prologue"), (61, "layer tails")]:
-        print(f"  {n:14s} {p[i]:12.0f}   {100 * p[i] / tot:5.1f}%")
+    for i, n in [(55, "L10 product"), (56, "L10 mix"), (54, "L10 tail+update"), (58, "prologue: SiLU, noise"), (60, "prologue: emb rows"), (61, "layer tails")]:
+        print(f"  {n:22s} {p[i]:12.0f}   {100 * p[i] / tot:5.1f}%")
 
 # per-wave event trace of one pass (profile builds of score_tiled_kernel stamp it, see TLTR): for every event the spread of the
 # waves' arrival, relative to the pass's first stamp
