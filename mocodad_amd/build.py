@@ -122,7 +122,12 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
         if verbose:
             print(f"+ {HIPCC} {' '.join(flags)} -c  x {len(todo)} translation units, {workers} at a time", flush=True)
         with cf.ThreadPoolExecutor(max_workers=workers) as ex:
-            futs = {ex.submit(_compile, [HIPCC] + flags + f + ["-c", s], os.path.join(obj_dir, o)): o for o, s, f in todo}
+            # -cuid: clang derives a compilation-unit id from the command line INCLUDING the output path and bakes it into the object
+            # (names of the fat-binary handles): with the private temporaries above every build had its own library hash, and the
+            # profile manifests (tools/profile_set.sh, bench.py's PMC check) could never match a rebuilt library.  A fixed id per
+            # (object, flag set) makes the library a function of the sources and flags alone.
+            cuid = lambda o: "-cuid=mcd_" + tag + "_" + re.sub(r"[^A-Za-z0-9]", "_", o)
+            futs = {ex.submit(_compile, [HIPCC] + flags + f + [cuid(o), "-c", s], os.path.join(obj_dir, o)): o for o, s, f in todo}
             for fu in cf.as_completed(futs):
                 dt = fu.result()
                 if verbose:

@@ -8,8 +8,9 @@ namespace mcd {
 // MFMA path for 12 < T_u <= 32 U-Net frames (concat over 24 frames, 16 + 16, ...): the activations of such a chain do not
 // fit LDS (257 KB at layer 5 of a 24-frame chain), so the chain lives in a slab of global memory (L2 / Infinity Cache) and a
 // layer is "32 input channels of ALL frames -> LDS -> mix -> channel GEMM -> slab", one 512-thread workgroup per CU:
-//   X      one 32-channel part of the layer's input, every frame, staged slab -> registers -> LDS (the next part's loads in
-//          flight behind this part's stages).  The four joint resamplers are not stages of their own: the layer behind one
+//   X      one 32-channel part of the layer's input, every frame, staged slab -> registers -> LDS (the next part's loads go out
+//          right before this part's channel GEMM -- NOT in front of its mixes: vector-memory loads return in order, and the
+//          mixes' in-place coefficient fetches wait with vmcnt(0); round 5, DESIGN.md 2.3 "in-order returns").  The four joint resamplers are not stages of their own: the layer behind one
 //          builds its X from the resampler's input rows (chunk of frames by chunk, resample_stage LDS -> LDS, + the U-Net skip)
 //   mix    both halves on the matrix cores: tl_time_mix (the (frames x frames) time mix of a joint as one MFMA product, Tq
 //          pre-packed as A fragments) writes Y to LDS, tl_joint_mix turns it into z in place.  z never leaves LDS

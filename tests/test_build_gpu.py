@@ -1,6 +1,6 @@
 """GPU box: the committed sources build from scratch with the box's own toolchain (`__graft_entry__.build(force=True)` into a
 scratch path: every translation unit recompiled, nothing taken from the prebuilt library or the object cache) and the result
-reproduces a reference-generated trajectory -- what is committed is what runs."""
+reproduces a reference-generated trajectory AND is byte-identical to the shipped library -- what is committed is what runs."""
 import ctypes as C
 import json
 import os
@@ -20,6 +20,12 @@ def test_fresh_build_loads_and_scores(tmp_path):
     out = str(tmp_path / "libmocodad_hip_fresh.so")
     G.build(force=True, out=out)
     assert os.path.getsize(out) > 500_000
+    # the build is reproducible: compiled again, anywhere, from the same sources the library is the SAME file (fixed -cuid per
+    # object in mocodad_amd/build.py) -- the profile manifests of tools/profile_set.sh and bench.py's PMC check rely on that
+    import hashlib
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    if os.environ.get("MCD_LIB") is None:
+        assert sha(out) == sha(_lib.LIB_PATH), "the shipped libmocodad_hip.so is not what the committed sources build"
     # the fresh library exports the whole C ABI of include/mocodad_hip.h ...
     fresh = C.CDLL(out)
     for name in _lib.EXPORTS:
