@@ -194,3 +194,23 @@ def test_window_views_materialize_like_the_reference_dataset():
     m2 = tw2.materialize()
     assert len(tw2) == 5 and tw2.frames[2].tolist() == [7, 8, 9, 10, 11, 12] and tw2.meta[2].tolist() == [1, 2, 1, 7]
     assert torch.equal(m2[2, 1, 0], torch.from_numpy(long[(1, 2, 1)][1][2, 1]))
+
+
+def test_build_is_reproducible_across_output_paths(tmp_path):
+    """The library must be a function of the sources and flags alone: tools/profile_set.sh stamps its sha256 into every profile
+    and bench.py attaches PMC numbers only to the library they were taken on.  clang bakes a compilation-unit id derived from the
+    command line -- output path included -- into each object; mocodad_amd/build.py pins it (-cuid).  One small unit of kernel
+    instantiations compiled to two different paths (as two builds with private temporaries do) must give the same object."""
+    import subprocess
+    from mocodad_amd import build as B
+    flags = B.BASE_FLAGS + ["-DMCD_INST_UNIT=22"]
+    src = os.path.join(B.CSRC, "mcd_inst.hip")
+    outs = [str(tmp_path / "a" / "unit.o"), str(tmp_path / "b" / "unit.o.tmp4242")]
+    for o in outs:
+        os.makedirs(os.path.dirname(o))
+        subprocess.run([B.HIPCC] + flags + ["-cuid=mcd_test_unit22", "-c", src, "-o", o], check=True, cwd=B.ROOT,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert open(outs[0], "rb").read() == open(outs[1], "rb").read()
+    # ... and build_library passes such an id for every object it compiles
+    import inspect
+    assert "-cuid=" in inspect.getsource(B.build_library)
