@@ -76,6 +76,10 @@ __host__ __device__ constexpr int ss_of(int c) { return MCD_TL_DENSE ? c : c + 4
 #define MCD_TL_PRE32 0      // (32 frames: 111 spilled registers already; -0.8 .. -2 % with them)
 #endif
 __host__ __device__ constexpr int tl_pre(int TF) { return TF <= 16 ? MCD_TL_PRE16 : TF == 24 ? MCD_TL_PRE24 : MCD_TL_PRE32; }
+#ifndef MCD_TL_L5_W2
+#define MCD_TL_L5_W2 1
+#endif
+template <class T> struct TlType { using type = T; };
 #ifndef MCD_TL_L10_MFMA
 #define MCD_TL_L10_MFMA 1
 #endif
@@ -842,10 +846,27 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                 constexpr bool AQ = NH > 2;
                 constexpr int KQA = (CIN / 16) * (RES ? 2 : 1);
                 const int mt = wave % MT, ng = MT > NWAVES ? 0 : (wave / MT < TI::NG ? wave / MT : NT), c0 = mt * 16 + 4 * (lane >> 4);
-                LayerAfr<AQ ? 1 : KQA> A;
+                // Layer 5 (64 -> 128) on TWELVE waves: its 8 m-tiles gave 8 waves one m-tile x ALL n-tiles each -- 60 / 80 accumulator
+                // registers per lane at 24 / 32 frames, held across the staging and the mixes of the second 32-channel part, i.e. parked
+                // in scratch there (16 / 111 spilled registers, every reload an in-order load in the middle of a stage), and four
+                // waves without a tile.  W2: 4 m-tile pairs x 3 n-thirds -- every wave the m-tiles (wave % 4) and (wave % 4) + 4 on
+                // the n-tiles wave / 4 + 3 i: 2 x 5 / 2 x 7 accumulators, the part's weight fragments (2 x 4 float4) fetched per part.
+                // 32 frames: 106 -> 58 spilled registers, 0.473 .. 0.517 run to run -> a steady 0.518 .. 0.520 (the spill traffic made
+                // the kernel erratic; profiles/r05zi_tiled32_l5w2_ab2.txt).  24 frames: 16 -> 0 spilled registers and -1.1 %: off there.
+                constexpr bool W2 = MCD_TL_L5_W2 && TF == 32 && L == 5 && MT == 8 && NWAVES == 12 && FS == 1 && RES && NH == 2;
+                using TI2 = Tiling<4, NT>;
+                static_assert(!W2 || (TI2::NG == 3 && !HOR && !HOC && !HO17), "");
+                float4 aq2[W2 ? 2 : 1][W2 ? 2 * KH : 1];
+                float4 bq2[2];
+                f32x4 acc2[W2 ? 2 : 1][W2 ? TI2::MAXN : 1];
+                const int mp2 = wave & 3, ng2 = wave >> 2;
+                LayerAfr<(AQ || W2) ? 1 : KQA> A;
                 float4 aq[AQ ? 2 * KH : 1];
                 const float* wfr = wb + Nl->wp[L] + ((size_t)mt * KQA * 64 + lane) * 4;
-                if constexpr (!AQ) {
+                if constexpr (W2) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) bq2[s2] = load_global4(wb + Nl->bias[L] + (mp2 + 4 * s2) * 16 + 4 * (lane >> 4));
+                } else if constexpr (!AQ) {
                     LayerW lw;
                     lw.wp = Nl->wp[L]; lw.bias = Nl->bias[L];
                     A.template load<MT>(wb, lw, wave, lane);
@@ -921,6 +942,17 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                         }
                         Xl = XA;
                     }
+                    if constexpr (W2) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const float* w2 = wb + Nl->wp[L] + ((size_t)(mp2 + 4 * s2) * KQA * 64 + lane) * 4;
+#pragma unroll
+                            for (int k = 0; k < KH; ++k) {
+                                aq2[s2][k] = load_global4(w2 + (h * KH + k) * 256);
+                                aq2[s2][KH + k] = load_global4(w2 + (CIN / 16 + h * KH + k) * 256);
+                            }
+                        }
+                    }
                     if constexpr (AQ) {
                         static_assert(!AQ || RES, "");
 #pragma unroll
@@ -934,6 +966,11 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                     TLMARK(4 * L);
                     auto gemm_fg = [&](int fg, f32x4 (&ac)[TI::MAXN]) {
                         const float* xg = Xl + fg * ROWSG * CSV;
+                        if constexpr (W2) {
+                            gemm_part<4, NT, KH, KH, 0, KH, h == 0>(aq2[0], ZA, CSZ, xg, CSV, wave, lane, acc2[0]);
+                            gemm_part<4, NT, KH, KH, 0, KH, h == 0>(aq2[1], ZA, CSZ, xg, CSV, wave, lane, acc2[1]);
+                            return;
+                        }
                         // (part 0 starts the accumulators: gemm_part's FIRST)
                         if constexpr (AQ) gemm_part<MT, NT, KH, KH, 0, KH, h == 0>(aq, ZA, CSZ, xg, CSV, wave, lane, ac);
                         else if constexpr (RES) gemm_part<MT, NT, KH, KH, h * KH, CIN / 16 + h * KH, h == 0>(A.a, ZA, CSZ, xg, CSV, wave, lane, ac);
@@ -952,12 +989,13 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                         }
                     };
                     // epilogue: bias, PReLU, embedding -> slab, or -> the X region (the next layer's input, row stride 36)
-                    auto epi_fg = [&](int fg, const f32x4 (&ac)[TI::MAXN]) {
-                        const float4 bcur = A.bcur;
-                        static_for<TI::MAXN>([&](auto ii) {
+                    auto epi_core = [&](auto tgc, int fg, const int mt, const int ng, const float4 bcur, const auto& ac) {
+                        using TG = typename decltype(tgc)::type;
+                        const int c0 = mt * 16 + 4 * (lane >> 4);
+                        static_for<TG::MAXN>([&](auto ii) {
                             constexpr int i = decltype(ii)::value;
-                            const int col = ng * 16 + (lane & 15) + i * TI::NG * 16;
-                            if (ng + i * TI::NG < NT && col < ROWSG) {
+                            const int col = ng * 16 + (lane & 15) + i * TG::NG * 16;
+                            if (ng + i * TG::NG < NT && col < ROWSG) {
                                 const int gcol = fg * ROWSG + col;
                                 float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
                                 if constexpr (!COND) e = *reinterpret_cast<const float4*>(EMB + (NB > 1 ? gcol / (TP * V) : 0) * EMBS + emb_off(L) + c0);
@@ -972,6 +1010,14 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
                                 if (HOC2 && gcol >= TL_FC * V) *reinterpret_cast<float4*>(EX + (gcol - TL_FC * V) * 36 + c0) = o;
                             }
                         });
+                    };
+                    auto epi_fg = [&](int fg, const f32x4 (&ac)[TI::MAXN]) {
+                        if constexpr (W2) {
+                            epi_core(TlType<TI2>{}, fg, mp2, ng2, bq2[0], acc2[0]);
+                            epi_core(TlType<TI2>{}, fg, mp2 + 4, ng2, bq2[1], acc2[1]);
+                        } else {
+                            epi_core(TlType<TI>{}, fg, mt, ng, A.bcur, ac);
+                        }
                     };
                     if constexpr (HO17 || L == 2) {
                         static_assert(!(HO17 || L == 2) || (FS == 2 && NH == 1 && COUT <= 32), "");
