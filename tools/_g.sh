@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r05zi
-{ bash tools/ab_bench.sh "--config concat32" mocodad_amd/lib_e0.so mocodad_amd/lib_e1.so; bash tools/ab_bench.sh "--config concat32" mocodad_amd/lib_e0.so mocodad_amd/lib_e1.so; } > gpurun_out/r05zi/tiled32_l5w2_ab2.txt 2>&1
-cat gpurun_out/r05zi/tiled32_l5w2_ab2.txt
+mkdir -p gpurun_out/r05zf
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05zf/pytest_gpu.txt
+cat gpurun_out/r05zf/pytest_gpu.txt
+cp gpurun_out/parity_errors.txt gpurun_out/r05zf/parity_errors.txt
+bash tools/profile_set.sh r05zz '' 8ecfb27 > gpurun_out/profile_set.log 2>&1; tail -3 gpurun_out/profile_set.log
