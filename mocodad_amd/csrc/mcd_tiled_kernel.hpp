@@ -73,7 +73,7 @@ __host__ __device__ constexpr int ss_of(int c) { return MCD_TL_DENSE ? c : c + 4
 #define MCD_TL_PRE24 7
 #endif
 #ifndef MCD_TL_PRE32
-#define MCD_TL_PRE32 0      // (32 frames: 111 spilled registers already; -0.8 .. -2 % with them)
+#define MCD_TL_PRE32 7      // (32 frames: -0.8 .. -2 % while layer 5 held 80 accumulators per lane; +1.5 % since it runs on twelve waves, profiles/r05zj_tiled32_pre_w2_ab.txt)
 #endif
 __host__ __device__ constexpr int tl_pre(int TF) { return TF <= 16 ? MCD_TL_PRE16 : TF == 24 ? MCD_TL_PRE24 : MCD_TL_PRE32; }
 #ifndef MCD_TL_L5_W2
