@@ -452,8 +452,8 @@ def sustained_run(launch, seconds, est_step_ms, windows_per_step, flop_per_windo
     ends = np.array([ev[0].elapsed_time(e) for e in ev[1:]])               # ms since the start of the region
     step = np.diff(np.concatenate([[0.0], ends]))
     total_ms = float(ends[-1])
-    first = int(np.searchsorted(ends, 1000.0)) + 1
-    last = n_steps - int(np.searchsorted(ends, total_ms - 1000.0))
+    first = min(int(np.searchsorted(ends, 1000.0)) + 1, n_steps)        # (a region shorter than 1 s: the whole of it, both ways)
+    last = min(n_steps - int(np.searchsorted(ends, total_ms - 1000.0)), n_steps)
     rate = lambda n, ms: windows_per_step * n / (ms * 1e-3)
     r_first = rate(first, float(ends[first - 1]))
     r_last = rate(last, total_ms - float(ends[n_steps - last - 1]) if last < n_steps else total_ms)
@@ -696,15 +696,19 @@ def main():
     if args.warmup > 0:
         run(sc, args.warmup, 0)
     barrier()
-    sampler = GpuSampler(dev_index, 0.05) if (rank == 0 and not args.no_extras) else None      # (a host thread; does not touch the stream)
-    if sampler:
-        sampler.__enter__()
+    # Nothing but the launch loop runs on the host inside the timed region (a clock / power sampler thread here would contend
+    # for the GIL with the launches and make default runs differ from --no-extras runs: ADVICE r5); the shader clock and the
+    # socket power are read ONCE right behind the closing barrier, and sampled over time in the `sustained` leg only.
     t0 = time.perf_counter()
     best = run(sc, args.steps, 100, ev)
     barrier()
     dt_local = time.perf_counter() - t0
-    if sampler:
-        sampler.__exit__()
+    gpu_after = None
+    if rank == 0 and not args.no_extras:
+        smp = GpuSampler(dev_index, 0.05)
+        clk_, pw_ = smp._read()
+        gpu_after = {"source": smp.source, "sclk_mhz": round(clk_, 1) if clk_ else None, "socket_power_w": round(pw_, 1) if pw_ else None,
+                     "note": "one reading right behind the timed region's closing barrier (no sampler thread runs during it)"}
     dt = dt_local
     step_ms = [a.elapsed_time(b) for a, b in ev]
     kern_ms = float(np.mean(step_ms)) if B > 0 else 0.0
@@ -770,7 +774,7 @@ def main():
             "step_ms_median": round(float(np.median(step_ms)), 4) if B > 0 else None,
             "step_ms_pct": ({"p5": round(float(np.percentile(step_ms, 5)), 4), "p50": round(float(np.percentile(step_ms, 50)), 4),
                              "p95": round(float(np.percentile(step_ms, 95)), 4)} if B > 0 else None),
-            "gpu_during_timed_region": sampler.summary() if sampler else None,
+            "gpu_after_timed_region": gpu_after,
             "step_ms_first": [round(float(v), 4) for v in step_ms[:4]] if B > 0 else None,
             "step_ms_max": [round(float(np.max(step_ms)), 4), int(np.argmax(step_ms))] if B > 0 else None,    # [ms, step index]
             "roofline": {"bound": "mfma", "kernel": kname + (" (condition encoder and aggregation inside: one launch per step)" if one_launch and enc_inside

@@ -71,6 +71,17 @@ def usable_flags(flags: List[str]) -> List[str]:
     return out
 
 
+def toolchain_id() -> str:
+    """One line naming the compiler that builds the library (`hipcc --version`: HIP version + clang version lines)."""
+    p = subprocess.run([HIPCC, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    keep = [l.strip() for l in p.stdout.splitlines() if l.startswith(("HIP version", "AMD clang version", "clang version"))]
+    return " | ".join(keep) or p.stdout.strip()[:200]
+
+
+def buildinfo_path(out: str) -> str:
+    return out + ".buildinfo"
+
+
 def _compile(cmd: List[str], obj: str) -> float:
     """Compile into a private temporary and rename it into place: concurrent builds (several ranks calling build() at once)
     never see, or link, a half-written object."""
@@ -138,6 +149,14 @@ def build_library(out: str = DEFAULT_OUT, defines: Iterable[str] = (), extra_fla
         tmp = out + ".tmp%d" % os.getpid()
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
         os.replace(tmp, out)        # (atomic: a concurrent reader never maps a half-written library)
+        # what built it, next to it (git-ignored like the library, travels with it): tests/test_build_gpu.py compares a fresh
+        # build byte for byte with the shipped file only when the box's toolchain is this one and no per-unit flag was dropped
+        want = unit_flags()
+        dropped = sorted({" ".join(f) for u, f in want.items() if not fast and uf.get(u, []) != f})
+        import json
+        with open(buildinfo_path(out) + ".tmp%d" % os.getpid(), "w") as fh:
+            json.dump({"toolchain": toolchain_id(), "flags": flags, "dropped_unit_flags": dropped}, fh)
+        os.replace(buildinfo_path(out) + ".tmp%d" % os.getpid(), buildinfo_path(out))
         if verbose:
             print(f"+ linked {os.path.relpath(out, ROOT)}  ({time.perf_counter() - t0:.1f} s)", flush=True)
     return relink

@@ -184,9 +184,13 @@ __device__ __forceinline__ SampleVals stage_samples(const float* src, long long 
 // Order statistics by rank counting: sample i's rank = #{k : x_k < x_i or (x_k == x_i and k < i)} is a permutation of
 // 0 .. S-1 whatever the ties; lane l ranks the samples l, l + 64, ...; the samples of rank r0 / r1 land in slot[0] / slot[1].
 // (No sort, no per-thread array: O(S^2 / 64) broadcast reads per lane.)  All lanes return the same pair.
+// A NaN among the samples (a diverged chain) breaks the permutation -- every NaN ranks 0 and the rank asked for may have no
+// writer -- and torch.median / torch.quantile return NaN then (mocodad.py:489-492,513-516): so does this, for both values.
 __device__ __forceinline__ void wave_rank_select(const SampleVals& X, int S, int lane, int r0, int r1, float* slot, float& v0, float& v1) {
+    bool nan = false;
     for (int i = lane; i < S; i += 64) {
         const float x = X(i);
+        nan |= x != x;
         int r = 0;
         for (int k = 0; k < S; ++k) {
             const float y = X(k);
@@ -196,7 +200,9 @@ __device__ __forceinline__ void wave_rank_select(const SampleVals& X, int S, int
         if (r == r1) slot[1] = x;
     }
     __syncthreads();
-    v0 = slot[0]; v1 = slot[1];
+    const bool any_nan = __ballot(nan) != 0ull;        // (one 64-lane wave per workgroup: aggregate_kernel's launch bound)
+    v0 = any_nan ? __builtin_nanf("") : slot[0];
+    v1 = any_nan ? __builtin_nanf("") : slot[1];
     __syncthreads();
 }
 // torch.median: the lower middle value; torch.quantile: linear interpolation, torch.lerp's two-sided form

@@ -367,6 +367,8 @@ __device__ __forceinline__ float aggregate_losses(float* L, int S, int strategy,
         for (int s = 0; s < S; ++s) sum += L[s];
         return sum / (float)S;
     }
+    for (int s = 0; s < S; ++s)            // torch.median / torch.quantile return NaN when a sample is NaN (a diverged chain);
+        if (L[s] != L[s]) return L[s];     // a comparison sort would leave an arbitrary finite value at the rank instead
     for (int i = 1; i < S; ++i) {          // insertion sort (S <= 64)
         const float x = L[i];
         int k = i - 1;

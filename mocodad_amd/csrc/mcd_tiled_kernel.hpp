@@ -437,8 +437,11 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
     constexpr int NG = Tiling<MT, NT>::NG, MAXN = Tiling<MT, NT>::MAXN, KQ = KQ1 + KQ2;
     const int ng = MT > NWAVES ? 0 : (wave / MT < NG ? wave / MT : NT);      // (wave counts that MT does not divide: the waves past NG x MT get no tile)
     const int j = lane & 15, g = lane >> 4;
-    const float* const p1b = b1 + __mul24(ng * 16 + j, cs1) + 4 * g;
-    const float* const p2b = b2 + __mul24(ng * 16 + j, cs2) + 4 * g;
+    // (a wave without a tile -- ng = NT -- reads its never-used read-ahead fragments from the rows of tile 0: inside the operand,
+    // not behind it.  ADVICE r5: out-of-range LDS reads do return 0 on this hardware, but nothing should rest on that.)
+    const int ngr = ng < NT ? ng : 0;
+    const float* const p1b = b1 + __mul24(ngr * 16 + j, cs1) + 4 * g;
+    const float* const p2b = b2 + __mul24(ngr * 16 + j, cs2) + 4 * g;
     constexpr int NP = (MAXN + 1) / 2;
     // first B fragment (k-group 0) of tile slot i -- read a pair ahead: the last k-group of a pair fetches the next pair's
     auto rd0 = [&](int i) { return *reinterpret_cast<const float4*>((KQ1 > 0 ? p1b + i * NG * 16 * cs1 : p2b + i * NG * 16 * cs2)); };
@@ -447,7 +450,8 @@ __device__ __forceinline__ void gemm_part(const float4 (&a)[NA], const float* __
         constexpr int p = decltype(pp)::value;
         if constexpr (p < NP) {
             constexpr int i0 = 2 * p, i1 = i0 + 1 < MAXN ? i0 + 1 : i0;
-            // (unconditional: a slot past the wave's last tile reads rows nobody uses -- LDS reads past the allocation return 0 --;
+            // (unconditional: a slot past the wave's last tile reads rows nobody uses -- at most NG - 1 tiles of rows behind the
+            // operand, which the LDS plan's regions behind it cover; a read past the allocation itself returns 0 --;
             // conditional reads made `nxt` a phi of every wave-dependent branch below and cost 2 - 8 register-pair moves per pair)
             nxt[0] = rd0(i0);
             if (i1 != i0) nxt[1] = rd0(i1);

@@ -24,8 +24,22 @@ def test_fresh_build_loads_and_scores(tmp_path):
     # object in mocodad_amd/build.py) -- the profile manifests of tools/profile_set.sh and bench.py's PMC check rely on that
     import hashlib
     sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    # ... compared only like with like: the shipped file's .buildinfo names the toolchain and the flag set that built
+    # it; another hipcc patch level, or a box whose hipcc rejected a per-unit `-mllvm` option (build.usable_flags drops it),
+    # legitimately gives other bytes -- then the functional checks below are the test and the difference is only reported
+    import warnings
+    from mocodad_amd import build as B
     if os.environ.get("MCD_LIB") is None:
-        assert sha(out) == sha(_lib.LIB_PATH), "the shipped libmocodad_hip.so is not what the committed sources build"
+        info_p, fresh_p = B.buildinfo_path(_lib.LIB_PATH), B.buildinfo_path(out)
+        info = json.load(open(info_p)) if os.path.exists(info_p) else None
+        fresh_info = json.load(open(fresh_p))
+        if info is None:
+            warnings.warn("no .buildinfo next to the shipped library: byte identity of a fresh build not checked")
+        elif info["toolchain"] != fresh_info["toolchain"] or info["dropped_unit_flags"] != fresh_info["dropped_unit_flags"]:
+            warnings.warn(f"shipped library built by {info['toolchain']!r} (dropped {info['dropped_unit_flags']}), this box has "
+                          f"{fresh_info['toolchain']!r} (dropped {fresh_info['dropped_unit_flags']}): byte identity not checked")
+        else:
+            assert sha(out) == sha(_lib.LIB_PATH), "the shipped libmocodad_hip.so is not what the committed sources build"
     # the fresh library exports the whole C ABI of include/mocodad_hip.h ...
     fresh = C.CDLL(out)
     for name in _lib.EXPORTS:
