@@ -21,6 +21,10 @@ import subprocess
 import sys
 import time
 
+# dmabuf IPC (the host driver supports no legacy IPC handles): without it RCCL across processes fails with
+# `hipIpcGetMemHandle: invalid argument`.  The boxes export it already; set before the HIP runtime loads, for any other launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 

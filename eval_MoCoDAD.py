@@ -14,6 +14,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL across processes (see bench.py); before HIP loads
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

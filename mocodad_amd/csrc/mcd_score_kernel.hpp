@@ -155,6 +155,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         const int b = window_of(threadIdx.x);
         WM[threadIdx.x] = P.win_mask ? P.win_mask[b] : (int)P.fixed_mask;
         WM[4 + threadIdx.x] = b;
+        if (threadIdx.x == 0) WM[8] = 0;      // "the trajectory that just ended diverged" (see the end of the sample loop)
     }
     // biases the W-first layers add inside their mix store functors: from LDS there, not from global memory (a global
     // load in a functor that also stores to LDS is re-issued per call: one L2 round trip per output row)
@@ -802,9 +803,21 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float l = sum / (float)per;
             if (win0 + n < Bq && loss_out) loss_out[(size_t)(win0 + n) * Sq + s] = l;
             if (s < 64) LOSSB[n * 64 + s] = l;
+            if (!(fabsf(l) <= 3.0e38f)) WM[8] = 1;       // NaN / Inf: this chain diverged
         }
     }
     bsync();        // RED (the work region) and XT are rewritten by the next sample
+    // A diverged chain (NaN / Inf activations: broken weights, or a NaN in the caller's noise tensor) leaves non-finite values in
+    // the work region, and the next trajectory of this workgroup would read some of them as PAD rows -- the joints behind a
+    // frame's last one in a mix's padded k-step, times a zero coefficient: NaN x 0 = NaN -- and come out NaN as well, where the
+    // reference's samples are independent (mocodad.py:155-180).  The region is cleared again then; the common path pays one LDS
+    // read per sample.  (Found by tests/test_samples50_gpu.py::test_fused_aggregation_with_a_diverged_sample.)
+    if (WM[8]) {
+        for (int u = tid_s; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
+        for (int u = tid_s; u < PL::ZN; u += NTHREADS) { ZN[u] = 0.f; ZO[u] = 0.f; }
+        bsync();
+        if (tid_s == 0) WM[8] = 0;
+    }
     }   // samples
 #ifdef MCD_PROFILE
     __syncthreads();

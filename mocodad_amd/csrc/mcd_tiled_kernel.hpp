@@ -573,6 +573,15 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
 #endif
     float* slab = slabs + (size_t)blockIdx.x * tl_slab_floats(TF);
     const int Tx = P.n_corrupt, K = P.ns > 2 ? P.ns - 1 : 1, per = C0 * Tx * 17;
+    // everything a chain leaves behind that the next chain of this workgroup reads before writing it (pad rows / pad frames meet
+    // zero coefficients: they must hold finite values) -- cleared at the start, and again behind a chain that DIVERGED (see below)
+    auto clear_state = [&](int t_id) {
+        for (int u = t_id; u < (int)tl_slab_floats(TF); u += NTHREADS) slab[u] = 0.f;
+        for (int u = t_id; u < (R17 + 16) * 4; u += NTHREADS) { XT[u] = 0.f; P4[u] = 0.f; }
+        for (int u = t_id; u < R17 * C0; u += NTHREADS) { ZN[u] = 0.f; ZO[u] = 0.f; }
+        for (int u = t_id; u < EXF; u += NTHREADS) EX[u] = 0.f;
+        for (int u = t_id; u < RA_F; u += NTHREADS) RA[u] = 0.f;
+    };
     for (int u = tid; u < (int)tl_slab_floats(TF); u += NTHREADS) slab[u] = 0.f;      // pad rows / pad frames: finite values
     for (int u = tid; u < (R17 + 16) * 4; u += NTHREADS) XT[u] = 0.f;
     if (tid < 64) P4[R17 * 4 + tid] = 0.f;
@@ -1265,6 +1274,7 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
         __syncthreads();
         if (COND || P.mode == 1) continue;
         // ---- loss over the corrupt frames (mocodad.py:484)
+        bool diverged = false;
         for (int i = 0; i < NB; ++i) {
             if (grp * NB + i >= P.n_chains) break;
             const long long chain = grp * NB + i;
@@ -1285,7 +1295,19 @@ __global__ __launch_bounds__(NTHREADS, (TP * NB <= 16 ? 2 : 1) * NWAVES / 4) voi
             // (tree over the next power of two: a workgroup of 12 waves has 768 threads; at 512 the order is the plain halving)
             constexpr int RP2 = NTHREADS <= 512 ? 512 : 1024;
             for (int o = RP2 / 2; o > 0; o >>= 1) { if (tid < o && tid + o < NTHREADS) RED[tid] += RED[tid + o]; __syncthreads(); }
-            if (tid == 0) P.loss_out[chain] = RED[0] / (float)per;
+            const float lsum = RED[0];                 // (every thread: the same LDS word)
+            if (tid == 0) P.loss_out[chain] = lsum / (float)per;
+            diverged |= !(fabsf(lsum) <= 3.0e38f);      // NaN / Inf
+            __syncthreads();
+        }
+        // A diverged chain (NaN / Inf activations) leaves non-finite values in the slab and the LDS regions; the NEXT chain of this
+        // workgroup -- another window, or another sample -- reads some of them as pad rows / pad frames against zero coefficients
+        // (NaN x 0 = NaN) and would come out NaN as well, where the reference's chains are independent (mocodad.py:155-180).
+        // Everything is cleared again then; the common path pays a compare per chain.
+        if (diverged) {
+            int t_c = tid0;
+            asm volatile("" : "+v"(t_c));
+            clear_state(t_c);
             __syncthreads();
         }
     }
