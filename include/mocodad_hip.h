@@ -184,7 +184,11 @@ int mcd_set_option(mcd_weights_t* w, int32_t option, int32_t value);
  *   step_table  (ns, 4+emb_dim): row i = [1/sqrt(alpha_i), (1-alpha_i)/sqrt(1-alpha_hat_i), sqrt(beta_i), 0,
  *               pos_encoding(i)[0..emb_dim)]  (mocodad.py:172-178, stsae_unet.py:173-179)
  *   loss_out    (B,S)  per-sample window loss
- *   pose_out    NULL or (B,S,C,Tx,V) generated x_0 */
+ *   pose_out    NULL or (B,S,C,Tx,V) generated x_0
+ * Chains are independent, as in the reference: a chain that diverges (NaN / Inf activations; a NaN in `noise`) returns a
+ * non-finite loss and changes no other chain's result -- the persistent kernels clear their state behind it and re-run the
+ * chains that shared its passes on their own.  PRECONDITION: `data` is finite.  (A window with non-finite poses scores NaN, as
+ * in the reference, but can take the other windows of its workgroup -- up to 4 neighbours in the batch -- with it.) */
 int mcd_score(const mcd_weights_t* w, const mcd_score_cfg_t* cfg, const float* data, const float* noise,
               uint64_t seed, int64_t first_window_id, const float* step_table, void* workspace,
               float* loss_out, float* pose_out, void* stream);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         const int b = window_of(threadIdx.x);
         WM[threadIdx.x] = P.win_mask ? P.win_mask[b] : (int)P.fixed_mask;
         WM[4 + threadIdx.x] = b;
-        if (threadIdx.x == 0) WM[8] = 0;      // "the trajectory that just ended diverged" (see the end of the sample loop)
+        if (threadIdx.x == 0) { WM[8] = 0; WM[9] = -1; }      // [8] "the trajectory that just ended diverged", [9] the chain slot that runs ALONE (-1: all) -- see the end of the sample loop
     }
     // biases the W-first layers add inside their mix store functors: from LDS there, not from global memory (a global
     // load in a functor that also stores to LDS is re-issued per call: one L2 round trip per output row)
@@ -292,7 +292,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     // embeddings of the first pass; those of pass i-1 are computed during the last layer of pass i
     auto silu_row = [&](int step, int t_id) {      // SEN[n][k] = SiLU(pe(step)[k] + cond[window of chain n][k])
         if (t_id >= 0 && t_id < NB * EDIM) {
-            const float e = P.step_table[step * (4 + EDIM) + 4 + (t_id % EDIM)] + CE[t_id];
+            const int solo = NB > 1 ? WM[9] : -1;       // (a slot that sits out a solo run: no condition, x = 0, no noise -- a benign chain)
+            const float e = P.step_table[step * (4 + EDIM) + 4 + (t_id % EDIM)] + ((solo >= 0 && t_id / EDIM != solo) ? 0.f : CE[t_id]);
             SEN[t_id] = e / (1.f + expf(-e));
         }
     };
@@ -319,10 +320,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const int n = u / TV17, t = (u / 17) % T, v = u % 17;
             const int b = WM[4 + n];
             const int fixed = WM[n];
+            const int solo = NB > 1 ? WM[9] : -1;
             float xv[C0];
 #pragma unroll
             for (int c = 0; c < C0; ++c) {
-                if (mode == 1) {
+                if (solo >= 0 && n != solo) {
+                    xv[c] = 0.f;
+                } else if (mode == 1) {
                     xv[c] = x_in ? x_in[((b * C0 + c) * T + t) * 17 + v] : 0.f;
                 } else if ((fixed >> t) & 1) {
                     xv[c] = load_coord(dv, b, c, fm_src(P, t), v, seg_len);
@@ -401,7 +405,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                 const int n = gi / (T * 9), r = gi % (T * 9), t = r / 9, v0 = (r % 9) * 2;
                 float z[4] = {0.f, 0.f, 0.f, 0.f};
                 const int fixed = WM[n];
-                if (!((fixed >> t) & 1)) {
+                const int solo = NB > 1 ? WM[9] : -1;
+                if (!((fixed >> t) & 1) && (solo < 0 || n == solo)) {
                     const int b = WM[4 + n];
                     const int tx = fm_tx(P, fixed, t);
                     const int k = P.ns - sidx;
@@ -764,7 +769,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         for (int u = tid_s; u < NB * per; u += NTHREADS) {
             const int n = u / per, e = u % per;
             const int c = e / (Tx * 17), tx = (e / 17) % Tx, v = e % 17;
-            const bool valid = win0 + n < Bq;
+            const int solo = NB > 1 ? WM[9] : -1;
+            const bool valid = win0 + n < Bq && (solo < 0 || n == solo);
             const int b = WM[4 + n];
             int tu = P.pos_of[tx];
             if (wmask) {                       // frame of the tx-th corrupt frame = tx-th clear bit of the window's mask
@@ -801,22 +807,43 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #pragma unroll
             for (int k = 0; k < 8; ++k) sum += PART[n * 8 + k];
             const float l = sum / (float)per;
-            if (win0 + n < Bq && loss_out) loss_out[(size_t)(win0 + n) * Sq + s] = l;
-            if (s < 64) LOSSB[n * 64 + s] = l;
-            if (!(fabsf(l) <= 3.0e38f)) WM[8] = 1;       // NaN / Inf: this chain diverged
+            const int solo = NB > 1 ? WM[9] : -1;
+            if (solo < 0 || n == solo) {
+                if (win0 + n < Bq && loss_out) loss_out[(size_t)(win0 + n) * Sq + s] = l;
+                if (s < 64) LOSSB[n * 64 + s] = l;
+                if (!(fabsf(l) <= 3.0e38f)) WM[8] = 1;       // NaN / Inf: this chain diverged
+            }
         }
     }
     bsync();        // RED (the work region) and XT are rewritten by the next sample
     // A diverged chain (NaN / Inf activations: broken weights, or a NaN in the caller's noise tensor) leaves non-finite values in
-    // the work region, and the next trajectory of this workgroup would read some of them as PAD rows -- the joints behind a
-    // frame's last one in a mix's padded k-step, times a zero coefficient: NaN x 0 = NaN -- and come out NaN as well, where the
-    // reference's samples are independent (mocodad.py:155-180).  The region is cleared again then; the common path pays one LDS
-    // read per sample.  (Found by tests/test_samples50_gpu.py::test_fused_aggregation_with_a_diverged_sample.)
-    if (WM[8]) {
-        for (int u = tid_s; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
-        for (int u = tid_s; u < PL::ZN; u += NTHREADS) { ZN[u] = 0.f; ZO[u] = 0.f; }
-        bsync();
-        if (tid_s == 0) WM[8] = 0;
+    // the work region.  Pad rows meet zero coefficients all over the pass -- the joints behind a frame's last one in a mix's or a
+    // resampler's padded k-step are the NEXT frame's (the next chain's) rows, stale pad columns are another layer's real ones --
+    // and NaN x 0 = NaN: the diverged chain takes (i) the other chains of this pass and (ii) every later trajectory of this
+    // workgroup with it, where the reference's chains are independent (mocodad.py:155-180).  So, behind a pass set whose loss is
+    // not finite: (ii) the region is cleared again, and (i) with several chains per workgroup the sample is run again once per
+    // chain slot, ALONE -- the other slots sit out as benign chains (x = 0, no noise, no condition) and write nothing -- so that a
+    // chain that is finite on its own gets its own loss back (bit-identical: a chain's arithmetic never depends on its
+    // neighbours' finite values).  The common path pays two LDS reads per sample.  Not covered: non-finite INPUT poses, whose
+    // window takes its workgroup partners along through the in-kernel condition encoder (include/mocodad_hip.h: inputs are finite).
+    // (Found by tests/test_samples50_gpu.py::test_a_diverged_chain_stays_alone.)
+    {
+        const int div = WM[8], solo = NB > 1 ? WM[9] : -1;
+        if (div) {
+            for (int u = tid_s; u < PL::R + PL::XT; u += NTHREADS) smem[u] = 0.f;
+            for (int u = tid_s; u < PL::ZN; u += NTHREADS) { ZN[u] = 0.f; ZO[u] = 0.f; }
+        }
+        if (NB > 1 && (div || solo >= 0)) {
+            // the joint run diverged: slot 0 alone next; a solo run: the next slot, or on to the next sample
+            const int nxt = solo < 0 ? 0 : (solo + 1 < NB ? solo + 1 : -1);
+            if (nxt >= 0) s -= P.split;                  // (the same sample again)
+            bsync();                                     // every thread has read WM[8] / WM[9]
+            if (tid_s == 0) { WM[8] = 0; WM[9] = nxt; }
+            bsync();
+        } else if (div) {
+            bsync();
+            if (tid_s == 0) WM[8] = 0;
+        }
     }
     }   // samples
 #ifdef MCD_PROFILE
