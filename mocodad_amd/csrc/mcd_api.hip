@@ -1055,10 +1055,10 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
         for (int o = 0; o < D.cout; ++o) B.buf[U.L[l].bias + o] = (float)(ft.b[o] + (D.res ? fr.b[o] : 0.0));
         // MFMA fragment order.  Logical matrix Wcat[M][K] (cinp = input channels padded to 16):
         //   mix-first layers: M = cout, K = cinp (W_t') + cinp (W_r', when the layer has a residual conv)
-        //   W-first layers 6 and 10: M = [W_t' ; W_r'] stacked (layer 10: rows 0,1 / 2,3 of one 16-row tile), K = cinp
-        const bool wfirst = (l == 6 || l == 10);
+        //   W-first layers 6, 8 and 10: M = [W_t' ; W_r'] stacked (layer 10: rows 0,1 / 2,3 of one 16-row tile), K = cinp
+        const bool wfirst = (l == 6 || l == 10 || (l == 8 && MCD_L8_WFIRST));
         const int cinp = D.cin;
-        const int M = l == 6 ? 2 * D.cout : mpad;
+        const int M = (l == 6 || (l == 8 && MCD_L8_WFIRST)) ? 2 * D.cout : mpad;
         const int Kc = wfirst ? cinp : cinp * (D.res ? 2 : 1);
         auto wt = [&](int r, int k) -> double { return (r < D.cout && k < cin) ? ft.w[(size_t)r * cin + k] : 0.0; };
         auto wr = [&](int r, int k) -> double { return (r < D.cout && k < cin) ? fr.w[(size_t)r * cin + k] : 0.0; };
@@ -1108,7 +1108,7 @@ int mcd_pack_weights(const mcd_tensor_t* tensors, int32_t n_tensors, const mcd_m
             if (!pack_mix_mfma(tm, std::string("model.") + names[l], T, D.V, B, TN.tq[l], TN.am[l], tiled_tp)) return fail(MCD_EMISSING, tm.missing);
             TN.tqm[l] = pack_time_mfma(tm.get(std::string("model.") + names[l] + ".gcn.T", (int64_t)D.V * T * T), T, D.V, tiled_tp, tl_nb(tiled_tp), B);
             TN.wp[l] = U.L[l].wp; TN.bias[l] = U.L[l].bias; TN.slope[l] = U.L[l].slope;
-            if (l == 6) {    // this kernel runs layer 6 mix-first like the others: [W_t' | W_r'] fragments (the specialised kernels' are W-first)
+            if (l == 6 || (l == 8 && MCD_L8_WFIRST)) {    // this kernel runs layers 6 and 8 mix-first like the others: [W_t' | W_r'] fragments (the specialised kernels' are W-first)
                 Folded ft, fr;
                 const std::string p6 = std::string("model.") + names[l];
                 if (!fold_conv_bn(tm, p6 + ".tcn.0", p6 + ".tcn.1", D.cout, D.cin, ft) || !fold_conv_bn(tm, p6 + ".residual.0", p6 + ".residual.1", D.cout, D.cin, fr))

@@ -23,7 +23,7 @@
 //             runs right behind each 16x16 tile
 //   resample  joint down/up-sampling per (frame, 16-channel block); the down-samplers' B operands double as the
 //             register-resident U-Net skip tensors d1/d2 that the up-samplers add back
-//   W-first   layers 6 and 10: GEMM first, then the mix on the (fewer) output channels with the layer epilogue
+//   W-first   layers 6, 8 and 10: GEMM first, then the mix on the (fewer) output channels with the layer epilogue
 //             (layer 10: + U-Net residual + DDPM update) in the mix's store functor
 // Everything is fp32 (the reverse chain amplifies error by up to 1e3).
 
@@ -81,6 +81,13 @@ __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byt
 #ifndef MCD_NWAVES
 #define MCD_NWAVES 8
 #endif
+// Layer 8 (su4.1, 64 -> 32 channels at 12 joints) W-first in score_kernel, like layers 6 and 10: mix(W X) = W mix(X), so the
+// GEMM [W_t ; W_r] X (64 rows x K = 64: as many MFMAs as [W_t | W_r] [Z ; X], 32 rows x K = 128) comes first and the mix runs on
+// the 32 OUTPUT channels instead of the 64 input ones -- half the time-mix FMAs, joint-mix MFMAs and unit overhead of that
+// stage (round 6; the packer of mcd_api.hip packs the layer's weights to match).  0: mix-first as in rounds 1-5 (A/B builds).
+#ifndef MCD_L8_WFIRST
+#define MCD_L8_WFIRST 1
+#endif
 #ifndef MCD_XB32
 #define MCD_XB32 1      // 1: the mixes' X reads of the kernels without a register cap as single ds_read_b32 (mix_stage); 2: + their Z stores
 #endif
@@ -116,7 +123,7 @@ enum { F_TQ = 0, F_AM = 1, F_WP = 2, F_BIAS = 3, F_SLOPE = 4, F_STRIDE = 8 };
 //   tab[l*8 + F_TQ]    time-mix coefficients packed 16 per VGPR for DPP row broadcast, TQD[q][r][64]:
 //                      lane 16g+i = gcn.T[v = mix_vmap(s,g)][t][q] with s*T+t = 16r+i
 //   tab[l*8 + F_AM]    MFMA A-operand fragments of A_q^T, AF[q][mt][s][64]: lane (i, g) = gcn.A[q][v=mix_vmap(s,g)][w=16mt+i]
-//   tab[l*8 + F_WP]    MFMA-packed [W_t' | W_r'] (layers 6, 10: [W_t' ; W_r'] stacked, W-first)
+//   tab[l*8 + F_WP]    MFMA-packed [W_t' | W_r'] (layers 6, 8, 10: [W_t' ; W_r'] stacked, W-first)
 //   tab[l*8 + F_BIAS]  folded bias, padded to 16
 //   tab[l*8 + F_SLOPE] PReLU slope (float bits)
 constexpr int TAB_WE = 88, TAB_BE = 89;   // WeAll[EMB_TOTAL][16], beAll[EMB_TOTAL]
@@ -1447,6 +1454,7 @@ struct Plan {
     static constexpr int UP3_out = 0;
     static constexpr int L7_in = 0, L7_z = s64b, L7_out = 2 * s64b;
     static constexpr int L8_in = 2 * s64b, L8_z = 0, L8_out = s64b;
+    static constexpr int L8_p = 0;              // W-first layer 8 (MCD_L8_WFIRST): P = [P_t | P_r] [P12][68] where z was; the layer's output replaces P_r
     static constexpr int UP2_out = cmax(s64b + s32b, 2 * s32a);      // behind layer 8's output and layer 9's (z, out)
     static constexpr int L9_in = UP2_out, L9_z = 0, L9_out = s32a;
     static constexpr int L10_in = s32a, L10_p = 2 * s32a;
@@ -1459,7 +1467,7 @@ struct Plan {
                                                      // then SiLU(pe + cond) of the NEXT pass [NB<=4][16]
     static constexpr int ZN = P17 * 2;          // this step's DDPM noise z[col][c]
     static constexpr int WM = 12;               // per chain (NB <= 4): condition-frame bitmask [0,4), window [4,8), sample [8,12)
-    static constexpr int BIA = 64 + 16;         // biases of the two W-first layers (6: 64, 10: 2), read inside their store functors
+    static constexpr int BIA = 64 + 16 + 32;    // biases of the W-first layers (6: 64, 10: 2 (+ pad), 8: 32), read inside their store functors
     static constexpr int UPD = 16;              // per (chain, U-Net frame): first column of the frame its prediction updates, or -1
     static constexpr int ZO = P17 * 2;          // layer 10's mixed output Z[col][c] between its mix and the element-wise tail
     static constexpr int TT = P17 * 2;          // per (column, coordinate) of the element-wise tail: packed (chain, frame, joint) indices

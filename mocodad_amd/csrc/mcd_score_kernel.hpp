@@ -206,6 +206,7 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     }
     if (threadIdx.x < 64) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 6 * F_STRIDE + F_BIAS) + threadIdx.x];
     else if (threadIdx.x < 64 + C0) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 10 * F_STRIDE + F_BIAS) + threadIdx.x - 64];
+    else if (threadIdx.x >= 80 && threadIdx.x < 112) BIA[threadIdx.x] = P.wbuf[tab_i(P.wbuf, 8 * F_STRIDE + F_BIAS) + threadIdx.x - 80];
     const int CTV = C0 * Tx * 17;          // elements of one generated pose
     const int K = P.ns > 2 ? P.ns - 1 : 1;  // noise slots per sample
 
@@ -607,29 +608,93 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
         lt_inject(7, RG + PL::L7_in, 68, 64, 12);
         LMix<8, T, NB> mc8;
+        RsCoef<32, 12, 17, T, NB, false> rc4;
+        LMix<9, T, NB> mc9;
+        auto stash1_back = [&] {
+            if constexpr (STASH1) {
+                const priv_float* sp = (const priv_float*)stash1_mem;
+                asm volatile("" : "+v"(sp));
+#pragma unroll
+                for (int i = 0; i < RS1::PER * RS1::SK; ++i) skip1[i] = sp[i];
+            }
+        };
+        if constexpr (MCD_L8_WFIRST) {
+            // ---- su4.0, then su4.1 (64 -> 32) W-first: P = [W_t ; W_r] X (64 rows), then out = PReLU(mix(P_t) + P_r + b) + e on the 32
+            //      output channels, in place of P_r; up2 reads it from there (row stride 68)
+            constexpr int NT = PL::P12 / 16;
+            constexpr int COLS = NB * T * 12;
+            const LayerW lw = layer_w(wb, 8);
+            float4 afr8[4];
+            MixCoef<32, 12, T, NB> mc8w;
+            layer_std<7, T, NB, LOWO>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof, nohook,
+                                [&] {
+                                    load_afrags<4, 4>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr8, 0);
+                                    if constexpr (EARLY2) mc8w.load(wb + lw.tq, wb + lw.am, wave, lane);
+                                }, WEARLY ? &A7 : nullptr);     // su4.0
+            STAGE(13);
+            lt_dump(7, RG + PL::L7_out, 68, 64, 12);
+            lt_inject(8, RG + PL::L8_in, 68, 64, 12);
+            float* Pb = RG + PL::L8_p;
+            prof.pp.thr();
+            if constexpr (!EARLY2) mc8w.load(wb + lw.tq, wb + lw.am, wave, lane);
+            auto epi8 = [&](auto ti, int col, int c0, f32x4 acc, int col0, int) {
+                constexpr int STEP = Tiling<4, NT>::NG * 16 * 68;
+                if (col < COLS) *reinterpret_cast<float4*>(Pb + __mul24(col0, 68) + c0 + decltype(ti)::value * STEP) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            };
+            gemm_tiles<4, NT, 4, 0, false, LOWO>(afr8, RG + PL::L8_in, 68, RG + PL::L8_in, 68, wave, lane, epi8, 0);
+#pragma unroll
+            for (int mi = 1; mi < Tiling<4, NT>::MW; ++mi) {
+                load_afrags<4, 4>(reinterpret_cast<const float4*>(wb + lw.wp), wave, lane, afr8, mi);
+                gemm_tiles<4, NT, 4, 0, false, LOWO>(afr8, RG + PL::L8_in, 68, RG + PL::L8_in, 68, wave, lane, epi8, mi);
+            }
+            if constexpr (EARLY2) { rs_early(rc4, 3); mix_early(mc9, 9); }      // up2's fragments, layer 9's mix coefficients
+            stash1_back();
+            bsync();
+            prof.pp.lat();
+            prof.mark(32 + 3 * 8 + 1);                                          // (the tool's "gemm" column of layer 8)
+            const float slope8 = lw.slope;
+            const float pinf8 = prelu_bound(slope8);
+            mix_stage<32, 12, T, NB, LOWO, true>(Pb, 68, mc8w, wb + lw.tq, wb + lw.am, wave, lane,
+                                     [&](int n, int q, int w0, ChIdx c, std::true_type) {   // the fragment's 4 joints of P_r at once
+                                         const float* pp = (Pb + (n * (T * 12) * 68 + q * (12 * 68) + 32 + c.cb16)) + (__mul24(w0, 68) + c.j);
+                                         // (w0 = 12: the next frame's rows, inside the region -- an MFMA's D rows are independent and those are never stored)
+                                         return f32x4{pp[0], pp[68], pp[136], pp[204]};
+                                     },
+                                     [&](int n, int q, int w0, ChIdx c, f32x4 v) {
+                                         const float bias = BIA[80 + c], e = EMB[n * EMB_STRIDE + emb_off(8) + c];
+                                         float* pp = (Pb + (n * (T * 12) * 68 + q * (12 * 68) + 32 + c.cb16)) + (__mul24(w0, 68) + c.j);
+                                         const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{bias, bias}, t1 = f32x2{v[2], v[3]} + f32x2{bias, bias};
+                                         const f32x2 m0 = t0 * slope8, m1 = t1 * slope8;
+                                         const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf8), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf8)} + f32x2{e, e};
+                                         const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf8), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf8)} + f32x2{e, e};
+                                         if (w0 < 12) { pp[0] = r0[0]; pp[68] = r0[1]; pp[136] = r1[0]; pp[204] = r1[1]; }
+                                     });
+            if constexpr (!EARLY2) rs_early(rc4, 3);
+            bsync();
+            prof.mark(32 + 3 * 8);                                              // (the tool's "mix" column: mix + epilogue)
+            STAGE(14);
+            lt_dump(8, RG + PL::L8_p + 32, 68, 32, 12);
+            lt_inject(14, RG + PL::L8_p + 32, 68, 32, 12);
+            if constexpr (!EARLY2) mix_early(mc9, 9);
+            resample_stage<32, 12, 17, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L8_p + 32, 68, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+        } else {
         layer_std<7, T, NB, LOWO>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, [&] { wearly(A8, MCD_LC(8)); }, WEARLY ? &A7 : nullptr);     // su4.0
         STAGE(13);
         lt_dump(7, RG + PL::L7_out, 68, 64, 12);
         lt_inject(8, RG + PL::L8_in, 68, 64, 12);
-        RsCoef<32, 12, 17, T, NB, false> rc4;
-        LMix<9, T, NB> mc9;
         layer_std<8, T, NB, LOWO>(wb, mc8, RG + PL::L8_in, RG + PL::L8_z, RG + PL::L8_out, EMB, wave, lane, prof,
                             [&] { rs_early(rc4, 3); },
                             [&] {
                                 if constexpr (EARLY2) mix_early(mc9, 9);
-                                if constexpr (STASH1) {
-                                    const priv_float* sp = (const priv_float*)stash1_mem;
-                                    asm volatile("" : "+v"(sp));
-#pragma unroll
-                                    for (int i = 0; i < RS1::PER * RS1::SK; ++i) skip1[i] = sp[i];
-                                }
+                                stash1_back();
                             }, WEARLY ? &A8 : nullptr);                                            // su4.1
         STAGE(14);
         lt_dump(8, RG + PL::L8_out, 36, 32, 12);
         lt_inject(14, RG + PL::L8_out, 36, 32, 12);
         if constexpr (!EARLY2) mix_early(mc9, 9);
         resample_stage<32, 12, 17, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L8_out, 36, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+        }
         wearly(A9, MCD_LC(9));
         bsync();
         STAGE(15);
