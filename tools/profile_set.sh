@@ -5,7 +5,7 @@
 # and bench.py refuses PMC numbers whose manifest hash is not that of the library it loaded.
 #   usage: gpurun -- bash tools/profile_set.sh <tag> "<configs or empty>" <git HEAD>
 set -x
-TAG=${1:-r05zz}
+TAG=${1:-r06zz}
 CFGS=${2:-"avenue stc ubnormal_concat seq24"}
 PCFGS=${2:-"avenue avenue_chainmajor stc ubnormal_concat seq24 concat24 concat32"}
 HEAD=${3:-unknown}
