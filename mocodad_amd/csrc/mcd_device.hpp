@@ -91,6 +91,9 @@ __device__ __forceinline__ float4 load_global4(const float* p) {       // 16-byt
 #ifndef MCD_XB32
 #define MCD_XB32 1      // 1: the mixes' X reads of the kernels without a register cap as single ds_read_b32 (mix_stage); 2: + their Z stores
 #endif
+#ifndef MCD_XB32_CAPPED
+#define MCD_XB32_CAPPED 1      // (round 6: +0.7 % at 3 frames, profiles/r06g_t3_variants_ab.txt) 1: the single-read form of the mixes' X reads in the register-capped trajectory kernels too; 2: + the Z stores (equal)
+#endif
 constexpr int NWAVES = MCD_NWAVES;          // waves per workgroup (8; 16 is a tuning experiment)
 constexpr int NTHREADS = NWAVES * 64;
 constexpr int C0 = 2;        // num_coords
@@ -618,7 +621,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                                           Init&& init, Store&& store) {
     using M = MixCfg<CIN, V, T, NB>;
     constexpr int KS = M::KS, KP = M::KP, MT = M::MT, CB = M::CB, QC = M::QC, NQ = M::NQ, PER = M::PER;
-    constexpr bool XB32 = FORCE && MCD_XB32;
+    constexpr bool XB32 = (FORCE || (SCORE && MCD_XB32_CAPPED)) && MCD_XB32;
     const int j = lane & 15, g = lane >> 4;
     const int voff_pair = 4 * (g & 1) + (g >> 1);
     // the X values of one unit: x[ks][t] = X[(n, t, joint of (ks, lane group))][channel cb*16 + j]
@@ -1244,7 +1247,7 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 #pragma unroll
                                      for (int r = 0; r < 4; ++r)
                                          if (w0 + r < V) {
-                                             if constexpr (FORCE && MCD_XB32 >= 2) ((volatile lds_float*)(uintptr_t)lds_addr(zp))[r * CSI] = v[r];     // (single ds_write_b32, see load_x)
+                                             if constexpr ((FORCE && MCD_XB32 >= 2) || (HASEMB && MCD_XB32_CAPPED >= 2)) ((volatile lds_float*)(uintptr_t)lds_addr(zp))[r * CSI] = v[r];     // (single ds_write_b32, see load_x)
                                              else zp[r * CSI] = v[r];
                                          }
                                  } else {

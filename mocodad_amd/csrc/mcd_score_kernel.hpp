@@ -444,7 +444,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         // each SIMD only waits): the resampler is too short to cover 36 loads per wave, and issued at its top they delayed its
         // MFMAs by ~2 k cycles
         // (6 frames: +1 % on top of the pre-barrier placement; 3 frames: -0.3 %, the 128-register budget has no room for it)
-        constexpr bool EARLY2 = (LOWO && !MCD_NO_EARLY2) || T == 6;
+#ifndef MCD_EARLY2_ALL
+#define MCD_EARLY2_ALL 0       // tuning: EARLY2 in every kernel
+#endif
+        constexpr bool EARLY2 = (LOWO && !MCD_NO_EARLY2) || T == 6 || MCD_EARLY2_ALL;
         LMix<1, T, NB> mc1;
         // layer 0 reads the chain state XT[col][4] in place (x in channels 0,1): its lanes' channels 2..15 are then other
         // columns' coordinates -- finite, and multiplied by the zero-padded K rows of the layer's weights -- so no 16-channel
