@@ -660,6 +660,17 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
         // time); it is accumulated with plain FMAs instead -- 5 per frame, partial sums over this lane group's joints
         constexpr bool J16 = V == 17;
         constexpr int MTM = J16 ? 1 : MT;            // m-tiles on the matrix cores
+        // Fragment layout (round 6): the joint mix runs as D[c][w] = sum_v Y[v][c] A_q[v][w] -- the time-mixed Y as the A operand
+        // (lane (j, g) = Y[joint of (ks, g)][channel j], the registers it is built in), the pre-packed A_q fragments as the B
+        // operand (lane (j, g) = A_q[joint of (ks, g)][w = 16 mt + j]: the same words as before, the operands swapped) -- so that
+        // a lane's D fragment holds ONE output joint w = 16 mt + j and FOUR CONSECUTIVE CHANNELS cb*16 + 4g .. + 3: one
+        // ds_write_b128 per (unit, frame) instead of four row-strided ds_write_b32 (which the compiler pairs into ds_write2_b32 with
+        // a re-basing v_add each), one ds_read_b128 for the residual fragment of a W-first layer, no per-row joint checks.
+        //   init(n, q, w, ChIdx{cb16, 4g})  -> f32x4: the accumulator's start for joint w, channels cb16 + 4g .. + 3 (ZeroInit: zeros)
+        //   store(n, q, w, ChIdx{cb16, 4g}, f32x4) for w < V (lanes of joints >= V are masked here);
+        //   store(n, q, 16, ChIdx{cb16, j}, float): joint 16 of the 17-joint layers, channel cb16 + j
+        constexpr bool ZINIT = std::is_same_v<std::decay_t<Init>, ZeroInit>;
+        static_assert(ZINIT || !J16, "a seeded accumulator (W-first layers) on a 17-joint layer: joint 16's seed is not wired up");
         f32x4 acc[QC][MTM];
         float part[QC];
 #pragma unroll
@@ -667,16 +678,10 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             part[qi] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt)
-                if (M::RAGGED && q0 + qi >= T) {
+                if ((M::RAGGED && q0 + qi >= T) || ZINIT) {
                     acc[qi][mt] = f32x4{0.f, 0.f, 0.f, 0.f};      // (the frame behind a ragged chain's last: computed on zero coefficients, never stored)
-                } else if constexpr (std::is_invocable_v<Init, int, int, int, ChIdx, std::true_type>) {
-                    acc[qi][mt] = init(n, q0 + qi, mt * 16 + 4 * g, ChIdx{cb * 16, j}, std::true_type{});   // whole fragment (masks joints >= V)
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[qi][mt][r] = 0.f;
-                        if (mt * 16 + 4 * g + r < V) acc[qi][mt][r] = init(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j);
-                    }
+                    acc[qi][mt] = init(n, q0 + qi, mt * 16 + j, ChIdx{cb * 16, 4 * g});
                 }
         }
         static_for<KS>([&](auto si) {
@@ -696,7 +701,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                 constexpr int qi = decltype(qq)::value;
 #pragma unroll
                 for (int mt = 0; mt < MTM; ++mt)
-                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.aop[qi][mt][ks], y[qi], acc[qi][mt], 0, 0, 0);
+                    acc[qi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[qi], cur.aop[qi][mt][ks], acc[qi][mt], 0, 0, 0);
                 if constexpr (J16) part[qi] = fmaf(cur.aop[qi][1][ks], y[qi], part[qi]);
             });
         });
@@ -705,15 +710,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
             if (M::RAGGED && q0 + qi >= T) continue;
 #pragma unroll
             for (int mt = 0; mt < MTM; ++mt) {
-                // a store functor that takes the whole 4-joint fragment can issue all its LDS reads before its first
-                // write (row-by-row calls serialise: every write may alias the next row's reads)
-                if constexpr (std::is_invocable_v<Store, int, int, int, ChIdx, f32x4>) {     // (the functor masks joints >= V)
-                    store(n, q0 + qi, mt * 16 + 4 * g, ChIdx{cb * 16, j}, acc[qi][mt]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (mt * 16 + 4 * g + r < V) store(n, q0 + qi, mt * 16 + 4 * g + r, cb * 16 + j, acc[qi][mt][r]);
-                }
+                if ((mt + 1) * 16 <= V || mt * 16 + j < V) store(n, q0 + qi, mt * 16 + j, ChIdx{cb * 16, 4 * g}, acc[qi][mt]);
             }
             if constexpr (J16) {
                 // sum the four lane groups' partials (lanes j, j+16, j+32, j+48): two register-swap steps
@@ -722,11 +719,7 @@ __device__ __forceinline__ void mix_stage(const float* __restrict__ in, int cs_i
                 const unsigned v2 = __float_as_uint(__uint_as_float(h[0]) + __uint_as_float(h[1]));
                 const auto f = __builtin_amdgcn_permlane16_swap(v2, v2, false, false);
                 const float z16 = __uint_as_float(f[0]) + __uint_as_float(f[1]);
-                if constexpr (std::is_same_v<std::decay_t<Init>, ZeroInit>) {
-                    if (g == 0) store(n, q0 + qi, 16, ChIdx{cb * 16, j}, z16);
-                } else {
-                    if (g == 0) store(n, q0 + qi, 16, ChIdx{cb * 16, j}, z16 + init(n, q0 + qi, 16, cb * 16 + j));
-                }
+                if (g == 0) store(n, q0 + qi, 16, ChIdx{cb * 16, j}, z16);
             }
         }
     };
@@ -1238,21 +1231,12 @@ __device__ __forceinline__ void layer_generic(const float* wb, const LayerW lw, 
 #endif
     mix_stage<CIN, V, T, NB, (FORCE && MCD_MIX_FORCE), HASEMB>(in, CSX, mc, wb + lw.tq, wb + lw.am, wave, lane,
                              ZeroInit{},
-                             [&](int n, int q, int w0, ChIdx c, auto v) {
-                                 // one LDS address per 4-joint fragment, the rows at constant offsets from it (row by row the
-                                 // compiler recomputes (.. + w) * CSI for every element: 2-3 VALU instructions per store); the
-                                 // unit's part of the address on the scalar unit, the lane's part one v_mad (see load_x)
-                                 float* zp = (z + (n * (T * V) * CSI + q * (V * CSI) + c.cb16)) + (__mul24(w0, CSI) + c.j);
-                                 if constexpr (std::is_same_v<decltype(v), f32x4>) {
-#pragma unroll
-                                     for (int r = 0; r < 4; ++r)
-                                         if (w0 + r < V) {
-                                             if constexpr ((FORCE && MCD_XB32 >= 2) || (HASEMB && MCD_XB32_CAPPED >= 2)) ((volatile lds_float*)(uintptr_t)lds_addr(zp))[r * CSI] = v[r];     // (single ds_write_b32, see load_x)
-                                             else zp[r * CSI] = v[r];
-                                         }
-                                 } else {
-                                     *zp = v;
-                                 }
+                             [&](int n, int q, int w, ChIdx c, auto v) {
+                                 // joint w's row, the lane's channels: the unit's part of the address on the scalar unit, the lane's
+                                 // part (w CSI + channel offset) one v_mad (see load_x)
+                                 float* zp = (z + (n * (T * V) * CSI + q * (V * CSI) + c.cb16)) + (__mul24(w, CSI) + c.j);
+                                 if constexpr (std::is_same_v<decltype(v), f32x4>) lds_store4(lds_addr(zp), v[0], v[1], v[2], v[3]);   // 4 channels: one ds_write_b128
+                                 else *zp = v;                                                                                       // joint 16, one channel
                              });
     prof.trace(trs + 1);
     // The NEXT stage's coefficient loads.  The vector-memory path accepts ~1 wave-wide load per 10 cycles and all eight waves

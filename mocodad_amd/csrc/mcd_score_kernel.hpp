@@ -555,22 +555,22 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope6 = lw.slope;
             const float pinf6 = prelu_bound(slope6);
             mix_stage<64, 10, T, NB, LOWO, true>(Pb, 132, mc6, wb + lw.tq, wb + lw.am, wave, lane,
-                                     [&](int n, int q, int w0, ChIdx c, std::true_type) {   // the fragment's 4 joints at once
-                                         // (address: the unit's part on the scalar unit + one v_mad for the lane's, see mix_stage)
-                                         const float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w0, 132) + c.j);
-                                         // joints >= 10 read the next frame's rows (inside the 64-column region): an MFMA's D rows
-                                         // are independent and those rows are never stored
-                                         return f32x4{pp[0], pp[132], pp[264], pp[396]};
+                                     [&](int n, int q, int w, ChIdx c) {   // P_r of joint w, the lane's 4 channels: one ds_read_b128
+                                         // (address: the unit's part on the scalar unit + one v_mad for the lane's, see mix_stage;
+                                         // joints >= 10 read the next frame's rows -- inside the 64-column region -- and are never stored)
+                                         const float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w, 132) + c.j);
+                                         const float4 r = lds_load4(lds_addr(pp));
+                                         return f32x4{r.x, r.y, r.z, r.w};
                                      },
-                                     [&](int n, int q, int w0, ChIdx c, f32x4 v) {
-                                         const float bias = BIA[c], e = EMB[n * EMB_STRIDE + emb_off(6) + c];
-                                         float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w0, 132) + c.j);
-                                         const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{bias, bias}, t1 = f32x2{v[2], v[3]} + f32x2{bias, bias};
+                                     [&](int n, int q, int w, ChIdx c, f32x4 v) {
+                                         const float4 b4 = lds_load4(lds_addr(BIA + c.cb16) + 4u * (unsigned)c.j);
+                                         const float4 e4 = lds_load4(lds_addr(EMB + n * EMB_STRIDE + emb_off(6) + c.cb16) + 4u * (unsigned)c.j);
+                                         float* pp = (Pb + (n * (T * 10) * 132 + q * (10 * 132) + 64 + c.cb16)) + (__mul24(w, 132) + c.j);
+                                         const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{b4.x, b4.y}, t1 = f32x2{v[2], v[3]} + f32x2{b4.z, b4.w};
                                          const f32x2 m0 = t0 * slope6, m1 = t1 * slope6;
-                                         const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf6), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf6)} + f32x2{e, e};
-                                         const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf6), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf6)} + f32x2{e, e};
-                                         if (w0 < 10) { pp[0] = r0[0]; pp[132] = r0[1]; }
-                                         if (w0 + 2 < 10) { pp[264] = r1[0]; pp[396] = r1[1]; }
+                                         const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf6), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf6)} + f32x2{e4.x, e4.y};
+                                         const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf6), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf6)} + f32x2{e4.z, e4.w};
+                                         lds_store4(lds_addr(pp), r0[0], r0[1], r1[0], r1[1]);
                                      });
         }
         if constexpr (STASH2) {
@@ -658,19 +658,20 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const float slope8 = lw.slope;
             const float pinf8 = prelu_bound(slope8);
             mix_stage<32, 12, T, NB, LOWO, true>(Pb, 68, mc8w, wb + lw.tq, wb + lw.am, wave, lane,
-                                     [&](int n, int q, int w0, ChIdx c, std::true_type) {   // the fragment's 4 joints of P_r at once
-                                         const float* pp = (Pb + (n * (T * 12) * 68 + q * (12 * 68) + 32 + c.cb16)) + (__mul24(w0, 68) + c.j);
-                                         // (w0 = 12: the next frame's rows, inside the region -- an MFMA's D rows are independent and those are never stored)
-                                         return f32x4{pp[0], pp[68], pp[136], pp[204]};
+                                     [&](int n, int q, int w, ChIdx c) {   // P_r of joint w, the lane's 4 channels (w >= 12: the next frame's rows, inside the region, never stored)
+                                         const float* pp = (Pb + (n * (T * 12) * 68 + q * (12 * 68) + 32 + c.cb16)) + (__mul24(w, 68) + c.j);
+                                         const float4 r = lds_load4(lds_addr(pp));
+                                         return f32x4{r.x, r.y, r.z, r.w};
                                      },
-                                     [&](int n, int q, int w0, ChIdx c, f32x4 v) {
-                                         const float bias = BIA[80 + c], e = EMB[n * EMB_STRIDE + emb_off(8) + c];
-                                         float* pp = (Pb + (n * (T * 12) * 68 + q * (12 * 68) + 32 + c.cb16)) + (__mul24(w0, 68) + c.j);
-                                         const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{bias, bias}, t1 = f32x2{v[2], v[3]} + f32x2{bias, bias};
+                                     [&](int n, int q, int w, ChIdx c, f32x4 v) {
+                                         const float4 b4 = lds_load4(lds_addr(BIA + 80 + c.cb16) + 4u * (unsigned)c.j);
+                                         const float4 e4 = lds_load4(lds_addr(EMB + n * EMB_STRIDE + emb_off(8) + c.cb16) + 4u * (unsigned)c.j);
+                                         float* pp = (Pb + (n * (T * 12) * 68 + q * (12 * 68) + 32 + c.cb16)) + (__mul24(w, 68) + c.j);
+                                         const f32x2 t0 = f32x2{v[0], v[1]} + f32x2{b4.x, b4.y}, t1 = f32x2{v[2], v[3]} + f32x2{b4.z, b4.w};
                                          const f32x2 m0 = t0 * slope8, m1 = t1 * slope8;
-                                         const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf8), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf8)} + f32x2{e, e};
-                                         const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf8), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf8)} + f32x2{e, e};
-                                         if (w0 < 12) { pp[0] = r0[0]; pp[68] = r0[1]; pp[136] = r1[0]; pp[204] = r1[1]; }
+                                         const f32x2 r0 = f32x2{__builtin_amdgcn_fmed3f(t0[0], m0[0], pinf8), __builtin_amdgcn_fmed3f(t0[1], m0[1], pinf8)} + f32x2{e4.x, e4.y};
+                                         const f32x2 r1 = f32x2{__builtin_amdgcn_fmed3f(t1[0], m1[0], pinf8), __builtin_amdgcn_fmed3f(t1[1], m1[1], pinf8)} + f32x2{e4.z, e4.w};
+                                         lds_store4(lds_addr(pp), r0[0], r0[1], r1[0], r1[1]);
                                      });
             if constexpr (!EARLY2) rs_early(rc4, 3);
             bsync();
@@ -756,16 +757,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
             const int e10_off = (sidx & 1) * 16;
             mix_stage<16, 17, T, NB, LOWO, true>(Pb, 20, mc10, wb + lw.tq, wb + lw.am, wave, lane,
                                      ZeroInit{},
-                                     [&](int n, int t, int w0, int c, auto val) {     // whole 4-joint fragments: one address, 4 stores
-                                         if (c < C0) {
-                                             float* zp = ZO + ((n * T + t) * 17 + w0) * C0 + c;
-                                             if constexpr (std::is_same_v<decltype(val), f32x4>) {
-#pragma unroll
-                                                 for (int r = 0; r < 4; ++r)
-                                                     if (w0 + r < 17) zp[r * C0] = val[r];
-                                             } else {
-                                                 *zp = val;
-                                             }
+                                     [&](int n, int t, int w, ChIdx c, auto val) {
+                                         if constexpr (std::is_same_v<decltype(val), f32x4>) {     // joint w, channels c.j .. c.j + 3: the two coordinates are lane group 0's
+                                             if (c.j == 0) *reinterpret_cast<float2*>(ZO + ((n * T + t) * 17 + w) * C0) = make_float2(val[0], val[1]);
+                                         } else {                                                  // joint 16, channel c.j
+                                             if (c.j < C0) ZO[((n * T + t) * 17 + w) * C0 + c.j] = val;
                                          }
                                      });
             bsync();
