@@ -60,7 +60,7 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 PMC passes of this round's kernels committed under profiles/ (tools/profile_set.sh): per-launch counter averages
 # of the profiled run; `roofline.traffic` and the matrix-pipe statistics of the bench line are READ from these files (they are
 # measurements of the same command under the profiler, not of this run) when the workload matches the profiled one
-PMC_SET = "r05zz"           # tools/profile_set.sh's run directory of the committed set: profiles/<PMC_SET>_<config>_pmc.txt
+PMC_SET = "r06zz"           # tools/profile_set.sh's run directory of the committed set: profiles/<PMC_SET>_<config>_pmc.txt
 PMC_PROFILES = {"avenue": (1024, 10, 5), "stc": (2048, 10, 5), "ubnormal_concat": (1024, 10, 5), "seq24": (1024, 50, 8),
                 "concat24": (1024, 10, 5), "concat32": (1024, 10, 5)}      # config -> (windows, noise_steps, samples) of the profiled command
 CLOCK_GHZ = 2.4            # the clock the FP32 peak is quoted at (256 CUs x 4 SIMDs x 64 FLOP/cycle x 2.4 GHz = 157.3 TFLOP/s)
