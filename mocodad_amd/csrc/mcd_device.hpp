@@ -803,7 +803,11 @@ struct RsCoef {
 // ILP (kernels with two waves per SIMD): the wave's units advance together, k-step by k-step -- PER independent
 // accumulator chains instead of PER dependent 4-5-MFMA chains one after the other (40 cycles of latency per link against 32
 // of issue, and nothing else on the SIMD half of the time)
-template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, bool ILP = false, int NSK>
+// SQMAP (round 6): the units follow the SAMEQ unit map of the 12-unit mixes (MixCfg::unit_of: 12 (chain, block, frame) units on 8
+// waves) instead of wave + i NWAVES -- the wave that mixes frame q of (chain, block) in a W-first layer's mix then resamples
+// exactly that frame, so no barrier separates the two stages; the matching down-sampler uses the same map so that the skip
+// registers it captures meet the up-sampler's units.
+template <int C, int VIN, int VOUT, int T, int NB, bool CAPTURE, bool ADD, bool ILP = false, bool SQMAP = false, int NSK>
 __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int cs_in, float* __restrict__ out, int cs_out,
                                                const RsCoef<C, VIN, VOUT, T, NB, CAPTURE>& rc,
                                                float (&skip)[NSK], int wave, int lane) {
@@ -819,11 +823,26 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     float xr[CAPTURE ? 1 : PER][CAPTURE ? 1 : KS] = {};      // (the down-samplers read straight into `skip`)
     // (FULL: every wave has all PER units -- said at compile time, or the conditional reads cost a copy of the whole `skip` array per unit)
     constexpr bool FULL = MCD_RS_FULL && (CAPTURE || ADD) && UNITS == PER * NWAVES;      // (score_kernel's resamplers; the slab-tiled kernel's fused ones keep the run-time test, see DESIGN)
+    // the mix whose unit map SQMAP follows (without SQMAP: a fixed valid instantiation, never used)
+    using SM = std::conditional_t<SQMAP, MixCfg<(SQMAP ? C : 32), (SQMAP ? (CAPTURE ? VOUT : VIN) : 12), (SQMAP ? T : 3), (SQMAP ? NB : 2)>, MixCfg<32, 12, 3, 2>>;
+    static_assert(!SQMAP || (SM::SAMEQ && UNITS == SM::UNITS && PER == SM::PER && !RC::ALIGNED), "SQMAP: the 12-unit SAMEQ mixes only");
+    // unit slot i of this wave -> (exists, channel block, frame)
+    auto unit_at = [&](int i, int& cb, int& nt) -> bool {
+        if constexpr (SQMAP) {
+            const int um = SM::unit_of(wave, i);
+            const int uu = um < 0 ? 0 : um, grp = uu / SM::NQ;
+            cb = grp % CB; nt = (grp / CB) * T + uu % SM::NQ;
+            return um >= 0;
+        } else {
+            const int u = wave + i * NWAVES;
+            cb = RC::ALIGNED ? wave % CB : u % CB; nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
+            return FULL || u < UNITS;
+        }
+    };
     static_for<PER>([&](auto pi) {
         constexpr int i = decltype(pi)::value;
-        const int u = wave + i * NWAVES;
-        if (FULL || u < UNITS) {
-            const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
+        int cb, nt;
+        if (unit_at(i, cb, nt)) {
             // addresses: the unit's part on the scalar unit, the lane's part one v_mad, the k-steps at instruction offsets
             // (see mix_stage's load_x)
             const float* ub = in + (nt * VIN * cs_in + cb * 16);
@@ -846,8 +865,8 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
     // the stores of one unit (+ the skip tensor of the up-samplers)
     auto finish = [&](auto pi, f32x4 (&acc)[MTM], float part) {
         constexpr int i = decltype(pi)::value;
-        const int u = wave + i * NWAVES;
-        const int cb = RC::ALIGNED ? wave % CB : u % CB, nt = RC::ALIGNED ? (wave / CB) * T + i : u / CB;
+        int cb, nt;
+        unit_at(i, cb, nt);
         if constexpr (ADD) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[0][r] += skip[i * SK + r];
@@ -891,13 +910,14 @@ __device__ __forceinline__ void resample_stage(const float* __restrict__ in, int
             });
         });
         static_for<PER>([&](auto pi) {
-            if (FULL || wave + decltype(pi)::value * NWAVES < UNITS) finish(pi, acc[decltype(pi)::value], part[decltype(pi)::value]);
+            int cb_, nt_;
+            if (unit_at(decltype(pi)::value, cb_, nt_)) finish(pi, acc[decltype(pi)::value], part[decltype(pi)::value]);
         });
     } else {
         static_for<PER>([&](auto pi) {
             constexpr int i = decltype(pi)::value;
-            const int u = wave + i * NWAVES;
-            if (FULL || u < UNITS) {
+            int cb_, nt_;
+            if (unit_at(i, cb_, nt_)) {
                 f32x4 acc[MTM];
                 float part = 0.f;
 #pragma unroll

@@ -478,7 +478,9 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         lt_dump(2, RG + PL::L2_out, 36, 32, 17);
         lt_inject(11, RG + PL::L2_out, 36, 32, 17);
         if constexpr (!EARLY2) mix_early(mc3, 3);
-        resample_stage<32, 17, 12, T, NB, true, false, (LOWO && MCD_RS_ILP)>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
+        // (SQ12: down1 / up2 take their units in the order of layer 8's W-first mix, so that up2 follows that mix without a barrier)
+        constexpr bool SQ12 = MCD_L8_WFIRST && !LT && MixCfg<32, 12, T, NB>::SAMEQ;
+        resample_stage<32, 17, 12, T, NB, true, false, (LOWO && MCD_RS_ILP), SQ12>(RG + PL::L2_out, 36, RG + PL::DN1_out, 36, rc1, skip1, wave, lane);  // down1 (captures d1)
         if constexpr (STASH1) {
             priv_float* sp = (priv_float*)stash1_mem;
             asm volatile("" : "+v"(sp));
@@ -606,7 +608,12 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         if constexpr (!EARLY2) mix_early(mc7, 7);
         resample_stage<64, 10, 12, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         wearly(A7, MCD_LC(7));
-        bsync();
+        // wave-aligned units again (round 6): with one wave per (chain, 16-channel block) in up3 AND in layer 7's mix (all T frames per
+        // unit, as many units as waves) the mix reads only what this wave just wrote -- layer 6's mix, up3 and layer 7's mix run
+        // without a barrier between them (a barrier is worth ~0.25 % of the 3-frame kernel: profiles/r06i_barrier_value_ab.txt)
+        constexpr bool FUSE_UP3_L7 = !LT && RsCfg<64, 10, 12, T, NB, false>::ALIGNED && MixCfg<64, 12, T, NB>::QC == T &&
+                                     MixCfg<64, 12, T, NB>::UNITS == NWAVES && !MixCfg<64, 12, T, NB>::SAMEQ;
+        if constexpr (!FUSE_UP3_L7) bsync();
         STAGE(12);
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
         lt_inject(7, RG + PL::L7_in, 68, 64, 12);
@@ -674,13 +681,13 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
                                          lds_store4(lds_addr(pp), r0[0], r0[1], r1[0], r1[1]);
                                      });
             if constexpr (!EARLY2) rs_early(rc4, 3);
-            bsync();
+            if constexpr (!SQ12) bsync();      // (SQ12: up2's unit (frame, block) is the one this wave's mix unit just wrote)
             prof.mark(32 + 3 * 8);                                              // (the tool's "mix" column: mix + epilogue)
             STAGE(14);
             lt_dump(8, RG + PL::L8_p + 32, 68, 32, 12);
             lt_inject(14, RG + PL::L8_p + 32, 68, 32, 12);
             if constexpr (!EARLY2) mix_early(mc9, 9);
-            resample_stage<32, 12, 17, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L8_p + 32, 68, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
+            resample_stage<32, 12, 17, T, NB, false, true, (LOWO && MCD_RS_ILP), SQ12>(RG + PL::L8_p + 32, 68, RG + PL::UP2_out, 36, rc4, skip1, wave, lane);  // up2 (+ d1)
         } else {
         layer_std<7, T, NB, LOWO>(wb, mc7, RG + PL::L7_in, RG + PL::L7_z, RG + PL::L7_out, EMB, wave, lane, prof,
                             [&] { mix_early(mc8, 8); }, [&] { wearly(A8, MCD_LC(8)); }, WEARLY ? &A7 : nullptr);     // su4.0
