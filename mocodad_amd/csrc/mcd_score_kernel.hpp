@@ -608,12 +608,11 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
         if constexpr (!EARLY2) mix_early(mc7, 7);
         resample_stage<64, 10, 12, T, NB, false, true, (LOWO && MCD_RS_ILP)>(RG + PL::L6_p + 64, 132, RG + PL::UP3_out, 68, rc3, skip2, wave, lane);  // up3 (+ d2)
         wearly(A7, MCD_LC(7));
-        // wave-aligned units again (round 6): with one wave per (chain, 16-channel block) in up3 AND in layer 7's mix (all T frames per
-        // unit, as many units as waves) the mix reads only what this wave just wrote -- layer 6's mix, up3 and layer 7's mix run
-        // without a barrier between them (a barrier is worth ~0.25 % of the 3-frame kernel: profiles/r06i_barrier_value_ab.txt)
-        constexpr bool FUSE_UP3_L7 = !LT && RsCfg<64, 10, 12, T, NB, false>::ALIGNED && MixCfg<64, 12, T, NB>::QC == T &&
-                                     MixCfg<64, 12, T, NB>::UNITS == NWAVES && !MixCfg<64, 12, T, NB>::SAMEQ;
-        if constexpr (!FUSE_UP3_L7) bsync();
+        // (up3 and layer 7's mix are both wave-aligned at 3 frames x 2 chains, and this barrier was removed in round 6 for +0.3 % --
+        // and put back: layer 7's z region [s64b, 2 s64b) overlaps layer 6's P region, which slower waves are still READING in up3;
+        // the golden tests passed, the determinism tests (same call twice, two streams) caught it.  The LDS plan has no room for a
+        // z that avoids both; profiles/r06i_barrier_value_ab.txt.)
+        bsync();
         STAGE(12);
         lt_dump(13, RG + PL::UP3_out, 68, 64, 12);
         lt_inject(7, RG + PL::L7_in, 68, 64, 12);
