@@ -390,6 +390,23 @@ def test_philox_noise_statistics_and_determinism():
     assert torch.equal(a[32:], h)
 
 
+@pytest.mark.parametrize("variant,B,S,ns", [("inject", 1024, 5, 10), ("inject", 700, 3, 6), ("concat", 512, 2, 6), ("T12", 64, 2, 4)])
+def test_repeated_calls_are_bit_identical(variant, B, S, ns):
+    """Race detector.  The trajectory kernels drop workgroup barriers wherever a stage reads only what the same wave wrote
+    (wave-aligned units); a barrier removed where SLOWER waves still read what a faster one overwrites is a race that the golden
+    tests pass (it needs the right timing) and that shows up as run-to-run differences on a busy GPU -- round 6 removed one
+    barrier too many and exactly this kind of test caught it.  Same call 12 times, full grid, both schedules: all bit-identical."""
+    sc, _, _ = _scorer(variant)
+    gen = torch.Generator().manual_seed(123)
+    data = torch.randn(B, 2, sc.seg_len, 17, generator=gen).clamp_(-3, 3).cuda()
+    for split in (0, 1):
+        sc.set_option("split", split)
+        ref = sc.score(data, n_samples=S, noise_steps=ns, seed=11)[0].clone()
+        assert torch.isfinite(ref).all()
+        for _ in range(11):
+            assert torch.equal(sc.score(data, n_samples=S, noise_steps=ns, seed=11)[0], ref), (variant, split)
+
+
 def test_overlapping_launches_on_two_streams():
     """Batches scored on alternating HIP streams (bench.py --streams 2) overlap on the GPU; each stream has its own
     condition-embedding workspace, so the results equal the one-stream ones bit for bit."""
