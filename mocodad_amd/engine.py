@@ -379,6 +379,14 @@ class FrameScoreAssembler:
         """scores (N,), trans (N,), meta (N,4), frames (N,seg_len): arrays or tensors, host or device -> pds (total,) float64
         (None if the dense (transform, clip, person) table would not fit the workspace cap: the caller falls back to the host)."""
         dev = self.device
+        # Host arrays (what processing_data hands over) are checked on the host: the same checks as torch device ops cost a lazy
+        # code-object load per op on first use (isfinite, >=, &, all, max: ~80 ms of a cold epoch end, tools/postproc_time.py)
+        ok = npers = None
+        if not torch.is_tensor(scores) and not torch.is_tensor(meta):
+            sc_h, me_h = np.asarray(scores), np.asarray(meta)
+            if sc_h.size:
+                ok = bool((np.isfinite(sc_h) & (sc_h >= 0)).all())
+                npers = int(me_h[:, 2].max()) + 1 if me_h.ndim == 2 and me_h.shape[1] == 4 else None
         as_t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, dt).contiguous()
         scores, trans, meta, frames = as_t(scores, torch.float32), as_t(trans, torch.int64), as_t(meta, torch.int64), as_t(frames, torch.int32)
         n = int(scores.numel())
@@ -387,9 +395,11 @@ class FrameScoreAssembler:
         # the scatter-max orders non-negative floats by their bit patterns: a NaN / negative / infinite window score (a
         # diverged model) must surface as an error here, not as a plausible-looking AUC (the reference's NumPy path lets the
         # NaN reach roc_auc_score, which raises)
-        if n and not bool((torch.isfinite(scores) & (scores >= 0)).all().item()):
+        if ok is None:
+            ok = (not n) or bool((torch.isfinite(scores) & (scores >= 0)).all().item())
+        if not ok:
             raise ValueError("window scores must be finite and non-negative (got NaN / inf / negative values: diverged model?)")
-        n_persons = int(meta[:, 2].max().item()) + 1 if n else 1
+        n_persons = (npers if npers is not None else int(meta[:, 2].max().item()) + 1) if n else 1
         cfg = self._cfg(max(n_persons, 1))
         need = int(self.L.mcd_frame_scores_workspace_bytes(C.byref(cfg)))
         if need > self.MAX_WORKSPACE:

@@ -402,11 +402,15 @@ class MoCoDAD(_Base):
         # The test_step loop only ENQUEUES device work: when it returns the GPU still has most of the epoch's batches in front of
         # it.  The host-side first-use work of the post-processing -- reading the ground-truth masks, building the frame tables --
         # is done NOW, under that queue, before anything below waits for the scores (it used to be a constant ~0.1 s behind them).
+        import time as _time
+        _t = [_time.perf_counter()]
+        _tick = lambda: _t.append(_time.perf_counter())
         if self.device.type == "cuda" and self.anomaly_score_frames_shift >= 1 and (self.shard is None or self.shard.rank == 0):
             try:
                 self._frame_assembler()
             except (OSError, ValueError, KeyError):
                 pass        # (no / unreadable ground truth: post_processing below reports it where it always did)
+        _tick()
         if self.shard is not None:
             # multi-GPU: every rank scored its contiguous window shard (possibly an empty one); ONE all-gather reassembles
             # the per-window scores, then rank 0 alone runs the post-processing and the AUC (the other ranks return nan)
@@ -422,11 +426,17 @@ class MoCoDAD(_Base):
             if not outs:
                 raise ValueError("no batches were scored")
             out, gt_data, trans, meta, frames = processing_data(outs)
+        _tick()
         self.last_scores = np.asarray(out)     # the (gathered) per-window scores of this epoch, in dataset order
         if self.save_tensors:
             self._save_tensors({"prediction": out, "gt_data": gt_data, "trans": trans, "metadata": meta, "frames": frames},
                                split_name=self.split, aggr_strategy=self.aggregation_strategy, n_gen=self.n_generated_samples)
         auc = self.post_processing(out, gt_data, trans, meta, frames)
+        _tick()
+        if os.environ.get("MCD_EPOCH_TIMING"):      # (diagnostic: where an epoch end's time goes)
+            import sys
+            print("epoch end: frame tables %.1f ms | collate / gather %.1f ms | post-processing + AUC %.1f ms" % tuple(
+                1e3 * (b - a) for a, b in zip(_t[:-1], _t[1:])), file=sys.stderr)
         self.log("AUC", auc)
         return auc
 
@@ -461,10 +471,17 @@ class MoCoDAD(_Base):
         out / trans / meta / frames: NumPy arrays (the reference's signature) or tensors; gt_data is unused, as in the reference."""
         from sklearn.metrics import roc_auc_score
         if self.device.type == "cuda" and self.anomaly_score_frames_shift >= 1:
+            import time as _time
+            _a = _time.perf_counter()
             asm = self._frame_assembler()
             pds = asm(out, trans, meta, frames)
+            _b = _time.perf_counter()
             if pds is not None:
-                return float(roc_auc_score(asm.gt, pds))
+                auc = float(roc_auc_score(asm.gt, pds))
+                if os.environ.get("MCD_EPOCH_TIMING"):
+                    import sys
+                    print("post-processing: frame scores %.1f ms | roc_auc_score over %d frames %.1f ms" % (1e3 * (_b - _a), len(pds), 1e3 * (_time.perf_counter() - _b)), file=sys.stderr)
+                return auc
         gts, masks = self._gt_and_masks()
         _np = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
         pds, gt = post_process_scores(_np(out), _np(trans), _np(meta), _np(frames), gts,
