@@ -129,7 +129,7 @@ def _epoch_worker(rank, world, port, gt_dir, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_epoch_end_rank0_auc(tmp_path, world):
     from mocodad_amd.data import synthetic
     from oracle import mocodad_oracle as O
@@ -149,4 +149,6 @@ def test_sharded_epoch_end_rank0_auc(tmp_path, world):
         p.join(60)
     assert abs(res[0][1] - ref) < 1e-9, (res, ref)
     assert all(np.isnan(r[1]) for r in res[1:])
-    assert [r[2] for r in res] == ([5, 4] if world == 2 else [3, 3, 3, 0])
+    # contiguous shards of ceil(n / world) windows, the tail ranks short or EMPTY (8 ranks = the node the path is built for)
+    assert [r[2] for r in res] == [hi - lo for lo, hi in (shard_range(n, r, world) for r in range(world))]
+    assert [r[2] for r in res] == {2: [5, 4], 4: [3, 3, 3, 0], 8: [2, 2, 2, 2, 1, 0, 0, 0]}[world]
