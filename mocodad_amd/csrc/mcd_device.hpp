@@ -480,13 +480,14 @@ __host__ __device__ constexpr int mix_vmap(int V, int ks, int g) {
 // ------------------------------------------------------------------------------------------------
 // mix: Z[c,q,w] = sum_v ( sum_t X[c,t,v] T[v,t,q] ) A[q,v,w]          (stsgcn.py:154-155)
 // The joint mix runs on the matrix cores: for one (chain n, output frame q, block of 16 channels)
-//     D[w][c] = sum_v A_q[v][w] * Y[v][c]        A operand = A_q^T fragments (pre-packed, from L2/L1)
-//                                                 B operand = Y[v][c], built in registers by the time mix:
+//     D[c][w] = sum_v Y[v][c] * A_q[v][w]        A operand = Y[v][c], built in registers by the time mix:
 //     Y[v][c] = sum_t X[(n,t,v)][c] * T[v][t][q]  lane (j = c, g): v = 4s + g for k-step s  (T LDS reads + T FMAs)
-// V is padded to KS*4 rows (zero weights) and 16*MT output joints.  The D fragment (lane: channel j,
-// joints 4g..4g+3) is stored to Z[(n,q,w)][c].
-// init(n,q,w,c) seeds the accumulator (0, or the residual term of a W-first layer); store(n,q,w,c,val) consumes the
-// result (plain Z store, in-place PReLU epilogue of layer 6, or the fused DDPM update of layer 10).
+//                                                 B operand = A_q fragments (pre-packed, from L2/L1): lane (j = w, g)
+// V is padded to KS*4 rows (zero weights) and 16*MT output joints.  The D fragment (lane: output joint w = j, channels
+// 4g..4g+3 of the block) is stored to Z[(n,q,w)][c .. c+3] with one ds_write_b128 (round 6; rounds 1-5 had the operands the
+// other way round: a lane held one channel x four joints, four row-strided stores).
+// init(n,q,w,c) seeds the accumulator (0, or the residual fragment of a W-first layer); store(n,q,w,c,val) consumes the
+// result (plain Z store, or the in-place PReLU epilogue of layers 6 / 8; layer 10's two channels feed the DDPM tail).
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int V, int T, int NB>
 struct MixCfg {
