@@ -16,15 +16,15 @@
 // (MCD_NWAVES): units 3, 5, 23, 11 and 12 hold ONLY the 12-frame, the 9- / 10- / 11-frame and the 24- / 32-frame (slab-tiled) trajectory kernels and build them with twelve waves per workgroup -- three per SIMD,
 // 168 registers, 12 mix units per stage, n-thirds in the 64-channel GEMMs: +2.6 % over eight waves (profiles/r04ak_t12_w12_ab.txt).
 // Its launcher (the same translation unit) launches 768 threads; nothing outside the unit depends on the wave count.
-#define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"      // (the scheduler strategy: 25 -> 19 spilled registers, +0.6 %, profiles/r04as_t12_sched_ab.txt)
+#define MCD_UNIT_FLAGS_3 "-DMCD_NWAVES=12"      // (round 4 added -mllvm -amdgpu-sched-strategy=iterative-minreg: 25 -> 19 spilled registers, +0.6 %; the kernel has spilled nothing since round 5, and the default strategy is +0.3 .. 0.4 % now: profiles/r06j_switch_sweep_ab.txt)
 #define MCD_UNIT_FLAGS_23 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"     // 9 frames: +1.3 % with it (11 frames -2.4 %, 24 / 32 frames -0.7 / -3.2 %: default strategy, profiles/r04at_minreg_ab.txt)
 #define MCD_UNIT_FLAGS_11 "-DMCD_NWAVES=12"     // the slab-tiled kernel at 24 frames: +4.5 % (profiles/r04aq_tiled_w12_ab.txt)
 #define MCD_UNIT_FLAGS_12 "-DMCD_NWAVES=12"     // ... and at 32 frames: +2.0 %
 #define MCD_UNIT_FLAGS_5 "-DMCD_NWAVES=12"      // 9, 10 and 11 frames (profiles/r04al_w12_shapes_ab.txt, r04an_t10_w12_ab.txt)
 // The layer-test (LT) forms behind mcd_layer_forward are built with the flags AND the template arguments of their production
 // twins, so that the stage tests run the shipped stage code (the twelve-wave mix tables, n-thirds tiling, skip-round branches):
-#define MCD_UNIT_FLAGS_24 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"     // LT of 12 and 9 frames (= units 3, 23)
-#define MCD_UNIT_FLAGS_25 "-DMCD_NWAVES=12"     // LT of 10 and 11 frames (= unit 5)
+#define MCD_UNIT_FLAGS_24 "-DMCD_NWAVES=12 -mllvm -amdgpu-sched-strategy=iterative-minreg"     // LT of 9 frames (= unit 23)
+#define MCD_UNIT_FLAGS_25 "-DMCD_NWAVES=12"     // LT of 10, 11 and 12 frames (= units 5, 3)
 #define MCD_UNIT_FLAGS_15 "-DMCD_NWAVES=12"     // LT of the slab-tiled kernel at 24 frames (= unit 11)
 #define MCD_UNIT_FLAGS_16 "-DMCD_NWAVES=12"     // ... and at 32 frames (= unit 12)
 
@@ -43,7 +43,7 @@
     X(22, 8, 1, 2, false) \
     X(4, 5, 1, 4, false) X(4, 7, 1, 2, false) \
     X(23, 9, 1, 3, false) X(5, 10, 1, 3, false) X(5, 11, 1, 3, false) /* twelve waves as well (unit 5): +3.7 / +0.9 / +0.9 %; 7 and 8 frames measured -1 % / +0.2 %: eight waves */ \
-    X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(24, 12, 1, 3, true) X(24, 9, 1, 3, true) \
+    X(9, 3, 2, 4, true) X(9, 6, 1, 4, true) X(25, 12, 1, 3, true) X(24, 9, 1, 3, true) \
     X(13, 5, 1, 4, true) X(13, 7, 1, 2, true) X(25, 10, 1, 3, true) X(25, 11, 1, 3, true) \
     MCD_SCORE_VARIANT_INSTANCES(X)
 

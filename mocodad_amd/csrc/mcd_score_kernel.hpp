@@ -273,8 +273,8 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
 #define MCD_STASH 0      // (round 5: nothing is hand-parked any more; bit 0 / 1: d2 / d1 of the 6-frame kernel, +1.7 % without)
 #endif
 #ifndef MCD_T6_LOWO
-#define MCD_T6_LOWO 1
-#endif
+#define MCD_T6_LOWO 0       // (round 6: off again -- with layer 8 W-first, the single-read mixes and the swapped-operand fragments in, the
+#endif                      //  plain forms are +1.2 .. 1.4 % at 6 frames, profiles/r06j_switch_sweep_ab.txt; round 5 had measured +1.1 % WITH it)
 #ifndef MCD_RELAUNDER_UP
 #define MCD_RELAUNDER_UP 1      // 0: off, 1: the register-capped kernels that spilled (see the step loop), 7: every kernel (A/B)
 #endif
