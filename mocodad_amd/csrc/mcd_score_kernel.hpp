@@ -355,7 +355,10 @@ __global__ __launch_bounds__(NTHREADS, MINW) void score_kernel(const ScoreParams
     // WEARLY: every layer's GEMM weight fragments are fetched at the end of the stage in front of the layer (see LayerAfr).
     // 3 / 4 frames only: +0.5 % there, nothing at 6 frames, -0.9 % at 12 (profiles/r03l_wearly_ab.txt) -- the larger shapes'
     // GEMM stages end with the other prefetches (EARLY2) already
-    constexpr bool WEARLY = T <= 4;
+#ifndef MCD_WEARLY
+#define MCD_WEARLY 1
+#endif
+    constexpr bool WEARLY = T <= 4 && MCD_WEARLY;
     LAfr<0> A0;
     if constexpr (WEARLY) load_lafr<0>(A0, P.wbuf, wave, lane);
     for (int sidx = i_first; sidx >= i_last; --sidx) {
